@@ -1,0 +1,82 @@
+"""ctypes binding of libbinhip.so (include/binhip.h).  The product path has NO fallback: if the
+library is missing or a call fails this raises, it never routes to PyTorch/CPU code."""
+import ctypes as C
+import os
+
+from .build import LIB_PATH
+
+RDN_LAYERS = 66
+EPI_PLANES, EPI_SHUFFLE, EPI_FINAL = 0, 1, 2
+
+
+class BinConvDesc(C.Structure):
+    _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("ksize", C.c_int32),
+                ("cin_chunks", C.c_int32), ("cout", C.c_int32), ("cout_pad", C.c_int32),
+                ("nterms", C.c_int32), ("epilogue", C.c_int32), ("relu", C.c_int32),
+                ("x_cpg", C.c_int32), ("x_group_stride", C.c_int64), ("n_images", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class BinRdnPlan(C.Structure):
+    _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("n_inputs", C.c_int32),
+                ("nterms", C.c_int32), ("reserved", C.c_int32),
+                ("w_hi", C.c_void_p * RDN_LAYERS), ("w_lo", C.c_void_p * RDN_LAYERS),
+                ("bias", C.c_void_p * RDN_LAYERS)]
+
+
+_SIGNATURES = {
+    "binhip_version": (C.c_int, []),
+    "binhip_device_cus": (C.c_int, []),
+    "binhip_conv_cout_block": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "binhip_weights_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "binhip_weights_relayout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "binhip_conv2d_fwd": (C.c_int, [C.POINTER(BinConvDesc)] + [C.c_void_p] * 10 +
+                          [C.POINTER(C.c_void_p), C.c_void_p]),
+    "binhip_nchw_to_planes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
+    "binhip_planes_to_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                        C.c_void_p]),
+    "binhip_pack_inputs": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
+    "binhip_convlstm_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                                          C.c_void_p, C.c_void_p]),
+    "binhip_charbonnier_partials": (C.c_int, [C.c_int64]),
+    "binhip_charbonnier_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p,
+                                         C.c_void_p]),
+    "binhip_charbonnier_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]),
+    "binhip_rdn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "binhip_rdn_forward": (C.c_int, [C.POINTER(BinRdnPlan), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p,
+                                     C.c_size_t, C.c_void_p]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Names every include/binhip.h entry point must resolve to (checked by the CPU test-suite)."""
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    """Load libbinhip.so (once).  Raises RuntimeError with the build hint when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"bin_amd: HIP library {LIB_PATH} not built. Run `python -c 'import __graft_entry__ as g; "
+                f"g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback by design.")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = {-1: "bad argument", -2: "unsupported shape", -3: "workspace too small"}.get(rc, f"hipError {rc}")
+        raise RuntimeError(f"bin_amd: {what} failed: {kind}")

@@ -1,0 +1,461 @@
+// binhip_conv.hip — im2col-free direct convolution on MI355X (gfx950) matrix cores.
+//
+// Stands in for every F.conv2d on the bin_stage4 path (reference models/archs/RDN.py:141 RDB_Conv,
+// :162 LFF, :187-188 SFENet1/2, :199-200 GFF, :205-207 UPNet) with the surrounding elementwise work
+// fused into the epilogue: bias, ReLU + "cat" (RDN.py:145-147: the 32 new channels are simply the
+// next two chunk planes of the dense block), residual add (RDN.py:165, :219), PixelShuffle(2)
+// (RDN.py:206) and the input-mean skip (RDN.py:221/279/333).
+//
+// Formulation: D[cout][pixel] += W[cout][tap][cin16] * X[cin16][pixel+tap] with
+// v_mfma_f32_32x32x16_f16 (A = weights, B = activations, fp32 accumulate).  A workgroup (4 wave64)
+// owns a TH x 32 pixel tile and COUTB output channels; per K-stage it DMA-copies
+// (buffer_load ... lds, 16 B/lane, zero-fill outside the image = the conv's zero padding) the
+// (TH+k-1) x (32+k-1) x 16-channel input patch and the k*k x COUTB x 16 weight slab into LDS,
+// double-buffered, then every wave runs k*k*MT*R MFMAs straight out of LDS (ds_read_b128, 16-byte
+// slots XOR-swizzled so each 16-lane read group hits 16 distinct bank slots).
+// Precision: NT=1 -> one fp16 product; NT=3 -> hi/lo split, Ah*Bh + Al*Bh + Ah*Bl (fp32 class).
+#include "binhip_internal.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+struct ConvKArgs {
+    const _Float16* x_hi;
+    const _Float16* x_lo;
+    const _Float16* w_hi;
+    const _Float16* w_lo;
+    const float* bias;
+    _Float16* y_hi;
+    _Float16* y_lo;
+    const _Float16* r_hi;
+    const _Float16* r_lo;
+    float* out_f32;
+    const float* img[5];
+    long long group_stride;   // elements
+    int N, H, W;
+    int nchunks;
+    int cpg;
+    int tiles_x, tiles_y;
+    int relu, has_res, nimg, cout;
+};
+
+template <int KS, int MT, int WM, int R, int WN, int KC, int NT, int NBUF, int EPI>
+struct ConvCfg {
+    static constexpr int PAD = KS / 2;
+    static constexpr int COUTB = 32 * MT * WM;
+    static constexpr int TH = R * WN;
+    static constexpr int PH = TH + KS - 1;
+    static constexpr int PW = 32 + KS - 1;
+    static constexpr int PP = (PH * PW * 2 + 63) / 64;   // 1-KiB DMA pieces of the patch, per chunk
+    static constexpr int WP = KS * KS * MT * WM;         // 1-KiB pieces of the weight slab, per chunk
+    static constexpr int CHUNK_BYTES = (PP + WP) * 1024;
+    static constexpr int NPL = (NT == 3) ? 2 : 1;
+    static constexpr int PLANE_BYTES = KC * CHUNK_BYTES;
+    static constexpr int BUF_BYTES = NPL * PLANE_BYTES;
+    static constexpr int LDS_BYTES = NBUF * BUF_BYTES;
+    static constexpr int NPJ = (PP + 3) / 4;
+    static constexpr int NWJ = (WP + 3) / 4;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+__device__ __forceinline__ half8 lds_ld8(const char* p) { return *reinterpret_cast<const half8*>(p); }
+
+// Issue the LDS-DMA of K-stage `st` (KC chunks x NPL planes: input patch + weight slab) into buffer `buf`.
+template <class C, int KS, int KC>
+__device__ __forceinline__ void issue_stage(const ConvKArgs& a, char* smem, int st, int buf, int wave, int lane, int z,
+                                            const unsigned (&voff)[C::NPJ], long long plane_elems,
+                                            unsigned plane_bytes) {
+    char* bbase = smem + buf * C::BUF_BYTES;
+    const int nchunks = a.nchunks;
+#pragma unroll
+    for (int pl = 0; pl < C::NPL; ++pl) {
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            const int c = st * KC + kc;
+            if (c < nchunks) {
+                const _Float16* xb = pl ? a.x_lo : a.x_hi;
+                const long long coff = (a.cpg > 0)
+                    ? (long long)(c / a.cpg) * a.group_stride + (long long)(c % a.cpg) * plane_elems
+                    : (long long)c * plane_elems;
+                __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)(xb + coff), 0, plane_bytes, 0x00020000);
+                char* lds = bbase + pl * C::PLANE_BYTES + kc * C::CHUNK_BYTES;
+#pragma unroll
+                for (int j = 0; j < C::NPJ; ++j) {
+                    const int i = wave + 4 * j;
+                    if (i < C::PP)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(lds + i * 1024), 16,
+                                                                 voff[j], 0, 0, 0);
+                }
+                const _Float16* wb = (pl ? a.w_lo : a.w_hi) +
+                                     ((long long)z * nchunks + c) * (KS * KS * C::COUTB * 16);
+                __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)wb, 0, KS * KS * C::COUTB * 32, 0x00020000);
+#pragma unroll
+                for (int j = 0; j < C::NWJ; ++j) {
+                    const int i = wave + 4 * j;
+                    if (i < C::WP)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(ws, (lds_void_t*)(lds + (C::PP + i) * 1024), 16,
+                                                                 lane * 16, i * 1024, 0, 0);
+                }
+            }
+        }
+    }
+}
+
+// All MFMAs of K-stage `st` out of LDS buffer `buf`.
+template <class C, int KS, int MT, int R, int KC, int NT>
+__device__ __forceinline__ void compute_stage(const char* smem, int st, int buf, int nchunks, int wm,
+                                              int a_lane_off, int b_lane_p, int kg, floatx16 (&acc)[MT][R]) {
+    const char* bbase = smem + buf * C::BUF_BYTES;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+        const int c = st * KC + kc;
+        if (c < nchunks) {
+            const char* pb = bbase + kc * C::CHUNK_BYTES;
+            const char* wb = pb + C::PP * 1024 + wm * (MT * 32 * 32);
+#pragma unroll
+            for (int dx = 0; dx < KS; ++dx) {
+                half8 Bh[R + KS - 1];
+                half8 Bl[R + KS - 1];
+#pragma unroll
+                for (int rr = 0; rr < R + KS - 1; ++rr) {
+                    const int p = b_lane_p + rr * C::PW + dx;
+                    const int off = p * 32 + ((kg ^ ((p >> 3) & 1)) << 4);
+                    Bh[rr] = lds_ld8(pb + off);
+                    if constexpr (NT == 3) Bl[rr] = lds_ld8(pb + C::PLANE_BYTES + off);
+                }
+#pragma unroll
+                for (int dy = 0; dy < KS; ++dy) {
+                    const int tap = dy * KS + dx;
+                    half8 Ah[MT];
+                    half8 Al[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const int off = (tap * C::COUTB + mt * 32) * 32 + a_lane_off;
+                        Ah[mt] = lds_ld8(wb + off);
+                        if constexpr (NT == 3) Al[mt] = lds_ld8(wb + C::PLANE_BYTES + off);
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            if constexpr (NT == 3) {
+                                acc[mt][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[mt], Bh[r + dy], acc[mt][r], 0, 0, 0);
+                                acc[mt][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[mt], Bl[r + dy], acc[mt][r], 0, 0, 0);
+                            }
+                            acc[mt][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[mt], Bh[r + dy], acc[mt][r], 0, 0, 0);
+                        }
+                }
+            }
+        }
+    }
+}
+
+template <int KS, int MT, int WM, int R, int WN, int KC, int NT, int NBUF, int EPI>
+__global__ void __launch_bounds__(256)
+conv_mfma_kernel(const ConvKArgs a) {
+    using C = ConvCfg<KS, MT, WM, R, WN, KC, NT, NBUF, EPI>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+    const int n = lane & 31;     // pixel column (B/N index) and cout row (A/M index) of this lane
+    const int kg = lane >> 5;    // which 8-channel half of the 16-channel chunk
+
+    int bid = blockIdx.x;
+    const int tx = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y;
+    const int img = bid / a.tiles_y;
+    const int z = blockIdx.y;
+    const int tx0 = tx * 32, ty0 = ty * C::TH;
+    const int H = a.H, W = a.W;
+    const long long plane_elems = (long long)a.N * H * W * 16;
+    const unsigned plane_bytes = (unsigned)(plane_elems * 2);
+
+    // ---- per-lane source offsets of the patch DMA pieces (stage independent) -------------------
+    unsigned voff[C::NPJ];
+#pragma unroll
+    for (int j = 0; j < C::NPJ; ++j) {
+        const int i = wave + 4 * j;
+        const int q = i * 64 + lane;          // 16-byte slot index in the LDS patch image
+        const int p = q >> 1;                 // patch pixel
+        const int s = q & 1;                  // slot within the pixel
+        const int py = p / C::PW;
+        const int px = p - py * C::PW;
+        const int gy = ty0 + py - C::PAD;
+        const int gx = tx0 + px - C::PAD;
+        const int cg = s ^ ((p >> 3) & 1);    // swizzle: slot s of pixel p holds channel group cg
+        const bool ok = (p < C::PH * C::PW) && (gy >= 0) && (gy < H) && (gx >= 0) && (gx < W);
+        voff[j] = ok ? (unsigned)((((long long)img * H + gy) * W + gx) * 32 + cg * 16) : 0x80000000u;
+    }
+
+    floatx16 acc[MT][R];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mt][r][e] = 0.f;
+
+    const int nchunks = a.nchunks;
+    const int nst = (nchunks + KC - 1) / KC;
+    const int a_lane_off = n * 32 + ((kg ^ ((n >> 3) & 1)) << 4);
+    const int b_lane_p = wn * R * C::PW + n;
+
+    if (NBUF == 2) {
+        issue_stage<C, KS, KC>(a, smem, 0, 0, wave, lane, z, voff, plane_elems, plane_bytes);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int st = 0; st < nst; ++st) {
+            const int cur = st & 1;
+            if (st + 1 < nst) issue_stage<C, KS, KC>(a, smem, st + 1, cur ^ 1, wave, lane, z, voff, plane_elems, plane_bytes);
+            compute_stage<C, KS, MT, R, KC, NT>(smem, st, cur, nchunks, wm, a_lane_off, b_lane_p, kg, acc);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    } else {
+        for (int st = 0; st < nst; ++st) {
+            issue_stage<C, KS, KC>(a, smem, st, 0, wave, lane, z, voff, plane_elems, plane_bytes);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            compute_stage<C, KS, MT, R, KC, NT>(smem, st, 0, nchunks, wm, a_lane_off, b_lane_p, kg, acc);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue -------------------------------------------------------------------------------
+    // acc[mt][r][4g+j] = D[cout = 8g + 4*kg + j][pixel = n]  (32x32 MFMA C/D layout)
+    const int gx = tx0 + n;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int gy = ty0 + wn * R + r;
+        const bool ok = (gy < H) && (gx < W);
+        if (!ok) continue;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = z * C::COUTB + (wm * MT + mt) * 32 + 8 * g + 4 * kg;
+                const float4 bv = *reinterpret_cast<const float4*>(a.bias + co);
+                float v[4] = {acc[mt][r][4 * g + 0] + bv.x, acc[mt][r][4 * g + 1] + bv.y,
+                              acc[mt][r][4 * g + 2] + bv.z, acc[mt][r][4 * g + 3] + bv.w};
+                if constexpr (EPI == BINHIP_EPI_FINAL) {
+                    if (co == 0) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (j >= a.cout) break;
+                            const long long idx = (((long long)img * a.cout + j) * H + gy) * W + gx;
+                            float s = 0.f;
+                            if (a.nimg > 0) {
+                                s = a.img[0][idx];
+                                for (int t = 1; t < a.nimg; ++t) s += a.img[t][idx];
+                                s = s / (float)a.nimg;
+                            }
+                            a.out_f32[idx] = v[j] + s;
+                        }
+                    }
+                } else {
+                    long long o;
+                    if constexpr (EPI == BINHIP_EPI_SHUFFLE) {
+                        const int cq = (a.cout + 3) / 4;      // channels after the shuffle
+                        const int sub = co / cq, cc = co - sub * cq;
+                        const int oy = 2 * gy + (sub >> 1), ox = 2 * gx + (sub & 1);
+                        o = (long long)(cc >> 4) * (plane_elems * 4) +
+                            ((((long long)img * 2 * H + oy) * (2 * W) + ox) << 4) + (cc & 15);
+                    } else {
+                        o = (long long)(co >> 4) * plane_elems + ((((long long)img * H + gy) * W + gx) << 4) + (co & 15);
+                        if (a.has_res) {
+                            const half4 rh = *reinterpret_cast<const half4*>(a.r_hi + o);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] += (float)rh[j];
+                            if constexpr (NT == 3) {
+                                const half4 rl = *reinterpret_cast<const half4*>(a.r_lo + o);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v[j] += (float)rl[j];
+                            }
+                        }
+                        if (a.relu) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                        }
+                    }
+                    half4 hv, lv;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        hv[j] = (_Float16)v[j];
+                        lv[j] = (_Float16)(v[j] - (float)hv[j]);
+                    }
+                    *reinterpret_cast<half4*>(a.y_hi + o) = hv;
+                    if constexpr (NT == 3) *reinterpret_cast<half4*>(a.y_lo + o) = lv;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <int KS, int MT, int WM, int R, int WN, int KC, int NT, int NBUF, int EPI>
+static int launch_cfg(const ConvKArgs& ka, int cout_pad, hipStream_t s) {
+    using C = ConvCfg<KS, MT, WM, R, WN, KC, NT, NBUF, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<KS, MT, WM, R, WN, KC, NT, NBUF, EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    ConvKArgs a = ka;
+    a.tiles_x = (a.W + 31) / 32;
+    a.tiles_y = (a.H + C::TH - 1) / C::TH;
+    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N), (unsigned)(cout_pad / C::COUTB));
+    conv_mfma_kernel<KS, MT, WM, R, WN, KC, NT, NBUF, EPI><<<grid, dim3(256), C::LDS_BYTES, s>>>(a);
+    BH_CHECK_LAUNCH();
+    return 0;
+}
+
+int bh_conv_cout_block(int ksize, int cout_pad, int nterms) {
+    if (cout_pad == 256) return nterms == 3 ? 64 : 128;
+    if (ksize == 5) return 32;
+    return cout_pad;
+}
+
+int bh_launch_conv(const BhConvCall& c, hipStream_t s) {
+    const BinConvDesc& d = c.d;
+    if (!c.x_hi || !c.w_hi || !c.bias) return BINHIP_E_ARG;
+    if (d.nterms != 1 && d.nterms != 3) return BINHIP_E_ARG;
+    if (d.nterms == 3 && (!c.x_lo || !c.w_lo)) return BINHIP_E_ARG;
+    if (d.N <= 0 || d.H <= 0 || d.W <= 0 || d.cin_chunks <= 0) return BINHIP_E_SHAPE;
+    if ((long long)d.N * d.H * d.W >= (1ll << 26)) return BINHIP_E_SHAPE;   // plane < 2 GiB (DMA OOB sentinel)
+    ConvKArgs a;
+    a.x_hi = (const _Float16*)c.x_hi; a.x_lo = (const _Float16*)c.x_lo;
+    a.w_hi = (const _Float16*)c.w_hi; a.w_lo = (const _Float16*)c.w_lo;
+    a.bias = c.bias;
+    a.y_hi = (_Float16*)c.y_hi; a.y_lo = (_Float16*)c.y_lo;
+    a.r_hi = (const _Float16*)c.r_hi; a.r_lo = (const _Float16*)c.r_lo;
+    a.out_f32 = c.y_f32;
+    for (int i = 0; i < 5; ++i) a.img[i] = c.images[i];
+    a.group_stride = d.x_group_stride;
+    a.N = d.N; a.H = d.H; a.W = d.W;
+    a.nchunks = d.cin_chunks;
+    a.cpg = d.x_cpg;
+    a.relu = d.relu; a.has_res = (c.r_hi != nullptr); a.nimg = d.n_images; a.cout = d.cout;
+    a.tiles_x = a.tiles_y = 0;
+    const int P = BINHIP_EPI_PLANES, S = BINHIP_EPI_SHUFFLE, F = BINHIP_EPI_FINAL;
+    if (d.epilogue == P) {
+        if (!c.y_hi || (d.nterms == 3 && !c.y_lo)) return BINHIP_E_ARG;
+        if (a.has_res && d.nterms == 3 && !c.r_lo) return BINHIP_E_ARG;
+    } else if (d.epilogue == S) {
+        if (!c.y_hi || (d.nterms == 3 && !c.y_lo)) return BINHIP_E_ARG;
+        if (d.cout % 4) return BINHIP_E_SHAPE;
+    } else if (d.epilogue == F) {
+        if (!c.y_f32 || d.cout > 4 || d.n_images < 0 || d.n_images > 5) return BINHIP_E_ARG;
+    } else {
+        return BINHIP_E_ARG;
+    }
+    const int k = d.ksize, cp = d.cout_pad, nt = d.nterms, e = d.epilogue;
+    //                         KS MT WM R WN KC NT NBUF EPI
+    if (nt == 1) {
+        if (k == 3 && cp == 32 && e == P)  return launch_cfg<3, 1, 1, 4, 4, 1, 1, 2, P>(a, cp, s);
+        if (k == 3 && cp == 32 && e == F)  return launch_cfg<3, 1, 1, 4, 4, 1, 1, 2, F>(a, cp, s);
+        if (k == 3 && cp == 64 && e == P)  return launch_cfg<3, 2, 1, 2, 4, 1, 1, 2, P>(a, cp, s);
+        if (k == 3 && cp == 96 && e == P)  return launch_cfg<3, 3, 1, 2, 4, 1, 1, 2, P>(a, cp, s);
+        if (k == 1 && cp == 96 && e == P)  return launch_cfg<1, 3, 1, 2, 4, 4, 1, 2, P>(a, cp, s);
+        if (k == 5 && cp == 96 && e == P)  return launch_cfg<5, 1, 1, 4, 4, 1, 1, 2, P>(a, cp, s);
+        if (k == 3 && cp == 256 && e == S) return launch_cfg<3, 2, 2, 4, 2, 1, 1, 2, S>(a, cp, s);
+    } else {
+        if (k == 3 && cp == 32 && e == P)  return launch_cfg<3, 1, 1, 4, 4, 1, 3, 2, P>(a, cp, s);
+        if (k == 3 && cp == 32 && e == F)  return launch_cfg<3, 1, 1, 4, 4, 1, 3, 2, F>(a, cp, s);
+        if (k == 3 && cp == 64 && e == P)  return launch_cfg<3, 2, 1, 2, 4, 1, 3, 2, P>(a, cp, s);
+        if (k == 3 && cp == 96 && e == P)  return launch_cfg<3, 3, 1, 2, 4, 1, 3, 2, P>(a, cp, s);
+        if (k == 1 && cp == 96 && e == P)  return launch_cfg<1, 3, 1, 2, 4, 2, 3, 2, P>(a, cp, s);
+        if (k == 5 && cp == 96 && e == P)  return launch_cfg<5, 1, 1, 4, 4, 1, 3, 1, P>(a, cp, s);
+        if (k == 3 && cp == 256 && e == S) return launch_cfg<3, 1, 2, 4, 2, 1, 3, 2, S>(a, cp, s);
+    }
+    return BINHIP_E_SHAPE;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Weight relayout: OIHW fp32 -> [cout_pad/cb][cin_chunks][k*k][cb][16] fp16 hi/lo, slot-swizzled.
+__global__ void relayout_kernel(const float* __restrict__ w, const float* __restrict__ bias, int cout, int cin,
+                                int ks, int cout_pad, int nchunks, int cb, int shuffle,
+                                _Float16* __restrict__ w_hi, _Float16* __restrict__ w_lo,
+                                float* __restrict__ bias_out) {
+    const long long total = (long long)cout_pad * nchunks * ks * ks * 2;   // 16-byte slots
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < cout_pad) {
+        int src = (int)t;
+        if (shuffle) { const int cq = cout / 4; const int sub = (int)t / cq, cc = (int)t % cq; src = cc * 4 + sub; }
+        bias_out[t] = (src < cout && bias) ? bias[src] : 0.f;
+    }
+    if (t >= total) return;
+    const int s = (int)(t & 1);
+    long long u = t >> 1;
+    const int row = (int)(u % cb); u /= cb;
+    const int tap = (int)(u % (ks * ks)); u /= (ks * ks);
+    const int c = (int)(u % nchunks); u /= nchunks;
+    const int zb = (int)u;
+    const int rg = zb * cb + row;
+    int src = rg;
+    if (shuffle) { const int cq = cout / 4; const int sub = rg / cq, cc = rg % cq; src = cc * 4 + sub; }
+    const int cg = s ^ ((row >> 3) & 1);
+    const int dy = tap / ks, dx = tap % ks;
+    half8 hv, lv;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ci = c * 16 + cg * 8 + e;
+        float v = 0.f;
+        if (src < cout && ci < cin) v = w[(((long long)src * cin + ci) * ks + dy) * ks + dx];
+        hv[e] = (_Float16)v;
+        lv[e] = (_Float16)(v - (float)hv[e]);
+    }
+    *reinterpret_cast<half8*>(w_hi + t * 8) = hv;
+    if (w_lo) *reinterpret_cast<half8*>(w_lo + t * 8) = lv;
+}
+
+extern "C" {
+
+int binhip_conv_cout_block(int ksize, int cout_pad, int nterms) { return bh_conv_cout_block(ksize, cout_pad, nterms); }
+
+size_t binhip_weights_bytes(int cout_pad, int cin_chunks, int ksize) {
+    return (size_t)cout_pad * cin_chunks * ksize * ksize * 32;
+}
+
+int binhip_weights_relayout(const float* w_oihw, const float* bias, int cout, int cin, int ksize,
+                            int cout_pad, int cin_chunks, int cout_block, int shuffle_perm,
+                            void* w_hi, void* w_lo, float* bias_out, void* stream) {
+    if (!w_oihw || !w_hi || !bias_out) return BINHIP_E_ARG;
+    if (cout_pad % 32 || cout_block <= 0 || cout_pad % cout_block || cout_block % 32) return BINHIP_E_SHAPE;
+    if (cin > cin_chunks * 16 || cout > cout_pad) return BINHIP_E_SHAPE;
+    if (shuffle_perm && (cout % 4 || cout != cout_pad)) return BINHIP_E_SHAPE;
+    const long long total = (long long)cout_pad * cin_chunks * ksize * ksize * 2;
+    const int th = 256;
+    const long long nb = (total + th - 1) / th;
+    hipLaunchKernelGGL(relayout_kernel, dim3((unsigned)nb), dim3(th), 0, (hipStream_t)stream, w_oihw, bias, cout, cin,
+                       ksize, cout_pad, cin_chunks, cout_block, shuffle_perm, (_Float16*)w_hi, (_Float16*)w_lo,
+                       bias_out);
+    BH_CHECK_LAUNCH();
+    return 0;
+}
+
+int binhip_conv2d_fwd(const BinConvDesc* d, const void* x_hi, const void* x_lo, const void* w_hi,
+                      const void* w_lo, const float* bias, const void* res_hi, const void* res_lo,
+                      void* y_hi, void* y_lo, float* y_f32, const float* const* images, void* stream) {
+    if (!d) return BINHIP_E_ARG;
+    BhConvCall c;
+    c.d = *d;
+    c.x_hi = x_hi; c.x_lo = x_lo; c.w_hi = w_hi; c.w_lo = w_lo; c.bias = bias;
+    c.r_hi = res_hi; c.r_lo = res_lo; c.y_hi = y_hi; c.y_lo = y_lo; c.y_f32 = y_f32;
+    for (int i = 0; i < 5; ++i) c.images[i] = (images && i < d->n_images) ? images[i] : nullptr;
+    if (d->epilogue == BINHIP_EPI_FINAL && d->n_images > 0 && !images) return BINHIP_E_ARG;
+    return bh_launch_conv(c, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,32 @@
+// Internal declarations shared by the libbinhip translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/binhip.h"
+
+#define BINHIP_VERSION 100
+
+// Chunk-plane helpers -------------------------------------------------------------------------
+// CP tensor: fp16 [chunk][N][H][W][16]; plane_elems = N*H*W*16.
+static inline int64_t bh_plane_elems(int N, int H, int W) { return (int64_t)N * H * W * 16; }
+static inline int bh_chunks(int C) { return (C + 15) / 16; }
+__device__ static inline int bh_chunks_dev(int C) { return (C + 15) / 16; }
+
+#define BH_CHECK_LAUNCH()                                   \
+    do {                                                    \
+        hipError_t e__ = hipGetLastError();                 \
+        if (e__ != hipSuccess) return (int)e__;             \
+    } while (0)
+
+// internal launcher used by both the per-op ABI and the RDN plan
+struct BhConvCall {
+    BinConvDesc d;
+    const void *x_hi, *x_lo, *w_hi, *w_lo;
+    const float* bias;
+    const void *r_hi, *r_lo;
+    void *y_hi, *y_lo;
+    float* y_f32;
+    const float* images[5];
+};
+int bh_launch_conv(const BhConvCall& c, hipStream_t s);
+int bh_conv_cout_block(int ksize, int cout_pad, int nterms);

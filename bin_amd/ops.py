@@ -1,0 +1,176 @@
+"""Thin torch-tensor wrappers over the libbinhip C ABI (include/binhip.h).
+
+PyTorch is plumbing here (device memory, streams); every computation is a hand-written HIP kernel.
+Activations between layers are "chunk planes" (CP): fp16 [C/16][N][H][W][16], optionally hi+lo.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("bin_amd: tensors must live on a HIP device (there is no CPU path; "
+                               "the CPU restatement lives in oracle/ and is test-only)")
+
+
+def chunks(c):
+    return (c + 15) // 16
+
+
+class CP:
+    """A chunk-plane tensor: `hi` (and `lo` when split) are fp16 [nchunks, N, H, W, 16]."""
+
+    def __init__(self, hi, lo, channels):
+        self.hi, self.lo, self.channels = hi, lo, channels
+
+    @property
+    def shape(self):
+        return tuple(self.hi.shape)
+
+    @staticmethod
+    def empty(nchunks, n, h, w, nterms, device, channels=None):
+        hi = torch.empty((nchunks, n, h, w, 16), dtype=torch.float16, device=device)
+        lo = torch.empty_like(hi) if nterms == 3 else None
+        return CP(hi, lo, channels if channels is not None else nchunks * 16)
+
+    def sub(self, c0, nch):
+        return CP(self.hi[c0:c0 + nch], self.lo[c0:c0 + nch] if self.lo is not None else None, nch * 16)
+
+
+def nchw_to_planes(x, nterms=1):
+    _need_cuda(x)
+    x = x.contiguous().float()
+    n, c, h, w = x.shape
+    y = CP.empty(chunks(c), n, h, w, nterms, x.device, c)
+    L.check(L.lib().binhip_nchw_to_planes(_ptr(x), n, c, h, w, _ptr(y.hi), _ptr(y.lo), _stream()), "nchw_to_planes")
+    return y
+
+
+def planes_to_nchw(cp, channels=None):
+    c = channels if channels is not None else cp.channels
+    _, n, h, w, _ = cp.hi.shape
+    y = torch.empty((n, c, h, w), dtype=torch.float32, device=cp.hi.device)
+    L.check(L.lib().binhip_planes_to_nchw(_ptr(cp.hi), _ptr(cp.lo), n, c, h, w, _ptr(y), _stream()), "planes_to_nchw")
+    return y
+
+
+def pack_inputs(images, nterms=1):
+    """K1: pixel_reshuffle(cat(images), 2) -> CP at half resolution (reference RDN.py:107-132)."""
+    _need_cuda(*images)
+    images = [im.contiguous().float() for im in images]
+    n, c, h, w = images[0].shape
+    assert c == 3 and h % 2 == 0 and w % 2 == 0
+    k = len(images)
+    y = CP.empty(chunks(12 * k), n, h // 2, w // 2, nterms, images[0].device, 12 * k)
+    arr = (C.c_void_p * k)(*[im.data_ptr() for im in images])
+    L.check(L.lib().binhip_pack_inputs(arr, k, n, h, w, _ptr(y.hi), _ptr(y.lo), _stream()), "pack_inputs")
+    return y
+
+
+class ConvWeights:
+    """Kernel-layout weights of one convolution (see binhip_weights_relayout)."""
+
+    def __init__(self, weight, bias, nterms=1, shuffle=False, cout_pad=None, cin_chunks=None):
+        _need_cuda(weight)
+        cout, cin, ks, _ = weight.shape
+        self.cout, self.cin, self.ks, self.nterms, self.shuffle = cout, cin, ks, nterms, shuffle
+        self.cout_pad = cout_pad if cout_pad is not None else ((cout + 31) // 32) * 32
+        self.cin_chunks = cin_chunks if cin_chunks is not None else chunks(cin)
+        lib = L.lib()
+        self.cout_block = lib.binhip_conv_cout_block(ks, self.cout_pad, nterms)
+        nbytes = lib.binhip_weights_bytes(self.cout_pad, self.cin_chunks, ks)
+        dev = weight.device
+        self.w_hi = torch.empty(nbytes // 2, dtype=torch.float16, device=dev)
+        self.w_lo = torch.empty(nbytes // 2, dtype=torch.float16, device=dev) if nterms == 3 else None
+        self.bias = torch.empty(self.cout_pad, dtype=torch.float32, device=dev)
+        w = weight.detach().contiguous().float()
+        b = bias.detach().contiguous().float() if bias is not None else None
+        L.check(lib.binhip_weights_relayout(_ptr(w), _ptr(b), cout, cin, ks, self.cout_pad, self.cin_chunks,
+                                            self.cout_block, 1 if shuffle else 0, _ptr(self.w_hi), _ptr(self.w_lo),
+                                            _ptr(self.bias), _stream()), "weights_relayout")
+
+
+def conv2d(x, cw, relu=False, residual=None, out=None, epilogue=L.EPI_PLANES, images=None, x_cpg=0,
+           x_group_stride=0, cin_chunks=None):
+    """One fused convolution launch.  x: CP (its first `cin_chunks` planes are read);
+    PLANES/SHUFFLE return a CP, FINAL returns fp32 NCHW."""
+    nch, n, h, w, _ = x.hi.shape
+    d = L.BinConvDesc()
+    d.N, d.H, d.W, d.ksize = n, h, w, cw.ks
+    d.cin_chunks = cin_chunks if cin_chunks is not None else cw.cin_chunks
+    d.cout, d.cout_pad, d.nterms, d.epilogue, d.relu = cw.cout, cw.cout_pad, cw.nterms, epilogue, int(relu)
+    d.x_cpg, d.x_group_stride = x_cpg, x_group_stride
+    d.n_images = len(images) if images else 0
+    dev = x.hi.device
+    y_f32, arr = None, None
+    if epilogue == L.EPI_PLANES:
+        if out is None:
+            out = CP.empty(chunks(cw.cout), n, h, w, cw.nterms, dev, cw.cout)
+    elif epilogue == L.EPI_SHUFFLE:
+        if out is None:
+            out = CP.empty(chunks(cw.cout // 4), n, 2 * h, 2 * w, cw.nterms, dev, cw.cout // 4)
+    else:
+        y_f32 = torch.empty((n, cw.cout, h, w), dtype=torch.float32, device=dev)
+        if images:
+            images = [im.contiguous().float() for im in images]
+            arr = (C.c_void_p * len(images))(*[im.data_ptr() for im in images])
+    rc = L.lib().binhip_conv2d_fwd(
+        C.byref(d), _ptr(x.hi), _ptr(x.lo), _ptr(cw.w_hi), _ptr(cw.w_lo), _ptr(cw.bias),
+        _ptr(residual.hi) if residual is not None else C.c_void_p(0),
+        _ptr(residual.lo) if residual is not None else C.c_void_p(0),
+        _ptr(out.hi) if out is not None else C.c_void_p(0),
+        _ptr(out.lo) if out is not None else C.c_void_p(0),
+        _ptr(y_f32), arr, _stream())
+    L.check(rc, "conv2d_fwd")
+    return y_f32 if epilogue == L.EPI_FINAL else out
+
+
+def convlstm_cell(x, state, weight, bias, forget_bias=1.0):
+    """ConvLSTMCell.forward (reference RDN.py:50-95).  Returns (h', [c', h'])."""
+    _need_cuda(x, weight)
+    x = x.contiguous().float()
+    n, c, h, w = x.shape
+    assert c == 3 and tuple(weight.shape) == (12, 6, 3, 3)
+    cn = torch.empty_like(x)
+    hn = torch.empty_like(x)
+    cp = state[0].contiguous().float() if state is not None else None
+    hp = state[1].contiguous().float() if state is not None else None
+    L.check(L.lib().binhip_convlstm_fwd(_ptr(x), _ptr(cp), _ptr(hp), _ptr(weight.detach().contiguous().float()),
+                                        _ptr(bias.detach().contiguous().float()), float(forget_bias), n, h, w,
+                                        _ptr(cn), _ptr(hn), _stream()), "convlstm_fwd")
+    return hn, [cn, hn]
+
+
+def charbonnier(x, y, eps=1e-6):
+    """mean(sqrt((x-y)^2 + eps)) (reference loss.py:137-141), forward only."""
+    _need_cuda(x, y)
+    x = x.contiguous().float()
+    y = y.contiguous().float()
+    lib = L.lib()
+    part = torch.empty(lib.binhip_charbonnier_partials(x.numel()), dtype=torch.float32, device=x.device)
+    loss = torch.empty((), dtype=torch.float32, device=x.device)
+    L.check(lib.binhip_charbonnier_fwd(_ptr(x), _ptr(y), x.numel(), float(eps), _ptr(part), _ptr(loss), _stream()),
+            "charbonnier_fwd")
+    return loss
+
+
+def charbonnier_grad(x, y, gloss, eps=1e-6):
+    x = x.contiguous().float()
+    y = y.contiguous().float()
+    gx = torch.empty_like(x)
+    g = gloss.reshape(1).contiguous().float()
+    L.check(L.lib().binhip_charbonnier_bwd(_ptr(x), _ptr(y), x.numel(), float(eps), _ptr(g), _ptr(gx),
+                                           C.c_void_p(0), _stream()), "charbonnier_bwd")
+    return gx

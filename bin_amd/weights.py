@@ -1,0 +1,108 @@
+"""Deterministic synthetic weights for the bin_stage4 network (SURVEY.md §8c "G0").
+
+The reference ships no weights (model_weights/download_adobe_bin.txt is a Drive URL) and
+there is no network, so every parity test / bench / smoke run uses this generator.  A tensor's
+values depend only on (seed, canonical parameter name), so the oracle, the reference (when it is
+importable in the build container) and the HIP path all see bit-identical fp32 weights without a
+46 MB blob in the repo.
+
+Magnitudes follow the reference's initialisers: nn.Conv2d default (kaiming-uniform a=sqrt(5)
+=> U(+-1/sqrt(fan_in)) for weight and bias) for every RDN conv (reference models/archs/RDN.py:
+141,162,187-208 never call a custom init) and xavier-uniform weight / zero bias for the ConvLSTM
+gates (RDN.py:26-38).
+"""
+import math
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+
+# (sub-net attribute, number of input frames) in construction order, RDN.py:342-363
+RDN_SETS = (("model1", 2), ("model2", 3), ("model3", 5), ("model4", 5))
+# alias names under `model.` -> canonical weight set (RDN.py:342-363: shared module objects)
+RDN_ALIASES = OrderedDict([
+    ("model1_1", "model1"), ("model1_2", "model1"), ("model1_3", "model1"), ("model1_4", "model1"),
+    ("model2_1", "model2"), ("model2_2", "model2"), ("model2_3", "model2"),
+    ("model3_1", "model3"), ("model3_2", "model3"),
+    ("model4_1", "model4"),
+])
+CLSTM_NAMES = ("clstm_4_prime", "clstm_6_prime", "clstm_8_prime",
+               "clstm_5_prime_prime", "clstm_7_prime_prime", "clstm_6_prime_prime_prime")
+
+G0, D, C, G = 96, 12, 4, 32   # RDN.py:418 (GO=96, D=12), RDN.py:171-172 (C=4, G=32)
+
+
+def rdn_param_shapes(n_in):
+    """Ordered {local name: shape} of one RDN sub-net with `n_in` input frames (RDN.py:167-334)."""
+    s = OrderedDict()
+    s["SFENet1.weight"] = (G0, 12 * n_in, 5, 5)
+    s["SFENet1.bias"] = (G0,)
+    s["SFENet2.weight"] = (G0, G0, 3, 3)
+    s["SFENet2.bias"] = (G0,)
+    for d in range(D):
+        for c in range(C):
+            s[f"RDBs.{d}.convs.{c}.conv.0.weight"] = (G, G0 + c * G, 3, 3)
+            s[f"RDBs.{d}.convs.{c}.conv.0.bias"] = (G,)
+        s[f"RDBs.{d}.LFF.weight"] = (G0, G0 + C * G, 1, 1)
+        s[f"RDBs.{d}.LFF.bias"] = (G0,)
+    s["GFF.0.weight"] = (G0, D * G0, 1, 1)
+    s["GFF.0.bias"] = (G0,)
+    s["GFF.1.weight"] = (G0, G0, 3, 3)
+    s["GFF.1.bias"] = (G0,)
+    s["UPNet.0.weight"] = (256, G0, 3, 3)
+    s["UPNet.0.bias"] = (256,)
+    s["UPNet.2.weight"] = (3, 64, 3, 3)
+    s["UPNet.2.bias"] = (3,)
+    return s
+
+
+def _rng(seed, name):
+    return np.random.Generator(np.random.PCG64([int(seed), zlib.crc32(name.encode())]))
+
+
+def _uniform(seed, name, shape, bound):
+    return _rng(seed, name).uniform(-bound, bound, size=shape).astype(np.float32)
+
+
+def canonical_weights(seed=0):
+    """{canonical name: float32 ndarray} for the 4 RDN weight sets + 6 ConvLSTM cells (540 tensors)."""
+    out = OrderedDict()
+    for nm in CLSTM_NAMES:
+        shape = (12, 6, 3, 3)
+        fan_in, fan_out = 6 * 9, 12 * 9
+        out[f"{nm}.Gates.weight"] = _uniform(seed, f"{nm}.Gates.weight", shape,
+                                             math.sqrt(6.0 / (fan_in + fan_out)))
+        out[f"{nm}.Gates.bias"] = np.zeros((12,), np.float32)
+    for set_name, n_in in RDN_SETS:
+        for local, shape in rdn_param_shapes(n_in).items():
+            wshape = shape if len(shape) == 4 else None
+            if wshape is None:
+                # bias bound uses the fan_in of the matching weight
+                wshape = rdn_param_shapes(n_in)[local.replace(".bias", ".weight")]
+            fan_in = wshape[1] * wshape[2] * wshape[3]
+            out[f"{set_name}.{local}"] = _uniform(seed, f"{set_name}.{local}", shape,
+                                                  1.0 / math.sqrt(fan_in))
+    return out
+
+
+def reference_state_dict(seed=0):
+    """The 1332-key aliased state_dict of RDN_residual_interp_5_input_ConvLSTM_L
+    (reference RDN.py:408-465; key naming per SURVEY.md §8b) as torch tensors."""
+    import torch
+    canon = canonical_weights(seed)
+    sd = OrderedDict()
+    for nm in CLSTM_NAMES:
+        for p in ("weight", "bias"):
+            sd[f"{nm}.Gates.{p}"] = torch.from_numpy(canon[f"{nm}.Gates.{p}"].copy())
+    for alias, set_name in RDN_ALIASES.items():
+        n_in = dict(RDN_SETS)[set_name]
+        for local in rdn_param_shapes(n_in):
+            sd[f"model.{alias}.{local}"] = torch.from_numpy(canon[f"{set_name}.{local}"].copy())
+    return sd
+
+
+def synthetic_frames(seed, n, h, w, count=6):
+    """`count` seeded U[0,1) fp32 frames [n,3,h,w] (SURVEY.md §8d synthetic inputs)."""
+    import torch
+    rng = np.random.Generator(np.random.PCG64(int(seed)))
+    return [torch.from_numpy(rng.random((n, 3, h, w), dtype=np.float32)) for _ in range(count)]

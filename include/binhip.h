@@ -1,0 +1,133 @@
+/*
+ * binhip.h — flat C ABI of libbinhip.so: the MI355X (gfx950) hot path of laomao0/BIN's
+ * `bin_stage4` network (reference: /root/reference/models/archs/RDN.py).
+ *
+ * The reference has no native code; the interface this library replaces is the set of ATen
+ * operator calls made by models/archs/RDN.py (F.conv2d / relu / cat / pixel_shuffle / sigmoid /
+ * tanh) and models/loss.py:130-141 behind the nn.Module boundary `define_G(opt)`
+ * (models/networks.py:5-14).  Each entry point cites the reference lines it stands in for.
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer owned by the caller (PyTorch allocates); the library never
+ *     allocates, frees or retains device memory.  `stream` is a hipStream_t passed as void*.
+ *   - All work is enqueued asynchronously on `stream`; no host synchronisation inside.
+ *   - Return value: 0 = ok, negative = argument/shape error (BINHIP_E_*), positive = hipError_t.
+ *   - Activations between layers live in "chunk planes" (CP): fp16 [C/16][N][H][W][16]
+ *     (channels-last inside 16-channel chunks, one contiguous plane per chunk, so a dense block's
+ *     concat is just "the next plane").  A CP tensor has a `hi` plane set and, in split precision
+ *     (nterms == 3), a `lo` plane set with x ~= hi + lo to ~22 mantissa bits.
+ *   - nterms: 1 = fp16-input MFMA, fp32 accumulate (whole-net max-abs error ~3e-4 vs fp32);
+ *             3 = fp16 hi/lo split, three MFMA products (error ~1e-6, fp32 class).
+ */
+#ifndef BINHIP_H
+#define BINHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BINHIP_E_ARG      (-1)   /* null pointer / bad enum */
+#define BINHIP_E_SHAPE    (-2)   /* unsupported shape */
+#define BINHIP_E_WORKSPACE (-3)  /* workspace too small */
+
+#define BINHIP_EPI_PLANES  0     /* y = [relu](conv + b [+ residual]) -> chunk planes            */
+#define BINHIP_EPI_SHUFFLE 1     /* conv + b -> PixelShuffle(2) -> chunk planes at 2H x 2W       */
+#define BINHIP_EPI_FINAL   2     /* conv + b + mean(images) -> fp32 NCHW [N,cout,H,W]            */
+
+#define BINHIP_RDN_LAYERS 66     /* SFE1, SFE2, 12 x (4 conv + LFF), GFF.0, GFF.1, UP.0, UP.2    */
+
+int binhip_version(void);
+
+/* Device properties the host needs for sizing (no allocation). */
+int binhip_device_cus(void);
+
+/* ---- stride-1 "same" convolution on chunk planes (RDN.py:141,162,187-188,199-200,205-207) -----
+ * Replaces F.conv2d(+bias)(+ReLU)(+cat)(+residual add)(+PixelShuffle)(+input mean).            */
+typedef struct BinConvDesc {
+    int32_t N, H, W;          /* input batch / height / width (output same, 2x for SHUFFLE)      */
+    int32_t ksize;            /* 1, 3 or 5                                                       */
+    int32_t cin_chunks;       /* number of 16-channel input chunks (zero-padded channels allowed) */
+    int32_t cout;             /* real output channels                                            */
+    int32_t cout_pad;         /* weight rows, multiple of 32 (32, 96, 256)                       */
+    int32_t nterms;           /* 1 or 3                                                          */
+    int32_t epilogue;         /* BINHIP_EPI_*                                                    */
+    int32_t relu;             /* apply ReLU (PLANES only)                                        */
+    int32_t x_cpg;            /* input chunks per group; chunk i lives at                        */
+    int64_t x_group_stride;   /*   x + (i / x_cpg) * x_group_stride + (i % x_cpg) * N*H*W*16     */
+                              /*   (elements). x_cpg <= 0: one group.                             */
+    int32_t n_images;         /* FINAL: number of fp32 NCHW images averaged into the output      */
+    int32_t reserved;
+} BinConvDesc;
+
+/* Rows per weight block for a (ksize, cout_pad, nterms) configuration (relayout needs it). */
+int binhip_conv_cout_block(int ksize, int cout_pad, int nterms);
+
+/* OIHW fp32 -> kernel layout fp16 [cout_pad/cb][cin_chunks][k*k][cb][16] (+lo), 16-byte slots
+ * XOR-swizzled for conflict-free ds_read_b128; input channels >= cin and rows >= cout are zero.
+ * shuffle_perm != 0 reorders output rows co' = (co%4)*(cout/4) + co/4 so PixelShuffle becomes a
+ * plain plane store.  bias_out: fp32 [cout_pad] (same row order, zero padded).  w_lo may be NULL. */
+int binhip_weights_relayout(const float* w_oihw, const float* bias, int cout, int cin, int ksize,
+                            int cout_pad, int cin_chunks, int cout_block, int shuffle_perm,
+                            void* w_hi, void* w_lo, float* bias_out, void* stream);
+size_t binhip_weights_bytes(int cout_pad, int cin_chunks, int ksize);   /* per plane (hi or lo) */
+
+int binhip_conv2d_fwd(const BinConvDesc* d,
+                      const void* x_hi, const void* x_lo,
+                      const void* w_hi, const void* w_lo, const float* bias,
+                      const void* res_hi, const void* res_lo,      /* PLANES residual or NULL   */
+                      void* y_hi, void* y_lo,                      /* PLANES / SHUFFLE output   */
+                      float* y_f32, const float* const* images,    /* FINAL output + host array */
+                      void* stream);                               /*   of n_images device ptrs */
+
+/* ---- layout glue ------------------------------------------------------------------------------ */
+/* fp32 NCHW [N,C,H,W] -> chunk planes (C padded with zeros to 16).                              */
+int binhip_nchw_to_planes(const float* x, int N, int C, int H, int W, void* y_hi, void* y_lo,
+                          void* stream);
+/* chunk planes -> fp32 NCHW (hi + lo when lo != NULL).                                           */
+int binhip_planes_to_nchw(const void* x_hi, const void* x_lo, int N, int C, int H, int W, float* y,
+                          void* stream);
+/* K1: pixel_reshuffle(cat(images), 2) (RDN.py:107-132, 211/269/323) fused into the CP writer:
+ * `n_images` fp32 [N,3,H,W] -> CP [N, H/2, W/2, pad16(12*n_images)].                            */
+int binhip_pack_inputs(const float* const* images, int n_images, int N, int H, int W,
+                       void* y_hi, void* y_lo, void* stream);
+
+/* ---- ConvLSTM cell (RDN.py:50-95): gates = conv3x3(cat(x,h)) 6->12, i,j,f,o = chunk(4);
+ * c' = c*sigmoid(f+forget_bias) + sigmoid(i)*tanh(j); h' = tanh(c')*sigmoid(o).  fp32 NCHW.
+ * c_prev/h_prev may both be NULL (zero state, RDN.py:57-68).                                      */
+int binhip_convlstm_fwd(const float* x, const float* c_prev, const float* h_prev,
+                        const float* w /*[12,6,3,3]*/, const float* b /*[12]*/, float forget_bias,
+                        int N, int H, int W, float* c_new, float* h_new, void* stream);
+
+/* ---- Charbonnier loss (loss.py:137-141): mean(sqrt((x-y)^2 + eps)).  Deterministic two-pass
+ * reduction; `partials` is a caller workspace of binhip_charbonnier_partials() floats.           */
+int binhip_charbonnier_partials(int64_t numel);
+int binhip_charbonnier_fwd(const float* x, const float* y, int64_t numel, float eps,
+                           float* partials, float* loss, void* stream);
+/* gx = gloss * (x-y)/sqrt((x-y)^2+eps)/numel ; gy = -gx (either may be NULL).                    */
+int binhip_charbonnier_bwd(const float* x, const float* y, int64_t numel, float eps,
+                           const float* gloss, float* gx, float* gy, void* stream);
+
+/* ---- one whole RDN sub-network (RDN.py:210-222 / 268-280 / 322-334) ---------------------------
+ * 66 convolutions launched back-to-back on `stream` from C (no Python between layers).           */
+typedef struct BinRdnPlan {
+    int32_t N, H, W;          /* full-resolution frame size (H, W even)                          */
+    int32_t n_inputs;         /* 2, 3 or 5 input frames                                          */
+    int32_t nterms;           /* 1 or 3                                                          */
+    int32_t reserved;
+    const void* w_hi[BINHIP_RDN_LAYERS];   /* relayouted weights per layer                       */
+    const void* w_lo[BINHIP_RDN_LAYERS];   /* NULL when nterms == 1                              */
+    const float* bias[BINHIP_RDN_LAYERS];
+} BinRdnPlan;
+
+size_t binhip_rdn_workspace_bytes(int N, int H, int W, int n_inputs, int nterms);
+int binhip_rdn_forward(const BinRdnPlan* plan, const float* const* inputs /* host array of
+                       n_inputs device ptrs, fp32 [N,3,H,W] */, float* out /* fp32 [N,3,H,W] */,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BINHIP_H */
