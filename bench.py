@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json metric: interpolated frames/s at 1280x720 on N MI355X.
+
+A "step" = one 6-frame forward of bin_stage4 (`netG(B1..B11)`, what the reference's test.py runs per
+input frame, test.py:249-379) on synthetic 6 x [1,3,720,1280] U[0,1) frames replicate-padded to
+[1,3,768,1344] by the test.py rule (:348-366), seeded random-init weights (bin_amd/weights.py), inputs
+resident in HBM before the timed region.  One step = one interpolated frame (Ft_p[13]) + two restored
+frames.  N>1: every rank runs its own windows (window-sharded inference, no data-path collective;
+weak scaling), value = all ranks' windows / max-over-ranks time.
+
+Extra objects on the JSON line:
+  roofline     — dominant kernel (RDB 3x3 conv Cin->32, 70 % of FLOPs): algorithmic fp32 bytes per launch
+                 / its mean duration measured with HIP events on the launch stream INSIDE the timed region
+  cpu_baseline — the oracle (CPU restatement, kind "port") timed on the host cores on a bounded sample
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+
+H, W = 720, 1280
+HBM_PEAK_GBS = 8000.0
+# SURVEY.md §8(d) / BASELINE.md §4 constants at 768x1344 padded
+FLOP_20, FLOP_17 = 29.386e12, 25.03e12
+BYTES_20, BYTES_17 = 304.5e9, 259.0e9
+
+
+def rdb_conv_algorithmic_bytes(n, h2, w2):
+    """fp32 layer-wise minimum of ONE launch of the dominant kernel, averaged over the four RDB convs
+    (Cin = 96,128,160,192 -> 32): read Cin planes once, write 32 once, weights once."""
+    px = n * h2 * w2
+    per = [(cin + 32) * 4 * px + (cin * 32 * 9 + 32) * 4 for cin in (96, 128, 160, 192)]
+    return sum(per) / len(per)
+
+
+def _host_cores():
+    """Cores this process may really use: affinity mask, clipped by the cgroup CPU quota if there is one."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, n)
+
+
+def cpu_baseline_worker(budget_s=20.0):
+    """(runs in a subprocess) Oracle forward on the host cores on a BOUNDED sample: 6-frame forwards of
+    the reference's literal schedule on growing crops (48x96 -> 96x168 -> 192x336 = 1/16 of the padded
+    768x1344 area), stopping before the time budget is exceeded; the largest crop timed is scaled to
+    720p windows/s by the pixel ratio (conv FLOPs are linear in pixels)."""
+    from oracle import rdn_oracle as O
+    from bin_amd.weights import canonical_weights, synthetic_frames
+    cores = min(_host_cores(), 64)
+    torch.set_num_threads(cores)
+    canon = {k: torch.from_numpy(v) for k, v in canonical_weights(0).items()}
+    t_begin = time.time()
+    best = None
+    with torch.no_grad():
+        O.bin_stage4_forward(synthetic_frames(1, 1, 32, 32, 6), canon)          # warm-up (thread pool, oneDNN)
+        prev = None
+        for hs, ws in ((48, 96), (96, 168), (192, 336)):
+            if prev is not None:
+                est = prev[2] * (hs * ws) / (prev[0] * prev[1])
+                if (time.time() - t_begin) + 2 * est > budget_s:
+                    break
+            frames = synthetic_frames(1234, 1, hs, ws, 6)
+            times = []
+            for _ in range(2):
+                t0 = time.time()
+                O.bin_stage4_forward(frames, canon)
+                times.append(time.time() - t0)
+            prev = (hs, ws, min(times))
+            best = prev
+    hs, ws, t = best
+    scale = (hs * ws) / (768.0 * 1344.0)
+    return {"value": round(scale / t, 6), "unit": "interpolated frames/s at 1280x720", "cores": cores,
+            "kind": "port",
+            "sample": f"oracle (PyTorch-CPU restatement of the reference, 20-call schedule) 6-frame forward on a "
+                      f"{hs}x{ws} crop = {t:.2f} s (best of 2), scaled by pixel ratio {scale:.5f} to 768x1344"}
+
+
+def cpu_baseline(timeout_s=150):
+    """Run the CPU baseline in a child process with a hard timeout so it can never stall the bench."""
+    import subprocess
+    code = ("import json,sys; sys.path.insert(0, %r); import bench; "
+            "print('CPU_BASELINE ' + json.dumps(bench.cpu_baseline_worker()))" % REPO)
+    env = dict(os.environ)
+    env["HIP_VISIBLE_DEVICES"] = ""
+    try:
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout_s, env=env)
+        for ln in out.stdout.splitlines():
+            if ln.startswith("CPU_BASELINE "):
+                return json.loads(ln[len("CPU_BASELINE "):])
+        return {"value": None, "unit": "interpolated frames/s at 1280x720", "cores": _host_cores(), "kind": "port",
+                "sample": "cpu baseline failed: " + (out.stderr.strip().splitlines() or ["?"])[-1][:200]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "interpolated frames/s at 1280x720", "cores": _host_cores(), "kind": "port",
+                "sample": f"cpu baseline exceeded {timeout_s}s and was cut"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--precision", default=os.environ.get("BIN_AMD_BENCH_PRECISION", "f16"),
+                    choices=["f16", "f16x3"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--reference-schedule", action="store_true",
+                    help="run the reference's literal 20 RDN calls + 12 cells instead of the exact 17 + 6")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from bin_amd import _lib as L
+    from bin_amd.models.archs.RDN import bin_stage4_lstm
+    from bin_amd.utils import util
+    from bin_amd.weights import reference_state_dict, synthetic_frames
+
+    net = bin_stage4_lstm()
+    net.load_state_dict(reference_state_dict(0), strict=True)
+    net = net.to(dev).eval().set_precision(args.precision)
+    net.reuse_schedule = not args.reference_schedule
+
+    pads = util.pad_sizes(H, W)
+    frames = [util.replicate_pad(f, pads).to(dev) for f in synthetic_frames(1234 + rank, 1, H, W, 6)]
+    hp, wp = frames[0].shape[2], frames[0].shape[3]
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = net(*frames)
+        sync_all()
+        lib = L.lib()
+        launches_per_step = (17 if net.reuse_schedule else 20) * 48
+        prof = rank == 0 and args.steps * launches_per_step <= 16384
+        if prof:
+            L.check(lib.binhip_profile_begin(3, 32, L.EPI_PLANES, args.steps * launches_per_step), "profile_begin")
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = net(*frames)
+        sync_all()
+        dt = time.perf_counter() - t0
+        kern_ms, kern_n = ctypes.c_double(0), ctypes.c_int(0)
+        if prof:
+            L.check(lib.binhip_profile_end(ctypes.byref(kern_ms), ctypes.byref(kern_n)), "profile_end")
+    assert all(torch.isfinite(o).all() for o in out)
+
+    t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    dt = float(t_max.item())
+
+    if rank == 0:
+        value = world * args.steps / dt
+        flops = FLOP_17 if net.reuse_schedule else FLOP_20
+        abytes = BYTES_17 if net.reuse_schedule else BYTES_20
+        ms = dt / args.steps * 1e3
+        roof = None
+        if prof and kern_n.value > 0:
+            avg_s = kern_ms.value / kern_n.value * 1e-3
+            ab = rdb_conv_algorithmic_bytes(1, hp // 2, wp // 2)
+            ach = ab / avg_s / 1e9
+            roof = {"bound": "hbm", "kernel": "conv_mfma_kernel<3,1,1,4,4,1,NT,2,PLANES> (RDB conv3x3 Cin->32 +ReLU)",
+                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "traffic": None, "avg_kernel_us": round(avg_s * 1e6, 2), "launches": kern_n.value,
+                    "algorithmic_bytes_per_launch": int(ab),
+                    "whole_forward": {"algorithmic_GB": abytes / 1e9, "achieved_GBs": round(abytes / (ms * 1e-3) / 1e9, 1),
+                                      "frac_hbm": round(abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                      "achieved_TFLOPs": round(flops / (ms * 1e-3) / 1e12, 1)}}
+        line = {
+            "metric": "interpolated frames/sec at 1280x720", "value": round(value, 4),
+            "unit": "interpolated frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16 MFMA inputs, f32 accumulate" if args.precision == "f16"
+                     else "f16 hi/lo split (3 MFMA products), f32 accumulate",
+            "data": "synthetic",
+            "config": {"workload": "Adobe240 test_blur 1280x720 inference, batch=1 per GPU "
+                                   "(6-frame window padded to 768x1344 by the test.py rule), window-sharded",
+                       "schedule": "17 RDN calls + 6 ConvLSTM cells (exact reuse)" if net.reuse_schedule
+                                   else "20 RDN calls + 12 ConvLSTM cells (reference literal)",
+                       "precision": args.precision, "parity": "max-abs <= 1e-3 vs fp32 reference (tests/)"},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -46,6 +46,8 @@ _SIGNATURES = {
                                          C.c_void_p]),
     "binhip_charbonnier_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p]),
+    "binhip_profile_begin": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "binhip_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "binhip_rdn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "binhip_rdn_forward": (C.c_int, [C.POINTER(BinRdnPlan), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p,
                                      C.c_size_t, C.c_void_p]),

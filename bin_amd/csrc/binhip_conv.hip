@@ -15,6 +15,7 @@
 // slots XOR-swizzled so each 16-lane read group hits 16 distinct bank slots).
 // Precision: NT=1 -> one fp16 product; NT=3 -> hi/lo split, Ah*Bh + Al*Bh + Ah*Bl (fp32 class).
 #include "binhip_internal.h"
+#include <vector>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -321,11 +322,25 @@ static int launch_cfg(const ConvKArgs& ka, int cout_pad, hipStream_t s) {
     return 0;
 }
 
+// ---- optional live profiling of ONE kernel class with HIP events on the launch stream -------------
+// (bench.py's roofline leg: average duration of the dominant kernel inside the timed region)
+namespace {
+struct Prof {
+    bool active = false;
+    int ks = 0, cout_pad = 0, epi = 0;
+    std::vector<hipEvent_t> ev;   // pairs: start, stop
+    size_t used = 0;
+} g_prof;
+constexpr size_t PROF_MAX_PAIRS = 16384;
+}  // namespace
+
 int bh_conv_cout_block(int ksize, int cout_pad, int nterms) {
     if (cout_pad == 256) return nterms == 3 ? 64 : 128;
     if (ksize == 5) return 32;
     return cout_pad;
 }
+
+static int bh_dispatch_conv(const ConvKArgs& a, int k, int cp, int nt, int e, hipStream_t s);
 
 int bh_launch_conv(const BhConvCall& c, hipStream_t s) {
     const BinConvDesc& d = c.d;
@@ -361,6 +376,20 @@ int bh_launch_conv(const BhConvCall& c, hipStream_t s) {
         return BINHIP_E_ARG;
     }
     const int k = d.ksize, cp = d.cout_pad, nt = d.nterms, e = d.epilogue;
+    if (g_prof.active && k == g_prof.ks && cp == g_prof.cout_pad && e == g_prof.epi &&
+        g_prof.used + 2 <= g_prof.ev.size()) {
+        hipEvent_t e0 = g_prof.ev[g_prof.used], e1 = g_prof.ev[g_prof.used + 1];
+        hipEventRecord(e0, s);
+        const int rc = bh_dispatch_conv(a, k, cp, nt, e, s);
+        hipEventRecord(e1, s);
+        g_prof.used += 2;
+        return rc;
+    }
+    return bh_dispatch_conv(a, k, cp, nt, e, s);
+}
+
+static int bh_dispatch_conv(const ConvKArgs& a, int k, int cp, int nt, int e, hipStream_t s) {
+    const int P = BINHIP_EPI_PLANES, S = BINHIP_EPI_SHUFFLE, F = BINHIP_EPI_FINAL;
     //                         KS MT WM R WN KC NT NBUF EPI
     if (nt == 1) {
         if (k == 3 && cp == 32 && e == P)  return launch_cfg<3, 1, 1, 4, 4, 1, 1, 2, P>(a, cp, s);
@@ -421,6 +450,39 @@ __global__ void relayout_kernel(const float* __restrict__ w, const float* __rest
 }
 
 extern "C" {
+
+int binhip_profile_begin(int ksize, int cout_pad, int epilogue, int max_launches) {
+    if (max_launches <= 0 || (size_t)max_launches > PROF_MAX_PAIRS) return BINHIP_E_ARG;
+    while (g_prof.ev.size() < (size_t)max_launches * 2) {
+        hipEvent_t ev;
+        hipError_t e = hipEventCreate(&ev);
+        if (e != hipSuccess) return (int)e;
+        g_prof.ev.push_back(ev);
+    }
+    g_prof.ks = ksize; g_prof.cout_pad = cout_pad; g_prof.epi = epilogue;
+    g_prof.used = 0;
+    g_prof.active = true;
+    return 0;
+}
+
+int binhip_profile_end(double* total_ms, int* launches) {
+    g_prof.active = false;
+    double tot = 0.0;
+    int n = 0;
+    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+        hipError_t e = hipEventSynchronize(g_prof.ev[i + 1]);
+        if (e != hipSuccess) return (int)e;
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]);
+        if (e != hipSuccess) return (int)e;
+        tot += ms;
+        ++n;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = n;
+    g_prof.used = 0;
+    return 0;
+}
 
 int binhip_conv_cout_block(int ksize, int cout_pad, int nterms) { return bh_conv_cout_block(ksize, cout_pad, nterms); }
 

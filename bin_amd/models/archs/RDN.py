@@ -1,0 +1,259 @@
+"""bin_stage4 network — MI355X-native counterpart of the reference's models/archs/RDN.py.
+
+Same class names, constructor arguments, forward signatures, output order and state_dict keys
+(1332 aliased keys, OIHW fp32) as the reference, so `adobe_bin.pth` loads with strict=True and
+`define_G(opt)` users see no difference.  What differs is everything below the nn.Module boundary:
+each RDN sub-network runs as ONE C call into libbinhip.so (66 fused MFMA convolution launches,
+concat-free dense blocks in fp16 chunk planes), the ConvLSTM cell is one fused HIP kernel, and the
+nn.Conv2d children are parameter containers only — their ATen forward is never called.
+
+There is no CPU path: calling forward on CPU tensors raises (the CPU restatement is oracle/, test-only).
+
+Precision (`precision` attribute of the top module, or env BIN_AMD_PRECISION):
+  "f16x3" (default) fp16 hi/lo split, 3 MFMA products, fp32-class results (~1e-6 vs reference)
+  "f16"             fp16-input MFMA, fp32 accumulate; whole-net max-abs error ~3e-4 (bar: 1e-3)
+"""
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.init as weight_init
+
+from ... import ops
+from ...rdn_plan import RdnWeights, rdn_forward
+
+PRECISIONS = {"f16": 1, "f16x3": 3}
+
+
+def default_precision():
+    p = os.environ.get("BIN_AMD_PRECISION", "f16x3")
+    if p not in PRECISIONS:
+        raise ValueError(f"BIN_AMD_PRECISION must be one of {sorted(PRECISIONS)}, got {p!r}")
+    return p
+
+
+class ConvLSTMCell(nn.Module):
+    """reference RDN.py:9-95.  (input_size, hidden_size) = (3, 3) on the live path."""
+
+    def __init__(self, input_size, hidden_size, forget_bias=1.0, kernel_size=3, padding=3 // 2):
+        super().__init__()
+        if (input_size, hidden_size, kernel_size, padding) != (3, 3, 3, 1):
+            raise NotImplementedError("bin_amd ConvLSTMCell: only the (3,3) 3x3 cell of bin_stage4 is built")
+        self.input_size, self.hidden_size = input_size, hidden_size
+        self.Gates = nn.Conv2d(input_size + hidden_size, 4 * hidden_size, kernel_size, padding=padding, bias=True)
+        self._forget_bias = forget_bias
+        weight_init.xavier_uniform_(self.Gates.weight.data)      # RDN.py:26-38
+        self.Gates.bias.data.zero_()
+
+    def forward(self, input_, prev_state):
+        return ops.convlstm_cell(input_, prev_state, self.Gates.weight, self.Gates.bias, self._forget_bias)
+
+
+def pixel_reshuffle(input, upscale_factor):
+    """reference RDN.py:107-132 (space-to-depth); returns fp32 NCHW like the reference."""
+    if upscale_factor != 2 or input.shape[1] % 3:
+        raise NotImplementedError("bin_amd pixel_reshuffle: r=2 on 3k-channel frames only")
+    frames = [input[:, i:i + 3] for i in range(0, input.shape[1], 3)]
+    out = []
+    for i in range(0, len(frames), 5):
+        grp = frames[i:i + 5]
+        out.append(ops.planes_to_nchw(ops.pack_inputs(grp, 3), 12 * len(grp)))
+    return torch.cat(out, 1) if len(out) > 1 else out[0]
+
+
+class RDB_Conv(nn.Module):
+    """reference RDN.py:135-147 (parameter container; executed inside the fused RDN plan)."""
+
+    def __init__(self, inChannels, growRate, kSize=3):
+        super().__init__()
+        self.conv = nn.Sequential(nn.Conv2d(inChannels, growRate, kSize, padding=(kSize - 1) // 2, stride=1),
+                                  nn.ReLU())
+
+
+class RDB(nn.Module):
+    """reference RDN.py:149-165 (parameter container)."""
+
+    def __init__(self, growRate0, growRate, nConvLayers, kSize=3):
+        super().__init__()
+        self.convs = nn.Sequential(*[RDB_Conv(growRate0 + c * growRate, growRate) for c in range(nConvLayers)])
+        self.LFF = nn.Conv2d(growRate0 + nConvLayers * growRate, growRate0, 1, padding=0, stride=1)
+
+
+class _RDNBase(nn.Module):
+    """Shared body of RDN_residual_interp_{2,2_1,4_1}_input (reference RDN.py:167-334): they differ only
+    in the number of input frames."""
+    N_INPUTS = 0
+
+    def __init__(self, G0=64, D=6, C=4, G=32):
+        super().__init__()
+        if (G0, D, C, G) != (96, 12, 4, 32):
+            raise NotImplementedError("bin_amd RDN: only the bin_stage4 configuration G0=96, D=12, C=4, G=32 is built")
+        self.G0, self.D, self.C, self.G = G0, D, C, G
+        kSize = 3
+        self.SFENet1 = nn.Conv2d(12 * self.N_INPUTS, G0, 5, padding=2, stride=1)
+        self.SFENet2 = nn.Conv2d(G0, G0, kSize, padding=1, stride=1)
+        self.RDBs = nn.ModuleList([RDB(growRate0=G0, growRate=G, nConvLayers=C) for _ in range(D)])
+        self.GFF = nn.Sequential(nn.Conv2d(D * G0, G0, 1, padding=0, stride=1),
+                                 nn.Conv2d(G0, G0, kSize, padding=1, stride=1))
+        self.UPNet = nn.Sequential(nn.Conv2d(G0, 256, kSize, padding=1, stride=1), nn.PixelShuffle(2),
+                                   nn.Conv2d(64, 3, kSize, padding=1, stride=1))
+        self.precision = None          # None -> inherit default_precision()
+        self._wcache = None            # (key, RdnWeights)
+
+    def kernel_weights(self, nterms):
+        """Relayout the 66 convolutions into kernel layout, cached on the parameters' version counters."""
+        params = dict(self.named_parameters())
+        key = (nterms, str(next(iter(params.values())).device),
+               tuple((p.data_ptr(), p._version) for p in params.values()))
+        if self._wcache is None or self._wcache[0] != key:
+            with torch.no_grad():
+                self._wcache = (key, RdnWeights(params, self.N_INPUTS, nterms))
+        return self._wcache[1]
+
+    def _run(self, *frames):
+        if len(frames) != self.N_INPUTS:
+            raise TypeError(f"{type(self).__name__}.forward takes {self.N_INPUTS} frames")
+        if torch.is_grad_enabled() and (any(f.requires_grad for f in frames) or
+                                         any(p.requires_grad for p in self.parameters())):
+            from ...autograd import rdn_apply        # training path (HIP backward)
+            return rdn_apply(self, frames)
+        nterms = PRECISIONS[self.precision or default_precision()]
+        return rdn_forward(self.kernel_weights(nterms), list(frames))
+
+
+class RDN_residual_interp_2_input(_RDNBase):
+    N_INPUTS = 2
+
+    def forward(self, B0, B1):
+        return self._run(B0, B1)
+
+
+class RDN_residual_interp_2_1_input(_RDNBase):
+    N_INPUTS = 3
+
+    def forward(self, I0, I1, I2):
+        return self._run(I0, I1, I2)
+
+
+class RDN_residual_interp_4_1_input(_RDNBase):
+    N_INPUTS = 5
+
+    def forward(self, B0, B1, B2, B3, B4):
+        return self._run(B0, B1, B2, B3, B4)
+
+
+class RDN_residual_interp_5_input(nn.Module):
+    """4-stage pyramid (reference RDN.py:337-405); lstm=True is the only constructible branch there."""
+
+    def __init__(self, lstm=False, GO=64, D=6):
+        super().__init__()
+        if not lstm:
+            raise NotImplementedError("reference RDN.py:358 references an undefined class when lstm=False")
+        self.lstm = lstm
+        self.model1_1 = RDN_residual_interp_2_input(G0=GO, D=D)
+        self.model1_2 = self.model1_1
+        self.model1_3 = self.model1_1
+        self.model1_4 = self.model1_1
+        self.model2_1 = RDN_residual_interp_2_1_input(G0=GO, D=D)
+        self.model2_2 = self.model2_1
+        self.model2_3 = self.model2_1
+        self.model3_1 = RDN_residual_interp_4_1_input(G0=GO, D=D)
+        self.model3_2 = self.model3_1
+        self.model4_1 = RDN_residual_interp_4_1_input(G0=GO, D=D)
+
+    def forward(self, B1, B3, B5, B7, B9, previous_input=None, stage1=None):
+        """`stage1`: optional precomputed (I2', I4', I6', I8') entries (None = compute) — lets the
+        2-window wrapper reuse the three stage-1 results that window 2 shares with window 1."""
+        s1 = stage1 or (None, None, None, None)
+        I2 = s1[0] if s1[0] is not None else self.model1_1(B1, B3)
+        I4 = s1[1] if s1[1] is not None else self.model1_2(B3, B5)
+        I6 = s1[2] if s1[2] is not None else self.model1_3(B5, B7)
+        I8 = s1[3] if s1[3] is not None else self.model1_4(B7, B9)
+        if previous_input is not None and previous_input[0] is not None:
+            p4, p6, p8, p5, p7, p6b = previous_input
+            I3 = self.model2_1(p4, I2, I4)
+            I5 = self.model2_2(p6, I4, I6)
+            I7 = self.model2_3(p8, I6, I8)
+            I4pp = self.model3_1(p5, B3, I3, I5, B5)
+            I6pp = self.model3_2(p7, B5, I5, I7, B7)
+            I5ppp = self.model4_1(p6b, I4, I4pp, I6pp, I6)
+        else:
+            I3 = self.model2_1(I2, I2, I4)
+            I5 = self.model2_2(I4, I4, I6)
+            I7 = self.model2_3(I6, I6, I8)
+            I4pp = self.model3_1(I3, B3, I3, I5, B5)
+            I6pp = self.model3_2(I5, B5, I5, I7, B7)
+            I5ppp = self.model4_1(I4, I4, I4pp, I6pp, I6)
+        self.I2_prime, self.I4_prime, self.I6_prime, self.I8_prime = I2, I4, I6, I8
+        self.I3_prime, self.I5_prime, self.I7_prime = I3, I5, I7
+        self.I4_prime_prime, self.I6_prime_prime, self.I5_prime_prime = I4pp, I6pp, I5ppp
+        return I2, I4, I6, I8, I3, I5, I7, I4pp, I6pp, I5ppp
+
+
+class RDN_residual_interp_5_input_ConvLSTM_L(nn.Module):
+    """Two overlapping 5-frame windows bridged by six ConvLSTM cells (reference RDN.py:408-465).
+
+    `reuse_schedule=True` (default) skips work the reference recomputes or discards, without changing
+    any returned value (verified bit-identical): window 2's stage-1 calls on (B3,B5),
+    (B5,B7), (B7,B9) equal window 1's I4', I6', I8' (same kernels, same inputs => same bits), and the six
+    ConvLSTM calls after window 2 feed nothing.  20 -> 17 RDN calls, 12 -> 6 cells.
+    `reuse_schedule=False` runs the reference's literal schedule (all 20 + 12)."""
+
+    def __init__(self, modelType="lstm"):
+        super().__init__()
+        self.modelType = modelType
+        self.clstm_4_prime = ConvLSTMCell(3, 3)
+        self.clstm_6_prime = ConvLSTMCell(3, 3)
+        self.clstm_8_prime = ConvLSTMCell(3, 3)
+        self.clstm_5_prime_prime = ConvLSTMCell(3, 3)
+        self.clstm_7_prime_prime = ConvLSTMCell(3, 3)
+        self.clstm_6_prime_prime_prime = ConvLSTMCell(3, 3)
+        self.model = RDN_residual_interp_5_input(lstm=True, GO=96, D=12)
+        self.prev_state = None         # inert in the reference too (RDN.py:419-420)
+        self.hidden_state = None
+        self.reuse_schedule = True
+        self.precision = None
+
+    def set_precision(self, precision):
+        if precision is not None and precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
+        self.precision = precision
+        for m in self.modules():
+            if isinstance(m, _RDNBase):
+                m.precision = precision
+        return self
+
+    def forward(self, B1, B3, B5, B7, B9, B11):
+        for t in (B1, B3, B5, B7, B9, B11):
+            if not t.is_cuda:
+                raise RuntimeError("bin_amd: bin_stage4 runs on a HIP device only (no CPU fallback; "
+                                   "see oracle/ for the test-only CPU restatement)")
+        cells = (self.clstm_4_prime, self.clstm_6_prime, self.clstm_8_prime, self.clstm_5_prime_prime,
+                 self.clstm_7_prime_prime, self.clstm_6_prime_prime_prime)
+        picks = (1, 2, 3, 5, 6, 8)
+        states = [None] * 6
+        hidden = [None] * 6
+        res = []
+        windows = ((B1, B3, B5, B7, B9), (B3, B5, B7, B9, B11))
+        for wi, win in enumerate(windows):
+            stage1 = None
+            if wi == 1 and self.reuse_schedule:
+                stage1 = (res[0][1], res[0][2], res[0][3], None)
+            out = self.model(*win, hidden, stage1=stage1)
+            self.Ft_p_1 = out
+            last = wi == len(windows) - 1
+            if self.modelType == "lstm" and not (last and self.reuse_schedule):
+                hidden = []
+                for k, (idx, cell) in enumerate(zip(picks, cells)):
+                    h, states[k] = cell(out[idx], states[k])
+                    hidden.append(h)
+            elif self.modelType != "lstm":
+                hidden = [out[i] for i in picks]
+            res.append(out)
+        return (res[0][0], res[0][1], res[0][2], res[0][3], res[0][4], res[0][5], res[0][6],
+                res[0][7], res[0][8], res[0][9], res[1][3], res[1][6], res[1][8], res[1][9])
+
+
+def bin_stage4_lstm():
+    """reference RDN.py:469-471."""
+    return RDN_residual_interp_5_input_ConvLSTM_L()

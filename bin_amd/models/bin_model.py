@@ -1,0 +1,352 @@
+"""bin_model — the drop-in wrapper API of the reference (models/bin_model.py:21-615) over the
+MI355X-native generator: same method names, argument meaning, stored attributes (`Ft_p`, `loss`,
+`loss_list`, `B1..B11`, `I1..I11`), the same 14-output / 17-term loss assembly and checkpoint format.
+
+Differences, all on the parallelism side:
+  * one process per GPU.  Non-dist: the generator is wrapped in `SingleProcessParallel`, which only
+    provides the `.module` attribute DataParallel users expect (no per-call replicate/scatter/gather).
+  * dist (`opt['dist']`): gradients are averaged across ranks with ONE flat all-reduce per step on the
+    default process group (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests) —
+    45.77 MB fp32, the message DistributedDataParallel would send in two buckets.
+Only nframes == 6 exists in the reference's factory (`bin_stage4`); other values raise.
+"""
+import logging
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import lr_scheduler
+from . import networks
+from .base_model import BaseModel, unwrap
+from .loss import CharbonnierLoss
+from ..utils import util
+from ..utils.util import AverageMeter
+
+logger = logging.getLogger("base")
+
+
+def _get(d, key, default=None):
+    """opt access that works for plain dicts and the reference's NoneDict."""
+    try:
+        v = d[key]
+    except (KeyError, TypeError):
+        return default
+    return default if v is None else v
+
+
+class SingleProcessParallel(nn.Module):
+    """Stand-in for nn.DataParallel in the one-process-per-GPU design: exposes `.module`, forwards calls."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+
+class FlatGradAllReduce:
+    """Average gradients over the default process group with one flat buffer (C1 in SURVEY.md §2c)."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        self.numel = sum(p.numel() for p in self.params)
+
+    def __call__(self):
+        import torch.distributed as dist
+        world = dist.get_world_size()
+        if world == 1:
+            return
+        dev = self.params[0].device
+        flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        o = 0
+        for p in self.params:
+            if p.grad is not None:
+                flat[o:o + p.numel()].copy_(p.grad.reshape(-1))
+            o += p.numel()
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(world)
+        o = 0
+        for p in self.params:
+            g = flat[o:o + p.numel()].view_as(p)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            o += p.numel()
+
+
+class bin_model(BaseModel):
+    """The model for Blurry Video Frame Interpolation (reference bin_model.py:21)."""
+
+    def __init__(self, opt, netG=None, cri_pix=None):
+        """`netG` / `cri_pix` (bin_amd extension, used by the CPU host-logic tests): inject a pre-built
+        generator / criterion instead of define_G(opt) / the HIP CharbonnierLoss.  The product objects have
+        no CPU path and raise on CPU tensors."""
+        super().__init__(opt)
+        self.nframes = int(opt["network_G"]["nframes"])
+        self.version = int(opt["network_G"]["version"])
+        if self.nframes != 6:
+            raise NotImplementedError("bin_amd: only nframes == 6 (bin_stage4) exists in the reference factory")
+        if opt["dist"]:
+            self.rank = torch.distributed.get_rank()
+        else:
+            self.rank = -1
+        train_opt = opt["train"] if "train" in opt else None
+
+        self.netG = (netG if netG is not None else networks.define_G(opt)).to(self.device)
+        self.netG = SingleProcessParallel(self.netG)
+        self.grad_sync = FlatGradAllReduce(self.netG.parameters()) if opt["dist"] else None
+        if opt["dist"]:
+            self._broadcast_parameters()
+
+        self.print_network()
+        self.load()
+
+        if self.is_train:
+            self.netG.train()
+            self.loss_type = loss_type = train_opt["pixel_criterion"]
+            if loss_type == "l1":
+                self.cri_pix = nn.L1Loss(reduction="sum").to(self.device)
+            elif loss_type == "l2":
+                self.cri_pix = nn.MSELoss(reduction="sum").to(self.device)
+            elif loss_type == "cb":
+                self.cri_pix = CharbonnierLoss().to(self.device)
+            else:
+                raise NotImplementedError("Loss type [{:s}] is not recognized.".format(loss_type))
+            if cri_pix is not None:
+                self.cri_pix = cri_pix
+            self.l_pix_w = train_opt["pixel_weight"]
+
+            wd_G = _get(train_opt, "weight_decay_G", 0)
+            optim_params = []
+            for k, v in self.netG.named_parameters():
+                if v.requires_grad:
+                    optim_params.append(v)
+                elif self.rank <= 0:
+                    logger.warning("Params [{:s}] will not optimize.".format(k))
+            self.optimizer_G = torch.optim.Adam(optim_params, lr=train_opt["lr_G"], weight_decay=wd_G,
+                                                betas=(train_opt["beta1"], train_opt["beta2"]))
+            self.optimizers.append(self.optimizer_G)
+
+            scheme = train_opt["lr_scheme"]
+            if scheme == "MultiStepLR":
+                for optimizer in self.optimizers:
+                    self.schedulers.append(lr_scheduler.MultiStepLR_Restart(
+                        optimizer, train_opt["lr_steps"], restarts=_get(train_opt, "restarts"),
+                        weights=_get(train_opt, "restart_weights"), gamma=train_opt["lr_gamma"],
+                        clear_state=_get(train_opt, "clear_state", False)))
+            elif scheme == "CosineAnnealingLR_Restart":
+                for optimizer in self.optimizers:
+                    self.schedulers.append(lr_scheduler.CosineAnnealingLR_Restart(
+                        optimizer, train_opt["T_period"], eta_min=train_opt["eta_min"],
+                        restarts=_get(train_opt, "restarts"), weights=_get(train_opt, "restart_weights")))
+            elif scheme == "ReduceLROnPlateau":
+                for optimizer in self.optimizers:
+                    self.schedulers.append(torch.optim.lr_scheduler.ReduceLROnPlateau(
+                        optimizer, "min", factor=train_opt["factor"], patience=train_opt["patience"]))
+            else:
+                raise NotImplementedError()
+            self.avg_log_dict = OrderedDict()
+            self.inst_log_dict = OrderedDict()
+
+    # ------------------------------------------------------------------ distributed helpers
+    def _broadcast_parameters(self):
+        import torch.distributed as dist
+        if dist.get_world_size() > 1:
+            for p in self.netG.parameters():
+                dist.broadcast(p.data, src=0)
+
+    # ------------------------------------------------------------------ training step (bin_model.py:130-141)
+    def optimize_parameters(self, step):
+        ft = _get(self.opt["train"], "ft_tsa_only")
+        if ft and step < ft:
+            self.set_params_lr_zero()
+        self.optimizer_G.zero_grad()
+        self.Ft_p = self.forward()
+        self.loss, self.loss_list = self.get_loss(ret=1)
+        l_pix = self.l_pix_w * self.loss
+        l_pix.backward()
+        if self.grad_sync is not None:
+            self.grad_sync()
+        self.optimizer_G.step()
+
+    def set_params_lr_zero(self):
+        self.optimizers[0].param_groups[0]["lr"] = 0
+
+    # ------------------------------------------------------------------ data staging (bin_model.py:147-274)
+    def feed_data(self, trainData, need_GT=True):
+        LQs, GTenh, GTinp = trainData["LQs"], trainData["GTenh"], trainData["GTinp"]   # B N C H W
+        for i, nm in enumerate(("B1", "B3", "B5", "B7", "B9", "B11")):
+            setattr(self, nm, LQs[:, i, ...].to(self.device))
+        for i, nm in enumerate(("I1", "I3", "I5", "I7", "I9", "I11")):
+            setattr(self, nm, GTenh[:, i, ...].to(self.device))
+        for i, nm in enumerate(("I2", "I4", "I6", "I8", "I10")):
+            setattr(self, nm, GTinp[:, i, ...].to(self.device))
+        self.batch, self.channel, self.height, self.width = (self.I1.size(k) for k in range(4))
+
+    def test_set_input(self, testData):
+        B1, B3, B5, B7, B9, B11, _ = testData
+        self.B1, self.B3, self.B5 = B1.to(self.device), B3.to(self.device), B5.to(self.device)
+        self.B7, self.B9, self.B11 = B7.to(self.device), B9.to(self.device), B11.to(self.device)
+        self.batch, self.channel, self.height, self.width = (self.B1.size(k) for k in range(4))
+
+    # ------------------------------------------------------------------ forward variants
+    def test(self):
+        self.netG.eval()
+        with torch.no_grad():
+            Ft_p = self.netG(self.B1, self.B3, self.B5, self.B7, self.B9, self.B11)
+        self.netG.train()
+        self.Ft_p = Ft_p
+        return Ft_p
+
+    def forward(self):
+        Ft_p = self.netG(self.B1, self.B3, self.B5, self.B7, self.B9, self.B11)
+        self.Ft_p = Ft_p
+        return Ft_p
+
+    def test_forward(self):
+        self.Ft_p = self.netG(self.B1, self.B3, self.B5, self.B7, self.B9, self.B11)
+
+    def reset_state(self):
+        self.netG.prev_state = None
+        self.netG.hidden_state = None
+
+    # ------------------------------------------------------------------ loss (bin_model.py:395-425)
+    def get_loss(self, ret=0):
+        loss_list = []
+        num, gt_list = self.get_info(mode=1)
+        assert num == len(gt_list)
+        for idx, gt in enumerate(gt_list):
+            loss_list.append(self.cri_pix(self.Ft_p[idx], gt))
+        loss = sum(loss_list) / len(loss_list)
+        if self.nframes == 6 and self.version == 2:
+            loss_list.append(self.cri_pix(self.Ft_p[1], self.Ft_p[7]))
+            loss_list.append(self.cri_pix(self.Ft_p[5], self.Ft_p[9]))
+            loss_list.append(self.cri_pix(self.Ft_p[2], self.Ft_p[8]))
+            loss = sum(loss_list) / len(loss_list)
+        loss_list = loss_list[:num]
+        if ret == 1:
+            return loss, loss_list
+        self.loss = loss
+        self.loss_list = loss_list
+
+    def get_info(self, mode=0):
+        num = 14
+        if mode == 0:
+            return num
+        gt_list = [self.I2, self.I4, self.I6, self.I8, self.I3, self.I5, self.I7, self.I4, self.I6,
+                   self.I5, self.I10, self.I9, self.I8, self.I7]
+        if mode == 1:
+            return num, gt_list
+        return num, gt_list, [self.B1, self.B3, self.B5, self.B7, self.B9, self.B11]
+
+    # ------------------------------------------------------------------ logging / meters
+    def get_current_log(self, mode="train"):
+        num = self.get_info()
+        self.avg_log_dict, self.avg_psnr_dict, self.inst_log_dict = OrderedDict(), OrderedDict(), OrderedDict()
+        if mode == "train":
+            for i in range(num):
+                self.avg_log_dict[str(i)] = self.train_loss_total[i].avg
+                self.inst_log_dict[str(i)] = self.loss_list[i].item()
+            self.avg_log_dict["Al"] = self.train_loss_total[-1].avg
+            return self.inst_log_dict, self.avg_log_dict
+        if mode == "val":
+            psnr_total_avg = ssim_total_avg = 0
+            for i in range(num):
+                self.avg_log_dict["Al" + str(i)] = self.val_loss_total[i].avg
+                self.avg_psnr_dict["Ap" + str(i)] = self.psnr_interp[i].avg
+                psnr_total_avg += self.psnr_interp[i].avg
+                ssim_total_avg += self.ssim_interp[i].avg
+            self.avg_log_dict["Al"] = self.val_loss_total[-1].avg
+            self.avg_psnr_dict["Ap"] = psnr_total_avg / num
+            return (self.avg_log_dict, self.avg_psnr_dict, psnr_total_avg / num, ssim_total_avg / num,
+                    self.val_loss_total[-1].avg)
+
+    def get_current_visuals(self, need_GT=True):
+        num, gt_list, lq_list = self.get_info(mode=2)
+        out = OrderedDict()
+        out["LQ"] = [d.detach()[0].float().cpu() for d in lq_list]
+        out["rlt"] = [self.Ft_p[i].detach()[0].float().cpu() for i in range(num)]
+        if need_GT:
+            out["GT"] = [d.detach()[0].float().cpu() for d in gt_list]
+        return out
+
+    def train_AverageMeter(self):
+        self.train_loss_total = [AverageMeter() for _ in range(self.get_info() + 1)]
+
+    def train_AverageMeter_update(self):
+        num = len(self.loss_list)
+        for i in range(num):
+            self.train_loss_total[i].update(self.loss_list[i].item(), 1)
+        self.train_loss_total[num].update(self.loss.item(), 1)
+
+    def train_AverageMeter_reset(self):
+        for m in self.train_loss_total:
+            m.reset()
+
+    def val_loss_AverageMeter(self):
+        self.val_loss_total = [AverageMeter() for _ in range(self.get_info() + 1)]
+
+    def val_loss_AverageMeter_update(self, loss_list, avg_loss):
+        num = len(loss_list)
+        for i in range(num):
+            self.val_loss_total[i].update(loss_list[i].item(), 1)
+        self.val_loss_total[num].update(avg_loss.item(), 1)
+
+    def val_loss_AverageMeter_reset(self):
+        for m in self.val_loss_total:
+            m.reset()
+
+    def val_AverageMeter_para(self):
+        num = self.get_info()
+        self.psnr_interp = [AverageMeter() for _ in range(num)]
+        self.ssim_interp = [AverageMeter() for _ in range(num)]
+
+    def val_AverageMeter_para_update(self, psnr_interp_t, ssim_interp_t):
+        for i in range(len(self.psnr_interp)):
+            self.psnr_interp[i].update(psnr_interp_t[i], 1)
+            self.ssim_interp[i].update(ssim_interp_t[i], 1)
+
+    def val_AverageMeter_para_reset(self):
+        for a, b in zip(self.psnr_interp, self.ssim_interp):
+            a.reset()
+            b.reset()
+
+    def compute_current_psnr_ssim(self, save=False, name=None, save_path=None):
+        """PSNR / SSIM of the 14 outputs vs GT through tensor2img (bin_model.py:564-589).  PNG saving needs
+        cv2, which is outside the hot path; `save=True` raises."""
+        if save:
+            raise NotImplementedError("bin_amd: PNG writing (cv2) is out of scope of the hot path")
+        num = self.get_info()
+        visuals = self.get_current_visuals()
+        psnr, ssim = [], []
+        for i in range(num):
+            rlt_img = util.tensor2img(visuals["rlt"][i])
+            gt_img = util.tensor2img(visuals["GT"][i])
+            psnr.append(util.calculate_psnr(rlt_img, gt_img))
+            ssim.append(util.calculate_ssim(rlt_img, gt_img))
+        return psnr, ssim
+
+    # ------------------------------------------------------------------ IO
+    def print_network(self):
+        s, n = self.get_network_description(self.netG)
+        net_struc_str = "{} - {}".format(self.netG.__class__.__name__, unwrap(self.netG).__class__.__name__)
+        if self.rank <= 0:
+            logger.info("Network G structure: {}, with parameters: {:,d}".format(net_struc_str, n))
+            logger.info(s)
+
+    def load(self):
+        load_path_G = _get(self.opt["path"], "pretrain_model_G")
+        if load_path_G is not None:
+            logger.info("Loading model for G [{:s}] ...".format(load_path_G))
+            self.load_network(load_path_G, self.netG, _get(self.opt["path"], "strict_load", True))
+
+    def save(self, iter_label):
+        self.save_network(self.netG, "G", iter_label)
+
+    @staticmethod
+    def get_lr(optimizer):
+        for param_group in optimizer.param_groups:
+            return param_group["lr"]

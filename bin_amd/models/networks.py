@@ -1,0 +1,15 @@
+"""Generator factory (reference models/networks.py:5-14)."""
+from .archs import RDN as RDN_arch
+
+
+def define_G(opt):
+    opt_net = opt["network_G"]
+    which_model = opt_net["which_model_G"]
+    if which_model == "bin_stage4":
+        netG = RDN_arch.bin_stage4_lstm()
+        prec = opt_net.get("precision") if hasattr(opt_net, "get") else None
+        if prec:
+            netG.set_precision(prec)           # bin_amd extension: "f16" | "f16x3"
+    else:
+        raise NotImplementedError("Generator model [{:s}] not recognized".format(which_model))
+    return netG

@@ -1,0 +1,105 @@
+"""Host helpers of the evaluation harness (counterparts of reference utils/util.py:113-137, 201-231,
+utils/AverageMeter.py and the padding rule of test.py:348-366).  Pure numpy/torch host code."""
+import math
+
+import numpy as np
+import torch
+
+
+class AverageMeter:
+    """reference utils/AverageMeter.py:1-16."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = self.avg = self.sum = self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+
+def tensor2img(tensor, out_type=np.uint8, min_max=(0, 1)):
+    """3-D (C,H,W) RGB tensor or 2-D tensor -> HWC BGR uint8 (reference utils/util.py:113-137:
+    clamp, scale to [0,1], x255, round, RGB->BGR).  4-D grids (torchvision.make_grid) are not built."""
+    t = tensor.detach().squeeze().float().cpu().clamp(*min_max)
+    t = (t - min_max[0]) / (min_max[1] - min_max[0])
+    if t.dim() == 3:
+        img = np.transpose(t.numpy()[[2, 1, 0], :, :], (1, 2, 0))
+    elif t.dim() == 2:
+        img = t.numpy()
+    else:
+        raise TypeError(f"Only support 3D and 2D tensor. But received with dimension: {t.dim()}")
+    if out_type == np.uint8:
+        img = (img * 255.0).round()
+    return img.astype(out_type)
+
+
+def calculate_psnr(img1, img2):
+    """reference utils/util.py:201-208 (inputs in [0,255])."""
+    mse = np.mean((img1.astype(np.float64) - img2.astype(np.float64)) ** 2)
+    if mse == 0:
+        return float("inf")
+    return 20 * math.log10(255.0 / math.sqrt(mse))
+
+
+def _gauss_window(size=11, sigma=1.5):
+    ax = np.arange(size, dtype=np.float64) - (size - 1) / 2.0
+    k = np.exp(-(ax ** 2) / (2 * sigma ** 2))
+    k /= k.sum()
+    return np.outer(k, k)
+
+
+def _filter_valid(img, win):
+    from numpy.lib.stride_tricks import sliding_window_view
+    v = sliding_window_view(img, win.shape)
+    return np.einsum("ijkl,kl->ij", v, win)
+
+
+def ssim(img1, img2):
+    """reference utils/util.py:211-231 ('valid' 11x11 Gaussian, sigma 1.5), numpy only."""
+    C1, C2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+    a, b = img1.astype(np.float64), img2.astype(np.float64)
+    win = _gauss_window()
+    mu1, mu2 = _filter_valid(a, win), _filter_valid(b, win)
+    s1 = _filter_valid(a * a, win) - mu1 ** 2
+    s2 = _filter_valid(b * b, win) - mu2 ** 2
+    s12 = _filter_valid(a * b, win) - mu1 * mu2
+    m = ((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 ** 2 + mu2 ** 2 + C1) * (s1 + s2 + C2))
+    return m.mean()
+
+
+def calculate_ssim(img1, img2):
+    """reference utils/util.py:234-251: per-channel mean for HWC images."""
+    if img1.shape != img2.shape:
+        raise ValueError("Input images must have the same dimensions.")
+    if img1.ndim == 2:
+        return ssim(img1, img2)
+    if img1.ndim == 3:
+        if img1.shape[2] == 3:
+            return float(np.mean([ssim(img1[..., i], img2[..., i]) for i in range(3)]))
+        if img1.shape[2] == 1:
+            return ssim(np.squeeze(img1), np.squeeze(img2))
+    raise ValueError("Wrong input image dimensions.")
+
+
+def pad_sizes(h, w):
+    """test.py:348-366 -> (left, right, top, bottom): pad up to the next multiple of 128 (centred), or
+    32+32 when already a multiple."""
+    def one(n):
+        if n != ((n >> 7) << 7):
+            padded = ((n >> 7) + 1) << 7
+            a = int((padded - n) / 2)
+            return a, padded - n - a
+        return 32, 32
+    l, r = one(w)
+    t, b = one(h)
+    return l, r, t, b
+
+
+def replicate_pad(x, pads):
+    """torch.nn.ReplicationPad2d([l, r, t, b]) (test.py:368-371)."""
+    return torch.nn.functional.pad(x, list(pads), mode="replicate")

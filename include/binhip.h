@@ -127,6 +127,13 @@ int binhip_rdn_forward(const BinRdnPlan* plan, const float* const* inputs /* hos
                        n_inputs device ptrs, fp32 [N,3,H,W] */, float* out /* fp32 [N,3,H,W] */,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- live kernel timing (bench.py roofline leg) --------------------------------------------------
+ * Between begin/end every conv launch whose (ksize, cout_pad, epilogue) matches is bracketed by a
+ * hipEvent pair recorded on the launch stream; end() synchronises on them and returns the summed
+ * kernel time.  Host-side only; at most `max_launches` (<= 16384) launches are recorded.           */
+int binhip_profile_begin(int ksize, int cout_pad, int epilogue, int max_launches);
+int binhip_profile_end(double* total_ms, int* launches);
+
 #ifdef __cplusplus
 }
 #endif
