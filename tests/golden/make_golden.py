@@ -248,8 +248,32 @@ def main():
         assert tuple(pads[f"{hh}x{ww}"]) == O.pad_sizes(hh, ww)
     save("g4_harness", t1=tt, t2=tt2, img1=i1, img2=i2, psnr=np.float64(ps),
          **{"pad." + k: v for k, v in pads.items()})
+    lr_goldens()
     print("all fixtures written; oracle == reference on every fixture")
 
 
+def lr_goldens():
+    """G6: LR curves of the reference's restartable schedulers (models/lr_scheduler.py:10-66)."""
+    import models.lr_scheduler as REF_LRS
+    curves = {}
+    for tag, mk in (("multistep", lambda o: REF_LRS.MultiStepLR_Restart(o, [5, 12, 20], restarts=[15], weights=[0.5],
+                                                                        gamma=0.5, clear_state=False)),
+                    ("cosine", lambda o: REF_LRS.CosineAnnealingLR_Restart(o, [10, 10, 10], restarts=[10, 20],
+                                                                           weights=[1, 0.5], eta_min=1e-7))):
+        p = torch.nn.Parameter(torch.zeros(1))
+        o = torch.optim.Adam([p], lr=1e-4)
+        s = mk(o)
+        lrs = []
+        for _ in range(30):
+            o.step()
+            s.step()
+            lrs.append(o.param_groups[0]["lr"])
+        curves[tag] = np.array(lrs, dtype=np.float64)
+    save("g6_lr", **curves)
+
+
 if __name__ == "__main__":
-    main()
+    if "--lr-only" in sys.argv:
+        lr_goldens()
+    else:
+        main()

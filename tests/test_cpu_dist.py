@@ -1,0 +1,80 @@
+"""CPU, world_size 2, gloo: the N>1 paths — flat gradient all-reduce of the training wrapper (DP) and
+window sharding of inference (no data-path collective, a gather of PSNR sums only)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import REPO
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, tmp, q):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from test_cpu_host import _cpu_model
+        from conftest import load_golden
+        g = load_golden("g3_train")
+        # global batch of 2 = the golden sample twice -> rank r gets one copy; averaged grads must equal
+        # the single-sample golden gradients, and both ranks must hold identical parameters afterwards
+        m = _cpu_model(tmp, dist=True)
+        m.feed_data({"LQs": torch.from_numpy(g["LQs"]), "GTenh": torch.from_numpy(g["GTenh"]),
+                     "GTinp": torch.from_numpy(g["GTinp"])})
+        if rank == 1:                       # perturb rank 1's data: grads differ before the all-reduce
+            m.B1 = m.B1 * 0.5
+        m.optimize_parameters(1)
+        named = dict(m.netG.module.named_parameters())
+        key = "model.model1_1.SFENet1.weight"
+        q.put((rank, float(m.loss), named[key].grad.double().sum().item(), named[key].detach().double().sum().item()))
+        from bin_amd.harness import shard_windows
+        q.put((rank, "shard", shard_windows(1287, rank, world)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_grad_allreduce_and_sharding(tmp_path):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in range(4)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    train = sorted([g for g in got if g[1] != "shard"])
+    shards = sorted([g for g in got if g[1] == "shard"])
+    assert train[0][1] != train[1][1]                      # different local losses (different data)
+    assert abs(train[0][2] - train[1][2]) < 1e-9           # identical averaged gradients
+    assert abs(train[0][3] - train[1][3]) < 1e-12          # identical parameters after the step
+    (a0, a1), (b0, b1) = shards[0][2], shards[1][2]
+    assert a0 == 0 and a1 == b0 and b1 == 1287 and abs((a1 - a0) - (b1 - b0)) <= 1
+
+
+def test_shard_windows_covers_everything():
+    from bin_amd.harness import shard_windows
+    for n in (0, 1, 7, 8, 1287):
+        for world in (1, 2, 3, 8):
+            spans = [shard_windows(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for (a, b), (c, d) in zip(spans, spans[1:]):
+                assert b == c
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,85 @@
+"""CPU: the oracle (oracle/rdn_oracle.py) against every golden fixture the reference produced
+(tests/golden/make_golden.py imports the reference in the build container and writes them)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+from oracle import rdn_oracle as O
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_pixel_reshuffle():
+    g = load_golden("g1_pixel_reshuffle")
+    assert torch.equal(O.pixel_reshuffle(T(g["x"]), 2), T(g["y"]))
+
+
+def test_convs_are_plain_conv2d(canon_cpu):
+    g = load_golden("g1_convs")
+    names = {"k3_sfe2": ("model1.SFENet2", 1), "k5_lff": ("model1.RDBs.0.LFF", 0), "k2_sfe1_36": ("model2.SFENet1", 2)}
+    for key, (wn, pad) in names.items():
+        y = F.conv2d(T(g[key + ".x"]), canon_cpu[wn + ".weight"], canon_cpu[wn + ".bias"], padding=pad)
+        assert float((y - T(g[key + ".y"])).abs().max()) <= 1e-5
+
+
+def test_charbonnier():
+    g = load_golden("g1_charbonnier")
+    x = T(g["x"]).requires_grad_(True)
+    l = O.charbonnier(x, T(g["y"]))
+    l.backward()
+    assert abs(float(l) - float(g["loss"])) <= 1e-7
+    assert float((x.grad - T(g["gx"])).abs().max()) <= 1e-9
+
+
+def test_rdb(canon_cpu):
+    g = load_golden("g2_rdb")
+    y = O.rdb(T(g["x"]), canon_cpu, "model1.RDBs.0")
+    assert float((y - T(g["y"])).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("set_name,k", [("model1", 2), ("model2", 3), ("model3", 5), ("model4", 5)])
+def test_rdn(set_name, k, canon_cpu):
+    g = load_golden(f"g2_rdn_{set_name}")
+    y = O.rdn([T(g[f"in{i}"]) for i in range(k)], canon_cpu, set_name)
+    assert float((y - T(g["y"])).abs().max()) <= 1e-5
+
+
+def test_convlstm(canon_cpu):
+    g = load_golden("g2_convlstm")
+    w, b = canon_cpu["clstm_6_prime.Gates.weight"], canon_cpu["clstm_6_prime.Gates.bias"]
+    h1, st1 = O.convlstm_cell(T(g["x1"]), None, w, b)
+    h2, st2 = O.convlstm_cell(T(g["x2"]), st1, w, b)
+    for got, key in ((h1, "h1"), (st1[0], "c1"), (h2, "h2"), (st2[0], "c2")):
+        assert float((got - T(g[key])).abs().max()) <= 1e-6
+
+
+def test_resblock():
+    g = load_golden("g5_resblock")
+    y = O.residual_block_nobn(T(g["x"]), T(g["w1"]), T(g["b1"]), T(g["w2"]), T(g["b2"]))
+    assert float((y - T(g["y"])).abs().max()) <= 1e-6
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_whole_net(tag, canon_cpu):
+    from bin_amd.weights import synthetic_frames
+    g = load_golden(f"g3_net_{tag}")
+    n, _, h, w = [int(v) for v in g["shape"]]
+    with torch.no_grad():
+        out = O.bin_stage4_forward(synthetic_frames(int(g["seed_x"]), n, h, w, 6), canon_cpu)
+    ref = T(g["out"])
+    assert max(float((o - r).abs().max()) for o, r in zip(out, ref)) <= 1e-5
+
+
+def test_harness_helpers():
+    g = load_golden("g4_harness")
+    i1, i2 = O.tensor2img(T(g["t1"])), O.tensor2img(T(g["t2"]))
+    assert np.array_equal(i1, g["img1"]) and np.array_equal(i2, g["img2"])
+    assert O.calculate_psnr(i1, i2) == float(g["psnr"])
+    for key in g.files:
+        if key.startswith("pad."):
+            h, w = [int(v) for v in key[4:].split("x")]
+            assert O.pad_sizes(h, w) == tuple(int(v) for v in g[key])
