@@ -24,6 +24,14 @@ class BinRdnPlan(C.Structure):
                 ("bias", C.c_void_p * RDN_LAYERS)]
 
 
+class BinRdnBwdPlan(C.Structure):
+    _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("n_inputs", C.c_int32),
+                ("nterms", C.c_int32), ("reserved", C.c_int32),
+                ("wt_hi", C.c_void_p * RDN_LAYERS), ("wt_lo", C.c_void_p * RDN_LAYERS),
+                ("zero_bias", C.c_void_p),
+                ("dw", C.c_void_p * RDN_LAYERS), ("db", C.c_void_p * RDN_LAYERS), ("gin", C.c_void_p * 5)]
+
+
 _SIGNATURES = {
     "binhip_version": (C.c_int, []),
     "binhip_device_cus": (C.c_int, []),
@@ -46,6 +54,27 @@ _SIGNATURES = {
                                          C.c_void_p]),
     "binhip_charbonnier_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p]),
+    "binhip_weights_relayout_dgrad": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "binhip_conv2d_bwd_data": (C.c_int, [C.POINTER(BinConvDesc)] + [C.c_void_p] * 7 + [C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]),
+    "binhip_wgrad_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
+    "binhip_conv2d_bwd_weight": (C.c_int, [C.POINTER(BinConvDesc)] + [C.c_void_p] * 6 + [C.c_size_t, C.c_void_p,
+                                           C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "binhip_grad_scale": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "binhip_nchw_to_planes_scaled": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.c_void_p]),
+    "binhip_unshuffle_planes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]),
+    "binhip_unpack_input_grads": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                            C.c_int, C.POINTER(C.c_void_p), C.c_void_p]),
+    "binhip_convlstm_bwd_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "binhip_convlstm_bwd": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_size_t] + [C.c_void_p] * 6),
+    "binhip_rdn_backward_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
+    "binhip_rdn_backward": (C.c_int, [C.POINTER(BinRdnBwdPlan), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                      C.c_size_t, C.c_void_p]),
     "binhip_profile_begin": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "binhip_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "binhip_rdn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -1,0 +1,127 @@
+"""Training path: torch.autograd.Function wrappers whose backward is hand-written HIP
+(counterpart of the autograd graph the reference builds through ATen when bin_model.py:140 calls
+`l_pix.backward()`).
+
+* `_RdnFn`   — one whole RDN sub-network: forward = binhip_rdn_forward into a PRIVATE workspace that doubles
+               as the saved activations (concat-free block buffers); backward = binhip_rdn_backward
+               (dgrad on the forward conv kernel with transposed/flipped weights, MFMA wgrad with LDS
+               transpose reads, fused ReLU masks / skip adds / PixelShuffle inverse).
+* `_ConvLstmFn` — ConvLSTMCell (RDN.py:50-95) forward/backward kernels.
+Training precision defaults to "f16x3" (fp32-class gradients); set BIN_AMD_TRAIN_PRECISION=f16 to trade
+gradient accuracy (~1e-3 relative) for speed.
+"""
+import ctypes as C
+import os
+
+import torch
+
+from . import _lib as L
+from .ops import _ptr, _stream
+from .rdn_plan import layer_names, rdn_forward, workspace
+
+
+def train_precision(module):
+    from .models.archs.RDN import PRECISIONS
+    p = module.precision or os.environ.get("BIN_AMD_TRAIN_PRECISION", "f16x3")
+    return PRECISIONS[p]
+
+
+class _RdnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, nterms, n_frames, *args):
+        frames = [a.contiguous().float() for a in args[:n_frames]]
+        weights = module.kernel_weights(nterms)
+        n, _, h, w = frames[0].shape
+        lib = L.lib()
+        nbytes = lib.binhip_rdn_workspace_bytes(n, h, w, n_frames, nterms)
+        if nbytes == 0:
+            raise RuntimeError(f"bin_amd: unsupported RDN shape N={n} H={h} W={w}")
+        saved = torch.empty(nbytes, dtype=torch.uint8, device=frames[0].device)
+        out = rdn_forward(weights, frames, ws=saved)
+        ctx.module, ctx.nterms, ctx.n_frames = module, nterms, n_frames
+        ctx.saved_ws = saved
+        ctx.dims = (n, h, w)
+        ctx.param_meta = [(tuple(a.shape), a.device) for a in args[n_frames:]]
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        module, nterms, k = ctx.module, ctx.nterms, ctx.n_frames
+        n, h, w = ctx.dims
+        dev = gout.device
+        gout = gout.contiguous().float()
+        lib = L.lib()
+        dgw = module.kernel_weights(nterms).dgrad(module)
+        plan = L.BinRdnBwdPlan()
+        plan.N, plan.H, plan.W, plan.n_inputs, plan.nterms = n, h, w, k, nterms
+        dgw.fill_plan(plan)
+        grads = [torch.empty(shape, dtype=torch.float32, device=dev) for shape, _ in ctx.param_meta]
+        for i in range(L.RDN_LAYERS):
+            plan.dw[i] = grads[2 * i].data_ptr()
+            plan.db[i] = grads[2 * i + 1].data_ptr()
+        gins = []
+        for i in range(k):
+            if ctx.needs_input_grad[3 + i]:
+                g = torch.empty((n, 3, h, w), dtype=torch.float32, device=dev)
+                plan.gin[i] = g.data_ptr()
+                gins.append(g)
+            else:
+                plan.gin[i] = None
+                gins.append(None)
+        nbytes = lib.binhip_rdn_backward_workspace_bytes(n, h, w, k, nterms)
+        ws = workspace(nbytes, dev, key="bwd")
+        L.check(lib.binhip_rdn_backward(C.byref(plan), _ptr(ctx.saved_ws), ctx.saved_ws.numel(), _ptr(gout), _ptr(ws),
+                                        ws.numel(), _stream()), "rdn_backward")
+        ctx.saved_ws = None
+        pgrads = [g if ctx.needs_input_grad[3 + k + i] else None for i, g in enumerate(grads)]
+        return (None, None, None, *gins, *pgrads)
+
+
+def rdn_apply(module, frames):
+    """Differentiable call of one RDN sub-network (used by _RDNBase._run when grad is enabled)."""
+    nterms = train_precision(module)
+    params = dict(module.named_parameters())
+    flat = []
+    for nm in layer_names():
+        flat += [params[nm + ".weight"], params[nm + ".bias"]]
+    return _RdnFn.apply(module, nterms, len(frames), *frames, *flat)
+
+
+class _ConvLstmFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, c_prev, h_prev, weight, bias, forget_bias):
+        from . import ops
+        state = None if c_prev is None else [c_prev, h_prev]
+        h, (c, _) = ops.convlstm_cell(x, state, weight, bias, forget_bias)
+        ctx.save_for_backward(x.contiguous().float(), None if c_prev is None else c_prev.contiguous().float(),
+                              None if h_prev is None else h_prev.contiguous().float(),
+                              weight.detach().contiguous().float(), bias.detach().contiguous().float())
+        ctx.fb = float(forget_bias)
+        return h, c
+
+    @staticmethod
+    def backward(ctx, gh, gc):
+        x, cp, hp, w, b = ctx.saved_tensors
+        n, _, hh, ww = x.shape
+        dev = x.device
+        lib = L.lib()
+        gh = gh.contiguous().float() if gh is not None else None
+        gc = gc.contiguous().float() if gc is not None else None
+        if gh is None and gc is None:
+            return None, None, None, None, None, None
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gcp = torch.empty_like(x) if (cp is not None and ctx.needs_input_grad[1]) else None
+        ghp = torch.empty_like(x) if (hp is not None and ctx.needs_input_grad[2]) else None
+        dw = torch.zeros_like(w)
+        db = torch.zeros_like(b)
+        ws = workspace(lib.binhip_convlstm_bwd_workspace_bytes(n, hh, ww), dev, key="clstm")
+        L.check(lib.binhip_convlstm_bwd(_ptr(x), _ptr(cp), _ptr(hp), _ptr(w), _ptr(b), ctx.fb, n, hh, ww, _ptr(gh),
+                                        _ptr(gc), _ptr(ws), ws.numel(), _ptr(gx), _ptr(ghp), _ptr(gcp), _ptr(dw),
+                                        _ptr(db), _stream()), "convlstm_bwd")
+        return gx, gcp, ghp, dw, db, None
+
+
+def convlstm_apply(x, state, weight, bias, forget_bias):
+    c_prev, h_prev = (None, None) if state is None else state
+    h, c = _ConvLstmFn.apply(x, c_prev, h_prev, weight, bias, forget_bias)
+    return h, [c, h]

@@ -32,6 +32,9 @@ struct ConvKArgs {
     _Float16* y_lo;
     const _Float16* r_hi;
     const _Float16* r_lo;
+    const _Float16* r2_hi;    // second residual (backward-data accumulation), same indexing as y
+    const _Float16* r2_lo;
+    const _Float16* m_hi;     // ReLU mask source (saved forward activation, hi plane), same indexing as y
     float* out_f32;
     const float* img[5];
     long long group_stride;   // elements
@@ -40,6 +43,10 @@ struct ConvKArgs {
     int cpg;
     int tiles_x, tiles_y;
     int relu, has_res, nimg, cout;
+    int res_chunks;           // residual r applies to output chunks < res_chunks
+    int mask_from;            // mask applies to output chunks >= mask_from (when m_hi != null)
+    int y_cpg;                // output chunk grouping (<=0: one group)
+    long long y_group_stride;
 };
 
 template <int KS, int MT, int WM, int R, int WN, int KC, int NT, int NBUF, int EPI>
@@ -272,8 +279,12 @@ conv_mfma_kernel(const ConvKArgs a) {
                         o = (long long)(cc >> 4) * (plane_elems * 4) +
                             ((((long long)img * 2 * H + oy) * (2 * W) + ox) << 4) + (cc & 15);
                     } else {
-                        o = (long long)(co >> 4) * plane_elems + ((((long long)img * H + gy) * W + gx) << 4) + (co & 15);
-                        if (a.has_res) {
+                        const int och = co >> 4;
+                        const long long pix16 = ((((long long)img * H + gy) * W + gx) << 4) + (co & 15);
+                        o = (a.y_cpg > 0)
+                            ? (long long)(och / a.y_cpg) * a.y_group_stride + (long long)(och % a.y_cpg) * plane_elems + pix16
+                            : (long long)och * plane_elems + pix16;
+                        if (a.has_res && och < a.res_chunks) {
                             const half4 rh = *reinterpret_cast<const half4*>(a.r_hi + o);
 #pragma unroll
                             for (int j = 0; j < 4; ++j) v[j] += (float)rh[j];
@@ -283,9 +294,24 @@ conv_mfma_kernel(const ConvKArgs a) {
                                 for (int j = 0; j < 4; ++j) v[j] += (float)rl[j];
                             }
                         }
+                        if (a.r2_hi) {
+                            const half4 rh = *reinterpret_cast<const half4*>(a.r2_hi + o);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] += (float)rh[j];
+                            if constexpr (NT == 3) {
+                                const half4 rl = *reinterpret_cast<const half4*>(a.r2_lo + o);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v[j] += (float)rl[j];
+                            }
+                        }
                         if (a.relu) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                        }
+                        if (a.m_hi && och >= a.mask_from) {
+                            const half4 mh = *reinterpret_cast<const half4*>(a.m_hi + o);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = ((float)mh[j] > 0.f) ? v[j] : 0.f;
                         }
                     }
                     half4 hv, lv;
@@ -335,9 +361,12 @@ constexpr size_t PROF_MAX_PAIRS = 16384;
 }  // namespace
 
 int bh_conv_cout_block(int ksize, int cout_pad, int nterms) {
-    if (cout_pad == 256) return nterms == 3 ? 64 : 128;
+    if (cout_pad <= 0 || cout_pad % 32) return -1;
+    if (cout_pad == 256) return nterms == 3 ? 64 : 128;     // UPNet.0 (PixelShuffle epilogue)
     if (ksize == 5) return 32;
-    return cout_pad;
+    if (cout_pad % 96 == 0) return 96;
+    if (ksize == 3 && cout_pad % 64 == 0) return 64;
+    return 32;
 }
 
 static int bh_dispatch_conv(const ConvKArgs& a, int k, int cp, int nt, int e, hipStream_t s);
@@ -355,6 +384,12 @@ int bh_launch_conv(const BhConvCall& c, hipStream_t s) {
     a.bias = c.bias;
     a.y_hi = (_Float16*)c.y_hi; a.y_lo = (_Float16*)c.y_lo;
     a.r_hi = (const _Float16*)c.r_hi; a.r_lo = (const _Float16*)c.r_lo;
+    a.r2_hi = (const _Float16*)c.r2_hi; a.r2_lo = (const _Float16*)c.r2_lo;
+    a.m_hi = (const _Float16*)c.m_hi;
+    a.res_chunks = c.res_chunks > 0 ? c.res_chunks : (1 << 30);
+    a.mask_from = c.mask_from;
+    a.y_cpg = c.y_cpg; a.y_group_stride = c.y_group_stride;
+    if (c.r2_hi && d.nterms == 3 && !c.r2_lo) return BINHIP_E_ARG;
     a.out_f32 = c.y_f32;
     for (int i = 0; i < 5; ++i) a.img[i] = c.images[i];
     a.group_stride = d.x_group_stride;
@@ -379,9 +414,9 @@ int bh_launch_conv(const BhConvCall& c, hipStream_t s) {
     if (g_prof.active && k == g_prof.ks && cp == g_prof.cout_pad && e == g_prof.epi &&
         g_prof.used + 2 <= g_prof.ev.size()) {
         hipEvent_t e0 = g_prof.ev[g_prof.used], e1 = g_prof.ev[g_prof.used + 1];
-        hipEventRecord(e0, s);
+        (void)hipEventRecord(e0, s);
         const int rc = bh_dispatch_conv(a, k, cp, nt, e, s);
-        hipEventRecord(e1, s);
+        (void)hipEventRecord(e1, s);
         g_prof.used += 2;
         return rc;
     }
@@ -390,23 +425,27 @@ int bh_launch_conv(const BhConvCall& c, hipStream_t s) {
 
 static int bh_dispatch_conv(const ConvKArgs& a, int k, int cp, int nt, int e, hipStream_t s) {
     const int P = BINHIP_EPI_PLANES, S = BINHIP_EPI_SHUFFLE, F = BINHIP_EPI_FINAL;
-    //                         KS MT WM R WN KC NT NBUF EPI
+    const int cb = bh_conv_cout_block(k, cp, nt);
+    if (cb <= 0 || cp % cb) return BINHIP_E_SHAPE;
+    //                                   KS MT WM R WN KC NT NBUF EPI
     if (nt == 1) {
-        if (k == 3 && cp == 32 && e == P)  return launch_cfg<3, 1, 1, 4, 4, 1, 1, 2, P>(a, cp, s);
-        if (k == 3 && cp == 32 && e == F)  return launch_cfg<3, 1, 1, 4, 4, 1, 1, 2, F>(a, cp, s);
-        if (k == 3 && cp == 64 && e == P)  return launch_cfg<3, 2, 1, 2, 4, 1, 1, 2, P>(a, cp, s);
-        if (k == 3 && cp == 96 && e == P)  return launch_cfg<3, 3, 1, 2, 4, 1, 1, 2, P>(a, cp, s);
-        if (k == 1 && cp == 96 && e == P)  return launch_cfg<1, 3, 1, 2, 4, 4, 1, 2, P>(a, cp, s);
-        if (k == 5 && cp == 96 && e == P)  return launch_cfg<5, 1, 1, 4, 4, 1, 1, 2, P>(a, cp, s);
-        if (k == 3 && cp == 256 && e == S) return launch_cfg<3, 2, 2, 4, 2, 1, 1, 2, S>(a, cp, s);
+        if (e == F && k == 3 && cp == 32)  return launch_cfg<3, 1, 1, 4, 4, 1, 1, 2, F>(a, cp, s);
+        if (e == S && k == 3 && cp == 256) return launch_cfg<3, 2, 2, 4, 2, 1, 1, 2, S>(a, cp, s);
+        if (e == P && k == 3 && cb == 32)  return launch_cfg<3, 1, 1, 4, 4, 1, 1, 2, P>(a, cp, s);
+        if (e == P && k == 3 && cb == 64)  return launch_cfg<3, 2, 1, 2, 4, 1, 1, 2, P>(a, cp, s);
+        if (e == P && k == 3 && cb == 96)  return launch_cfg<3, 3, 1, 2, 4, 1, 1, 2, P>(a, cp, s);
+        if (e == P && k == 1 && cb == 32)  return launch_cfg<1, 1, 1, 4, 4, 4, 1, 2, P>(a, cp, s);
+        if (e == P && k == 1 && cb == 96)  return launch_cfg<1, 3, 1, 2, 4, 4, 1, 2, P>(a, cp, s);
+        if (e == P && k == 5 && cb == 32)  return launch_cfg<5, 1, 1, 4, 4, 1, 1, 2, P>(a, cp, s);
     } else {
-        if (k == 3 && cp == 32 && e == P)  return launch_cfg<3, 1, 1, 4, 4, 1, 3, 2, P>(a, cp, s);
-        if (k == 3 && cp == 32 && e == F)  return launch_cfg<3, 1, 1, 4, 4, 1, 3, 2, F>(a, cp, s);
-        if (k == 3 && cp == 64 && e == P)  return launch_cfg<3, 2, 1, 2, 4, 1, 3, 2, P>(a, cp, s);
-        if (k == 3 && cp == 96 && e == P)  return launch_cfg<3, 3, 1, 2, 4, 1, 3, 2, P>(a, cp, s);
-        if (k == 1 && cp == 96 && e == P)  return launch_cfg<1, 3, 1, 2, 4, 2, 3, 2, P>(a, cp, s);
-        if (k == 5 && cp == 96 && e == P)  return launch_cfg<5, 1, 1, 4, 4, 1, 3, 1, P>(a, cp, s);
-        if (k == 3 && cp == 256 && e == S) return launch_cfg<3, 1, 2, 4, 2, 1, 3, 2, S>(a, cp, s);
+        if (e == F && k == 3 && cp == 32)  return launch_cfg<3, 1, 1, 4, 4, 1, 3, 2, F>(a, cp, s);
+        if (e == S && k == 3 && cp == 256) return launch_cfg<3, 1, 2, 4, 2, 1, 3, 2, S>(a, cp, s);
+        if (e == P && k == 3 && cb == 32)  return launch_cfg<3, 1, 1, 4, 4, 1, 3, 2, P>(a, cp, s);
+        if (e == P && k == 3 && cb == 64)  return launch_cfg<3, 2, 1, 2, 4, 1, 3, 2, P>(a, cp, s);
+        if (e == P && k == 3 && cb == 96)  return launch_cfg<3, 3, 1, 2, 4, 1, 3, 2, P>(a, cp, s);
+        if (e == P && k == 1 && cb == 32)  return launch_cfg<1, 1, 1, 4, 4, 2, 3, 2, P>(a, cp, s);
+        if (e == P && k == 1 && cb == 96)  return launch_cfg<1, 3, 1, 2, 4, 2, 3, 2, P>(a, cp, s);
+        if (e == P && k == 5 && cb == 32)  return launch_cfg<5, 1, 1, 4, 4, 1, 3, 1, P>(a, cp, s);
     }
     return BINHIP_E_SHAPE;
 }
@@ -449,7 +488,74 @@ __global__ void relayout_kernel(const float* __restrict__ w, const float* __rest
     if (w_lo) *reinterpret_cast<half8*>(w_lo + t * 8) = lv;
 }
 
+// Backward-data weights: the dgrad of a stride-1 "same" conv is the same conv with in/out channels swapped and the
+// taps flipped: W'[r = ci][j = co][dy][dx] = W[co][ci][k-1-dy][k-1-dx].  shuffle != 0: the dgrad input channels j
+// are in the PixelShuffle-permuted order of UPNet.0's rows (j = sub*(cout/4) + c  <->  co = c*4 + sub).
+__global__ void relayout_dgrad_kernel(const float* __restrict__ w, int cout, int cin, int ks, int rows_pad,
+                                      int nchunks, int cb, int shuffle, _Float16* __restrict__ w_hi,
+                                      _Float16* __restrict__ w_lo, float* __restrict__ bias_out) {
+    const long long total = (long long)rows_pad * nchunks * ks * ks * 2;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < rows_pad) bias_out[t] = 0.f;
+    if (t >= total) return;
+    const int s = (int)(t & 1);
+    long long u = t >> 1;
+    const int row = (int)(u % cb); u /= cb;
+    const int tap = (int)(u % (ks * ks)); u /= (ks * ks);
+    const int c = (int)(u % nchunks); u /= nchunks;
+    const int zb = (int)u;
+    const int r = zb * cb + row;                      // = original input channel
+    const int cg = s ^ ((row >> 3) & 1);
+    const int dy = ks - 1 - tap / ks, dx = ks - 1 - tap % ks;
+    half8 hv, lv;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int j = c * 16 + cg * 8 + e;            // dgrad input channel = original output channel (maybe permuted)
+        int co = j;
+        if (shuffle) { const int cq = cout / 4; const int sub = j / cq, cc = j % cq; co = cc * 4 + sub; }
+        float v = 0.f;
+        if (r < cin && j < cout) v = w[(((long long)co * cin + r) * ks + dy) * ks + dx];
+        hv[e] = (_Float16)v;
+        lv[e] = (_Float16)(v - (float)hv[e]);
+    }
+    *reinterpret_cast<half8*>(w_hi + t * 8) = hv;
+    if (w_lo) *reinterpret_cast<half8*>(w_lo + t * 8) = lv;
+}
+
 extern "C" {
+
+int binhip_weights_relayout_dgrad(const float* w_oihw, int cout, int cin, int ksize, int rows_pad, int cin_chunks,
+                                  int cout_block, int shuffle_perm, void* w_hi, void* w_lo, float* bias_out,
+                                  void* stream) {
+    if (!w_oihw || !w_hi || !bias_out) return BINHIP_E_ARG;
+    if (rows_pad % 32 || cout_block <= 0 || rows_pad % cout_block || cout_block % 32) return BINHIP_E_SHAPE;
+    if (cin > rows_pad || cout > cin_chunks * 16) return BINHIP_E_SHAPE;
+    if (shuffle_perm && cout % 4) return BINHIP_E_SHAPE;
+    const long long total = (long long)rows_pad * cin_chunks * ksize * ksize * 2;
+    const long long nb = (total + 255) / 256;
+    hipLaunchKernelGGL(relayout_dgrad_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, w_oihw, cout, cin,
+                       ksize, rows_pad, cin_chunks, cout_block, shuffle_perm, (_Float16*)w_hi, (_Float16*)w_lo, bias_out);
+    BH_CHECK_LAUNCH();
+    return 0;
+}
+
+int binhip_conv2d_bwd_data(const BinConvDesc* d, const void* gy_hi, const void* gy_lo, const void* wt_hi,
+                           const void* wt_lo, const float* zero_bias, const void* res_hi, const void* res_lo,
+                           int res_chunks, const void* acc_hi, const void* acc_lo, const void* mask_hi, int mask_from,
+                           int y_cpg, int64_t y_group_stride, void* gx_hi, void* gx_lo, void* stream) {
+    if (!d) return BINHIP_E_ARG;
+    if (d->epilogue != BINHIP_EPI_PLANES) return BINHIP_E_ARG;
+    BhConvCall c;
+    c.d = *d;
+    c.x_hi = gy_hi; c.x_lo = gy_lo; c.w_hi = wt_hi; c.w_lo = wt_lo; c.bias = zero_bias;
+    c.r_hi = res_hi; c.r_lo = res_lo; c.res_chunks = res_chunks;
+    c.r2_hi = acc_hi; c.r2_lo = acc_lo;
+    c.m_hi = mask_hi; c.mask_from = mask_from;
+    c.y_cpg = y_cpg; c.y_group_stride = y_group_stride;
+    c.y_hi = gx_hi; c.y_lo = gx_lo; c.y_f32 = nullptr;
+    for (int i = 0; i < 5; ++i) c.images[i] = nullptr;
+    return bh_launch_conv(c, (hipStream_t)stream);
+}
 
 int binhip_profile_begin(int ksize, int cout_pad, int epilogue, int max_launches) {
     if (max_launches <= 0 || (size_t)max_launches > PROF_MAX_PAIRS) return BINHIP_E_ARG;

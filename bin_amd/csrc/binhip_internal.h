@@ -24,6 +24,12 @@ struct BhConvCall {
     const void *x_hi, *x_lo, *w_hi, *w_lo;
     const float* bias;
     const void *r_hi, *r_lo;
+    const void *r2_hi = nullptr, *r2_lo = nullptr;   // second residual (may alias y: in-place accumulate)
+    const void* m_hi = nullptr;                      // ReLU mask source planes (hi)
+    int res_chunks = 0;                              // 0: residual applies to every chunk
+    int mask_from = 0;
+    int y_cpg = 0;
+    int64_t y_group_stride = 0;
     void *y_hi, *y_lo;
     float* y_f32;
     const float* images[5];

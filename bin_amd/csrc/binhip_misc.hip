@@ -10,7 +10,9 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 // ---- fp32 NCHW -> chunk planes -----------------------------------------------------------------
 // one thread = one 16-byte slot (8 channels of one pixel)
 __global__ void nchw_to_planes_kernel(const float* __restrict__ x, int N, int C, int H, int W,
-                                      _Float16* __restrict__ y_hi, _Float16* __restrict__ y_lo) {
+                                      _Float16* __restrict__ y_hi, _Float16* __restrict__ y_lo,
+                                      const float* __restrict__ scale) {
+    const float sc = scale ? scale[0] : 1.f;
     const long long HW = (long long)H * W;
     const long long total = (long long)bh_chunks_dev(C) * N * HW * 2;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -24,7 +26,7 @@ __global__ void nchw_to_planes_kernel(const float* __restrict__ x, int N, int C,
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int c = ch * 16 + s * 8 + e;
-        const float v = (c < C) ? x[((long long)n * C + c) * HW + pix] : 0.f;
+        const float v = (c < C) ? x[((long long)n * C + c) * HW + pix] * sc : 0.f;
         hv[e] = (_Float16)v;
         lv[e] = (_Float16)(v - (float)hv[e]);
     }
@@ -174,6 +176,228 @@ charb_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, long 
     }
 }
 
+// ---- gradient scaling: scale = 2^floor(log2(target / amax)) so fp16 gradient planes neither overflow nor
+// underflow; sc[0] = scale, sc[1] = 1/scale.  Two-pass amax (deterministic).
+__global__ void __launch_bounds__(256)
+amax_partial_kernel(const float* __restrict__ x, long long n, float* __restrict__ partials) {
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+    __shared__ float sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+}
+__global__ void grad_scale_final_kernel(const float* __restrict__ partials, int nb, float target, float* __restrict__ sc) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float m = 0.f;
+    for (int i = 0; i < nb; ++i) m = fmaxf(m, partials[i]);
+    float s = 1.f;
+    if (m > 0.f && isfinite(m)) {
+        int e = (int)floorf(log2f(target / m));
+        e = e > 40 ? 40 : (e < -40 ? -40 : e);
+        s = exp2f((float)e);
+    }
+    sc[0] = s;
+    sc[1] = 1.f / s;
+}
+
+// ---- inverse PixelShuffle on chunk planes: [C/16] planes at 2H x 2W -> [4*C/16] planes at H x W, output chunk
+// sub*(C/16) + c (the channel order UPNet.0's permuted rows use).  Pure 16-byte slot copy.
+__global__ void unshuffle_planes_kernel(const _Float16* __restrict__ x, int N, int H, int W, int nch,
+                                        _Float16* __restrict__ y) {
+    const long long hw = (long long)H * W;
+    const long long total = (long long)4 * nch * N * hw * 2;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int s = (int)(t & 1);
+    long long u = t >> 1;
+    const long long pix = u % hw; u /= hw;
+    const int n = (int)(u % N); u /= N;
+    const int oc = (int)u;                       // output chunk = sub*nch + c
+    const int sub = oc / nch, c = oc - sub * nch;
+    const int yy = (int)(pix / W), xx = (int)(pix - (long long)yy * W);
+    const long long src = ((((long long)c * N + n) * (2 * H) + (2 * yy + (sub >> 1))) * (2 * W) + (2 * xx + (sub & 1))) * 16 + s * 8;
+    *reinterpret_cast<half8*>(y + t * 8) = *reinterpret_cast<const half8*>(x + src);
+}
+
+// ---- gradients w.r.t. the RDN's input frames: inverse of pack_inputs (pixel-shuffle of the SFENet1 input
+// gradient) un-scaled, plus the mean skip path gout / k (RDN.py:221/279/333).
+struct UnpackArgs {
+    float* out[5];
+    int nimg, N, H, W;
+};
+__global__ void unpack_input_grads_kernel(UnpackArgs a, const _Float16* __restrict__ g_hi, const _Float16* __restrict__ g_lo,
+                                          const float* __restrict__ gout, const float* __restrict__ sc) {
+    const long long HW = (long long)a.H * a.W;
+    const long long total = (long long)a.N * 3 * HW;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const long long pix = t % HW;
+    const int rgb = (int)((t / HW) % 3);
+    const int n = (int)(t / (3 * HW));
+    const int Y = (int)(pix / a.W), X = (int)(pix - (long long)Y * a.W);
+    const int h = a.H / 2, w = a.W / 2;
+    const float inv = sc ? sc[1] : 1.f;
+    const float skip = gout[t] / (float)a.nimg;
+    for (int im = 0; im < a.nimg; ++im) {
+        if (!a.out[im]) continue;
+        float v = skip;
+        if (g_hi) {
+            const int c = 4 * (im * 3 + rgb) + 2 * (Y & 1) + (X & 1);
+            const long long o = ((((long long)(c >> 4) * a.N + n) * h + (Y >> 1)) * w + (X >> 1)) * 16 + (c & 15);
+            float g = (float)g_hi[o];
+            if (g_lo) g += (float)g_lo[o];
+            v += g * inv;
+        }
+        a.out[im][t] = v;
+    }
+}
+
+// ---- ConvLSTM backward -----------------------------------------------------------------------------
+// pass 1: recompute the gates per pixel, emit dgates [N,12,H,W] (i,j,f,o order) and gc_prev
+__global__ void __launch_bounds__(256)
+convlstm_bwd_gates_kernel(const float* __restrict__ x, const float* __restrict__ cp, const float* __restrict__ hp,
+                          const float* __restrict__ w, const float* __restrict__ b, float fb, int N, int H, int W,
+                          const float* __restrict__ gh, const float* __restrict__ gc, float* __restrict__ dgates,
+                          float* __restrict__ gcp) {
+    __shared__ float ws[12 * 6 * 9 + 12];
+    for (int i = threadIdx.x; i < 12 * 54 + 12; i += blockDim.x) ws[i] = (i < 648) ? w[i] : b[i - 648];
+    __syncthreads();
+    const long long HW = (long long)H * W;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)N * HW) return;
+    const int n = (int)(t / HW);
+    const long long pix = t - (long long)n * HW;
+    const int y = (int)(pix / W), xx = (int)(pix - (long long)y * W);
+    float g[12];
+#pragma unroll
+    for (int o = 0; o < 12; ++o) g[o] = ws[648 + o];
+    const int nin = hp ? 6 : 3;
+    for (int ci = 0; ci < nin; ++ci) {
+        const float* src = (ci < 3) ? (x + ((long long)n * 3 + ci) * HW) : (hp + ((long long)n * 3 + (ci - 3)) * HW);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = y + dy - 1;
+            if (yy < 0 || yy >= H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int xq = xx + dx - 1;
+                if (xq < 0 || xq >= W) continue;
+                const float v = src[(long long)yy * W + xq];
+#pragma unroll
+                for (int o = 0; o < 12; ++o) g[o] = fmaf(ws[(o * 6 + ci) * 9 + dy * 3 + dx], v, g[o]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const long long o = ((long long)n * 3 + k) * HW + pix;
+        const float cprev = cp ? cp[o] : 0.f;
+        const float si = sigmoidf_(g[k]), tj = tanhf(g[3 + k]), sf = sigmoidf_(g[6 + k] + fb), so = sigmoidf_(g[9 + k]);
+        const float c1 = cprev * sf + si * tj;
+        const float tc = tanhf(c1);
+        const float ghv = gh ? gh[o] : 0.f;
+        const float gct = (gc ? gc[o] : 0.f) + ghv * so * (1.f - tc * tc);
+        const long long d0 = ((long long)n * 12) * HW + pix;
+        dgates[d0 + (long long)(k) * HW] = gct * tj * si * (1.f - si);
+        dgates[d0 + (long long)(3 + k) * HW] = gct * si * (1.f - tj * tj);
+        dgates[d0 + (long long)(6 + k) * HW] = gct * cprev * sf * (1.f - sf);
+        dgates[d0 + (long long)(9 + k) * HW] = ghv * tc * so * (1.f - so);
+        if (gcp) gcp[o] = gct * sf;
+    }
+}
+// pass 2: dx / dh_prev = conv_transpose(dgates, w)
+__global__ void __launch_bounds__(256)
+convlstm_bwd_input_kernel(const float* __restrict__ dgates, const float* __restrict__ w, int N, int H, int W,
+                          float* __restrict__ gx, float* __restrict__ ghp) {
+    __shared__ float ws[648];
+    for (int i = threadIdx.x; i < 648; i += blockDim.x) ws[i] = w[i];
+    __syncthreads();
+    const long long HW = (long long)H * W;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)N * HW) return;
+    const int n = (int)(t / HW);
+    const long long pix = t - (long long)n * HW;
+    const int y = (int)(pix / W), xx = (int)(pix - (long long)y * W);
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int yy = y - (dy - 1);
+        if (yy < 0 || yy >= H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int xq = xx - (dx - 1);
+            if (xq < 0 || xq >= W) continue;
+            for (int o = 0; o < 12; ++o) {
+                const float d = dgates[((long long)n * 12 + o) * HW + (long long)yy * W + xq];
+#pragma unroll
+                for (int ci = 0; ci < 6; ++ci) acc[ci] = fmaf(ws[(o * 6 + ci) * 9 + dy * 3 + dx], d, acc[ci]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const long long o = ((long long)n * 3 + k) * HW + pix;
+        if (gx) gx[o] = acc[k];
+        if (ghp) ghp[o] = acc[3 + k];
+    }
+}
+// pass 3: dW / db partials per pixel strip (LDS tiles), then a fixed-order final sum
+#define CL_TW 64
+#define CL_TH 8
+__global__ void __launch_bounds__(256)
+convlstm_bwd_weight_kernel(const float* __restrict__ dgates, const float* __restrict__ x, const float* __restrict__ hp,
+                           int N, int H, int W, int tiles_x, int tiles_y, float* __restrict__ partials) {
+    __shared__ float sd[12][CL_TH][CL_TW];
+    __shared__ float sx[6][CL_TH + 2][CL_TW + 2];
+    int b = blockIdx.x;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y;
+    const int n = b / tiles_y;
+    const int x0 = tx * CL_TW, y0 = ty * CL_TH;
+    const long long HW = (long long)H * W;
+    for (int i = threadIdx.x; i < 12 * CL_TH * CL_TW; i += 256) {
+        const int o = i / (CL_TH * CL_TW), r = (i / CL_TW) % CL_TH, c = i % CL_TW;
+        const int yy = y0 + r, xx = x0 + c;
+        sd[o][r][c] = (yy < H && xx < W) ? dgates[((long long)n * 12 + o) * HW + (long long)yy * W + xx] : 0.f;
+    }
+    for (int i = threadIdx.x; i < 6 * (CL_TH + 2) * (CL_TW + 2); i += 256) {
+        const int ci = i / ((CL_TH + 2) * (CL_TW + 2)), r = (i / (CL_TW + 2)) % (CL_TH + 2), c = i % (CL_TW + 2);
+        const int yy = y0 + r - 1, xx = x0 + c - 1;
+        float v = 0.f;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            if (ci < 3) v = x[((long long)n * 3 + ci) * HW + (long long)yy * W + xx];
+            else if (hp) v = hp[((long long)n * 3 + (ci - 3)) * HW + (long long)yy * W + xx];
+        }
+        sx[ci][r][c] = v;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 660; k += 256) {
+        float acc = 0.f;
+        if (k < 648) {
+            const int o = k / 54, ci = (k / 9) % 6, dy = (k % 9) / 3, dx = k % 3;
+            for (int r = 0; r < CL_TH; ++r)
+                for (int c = 0; c < CL_TW; ++c) acc = fmaf(sd[o][r][c], sx[ci][r + dy][c + dx], acc);
+        } else {
+            const int o = k - 648;
+            for (int r = 0; r < CL_TH; ++r)
+                for (int c = 0; c < CL_TW; ++c) acc += sd[o][r][c];
+        }
+        partials[(long long)blockIdx.x * 660 + k] = acc;
+    }
+}
+__global__ void convlstm_bwd_weight_final_kernel(const float* __restrict__ partials, int nb, float* __restrict__ dw,
+                                                 float* __restrict__ db) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= 660) return;
+    double acc = 0.0;
+    for (int i = 0; i < nb; ++i) acc += (double)partials[(long long)i * 660 + k];
+    if (k < 648) dw[k] = (float)acc; else db[k - 648] = (float)acc;
+}
+
 extern "C" {
 
 int binhip_version(void) { return BINHIP_VERSION; }
@@ -191,7 +415,18 @@ int binhip_nchw_to_planes(const float* x, int N, int C, int H, int W, void* y_hi
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return BINHIP_E_SHAPE;
     const long long total = (long long)bh_chunks(C) * N * H * W * 2;
     hipLaunchKernelGGL(nchw_to_planes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       x, N, C, H, W, (_Float16*)y_hi, (_Float16*)y_lo);
+                       x, N, C, H, W, (_Float16*)y_hi, (_Float16*)y_lo, (const float*)nullptr);
+    BH_CHECK_LAUNCH();
+    return 0;
+}
+
+int binhip_nchw_to_planes_scaled(const float* x, int N, int C, int H, int W, const float* scale, void* y_hi,
+                                 void* y_lo, void* stream) {
+    if (!x || !y_hi || !scale) return BINHIP_E_ARG;
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return BINHIP_E_SHAPE;
+    const long long total = (long long)bh_chunks(C) * N * H * W * 2;
+    hipLaunchKernelGGL(nchw_to_planes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       x, N, C, H, W, (_Float16*)y_hi, (_Float16*)y_lo, scale);
     BH_CHECK_LAUNCH();
     return 0;
 }
@@ -257,6 +492,80 @@ int binhip_charbonnier_bwd(const float* x, const float* y, int64_t numel, float 
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(charb_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, y,
                        (long long)numel, eps, gloss, gx, gy);
+    BH_CHECK_LAUNCH();
+    return 0;
+}
+
+int binhip_grad_scale(const float* g, int64_t numel, float target, float* partials, float* scale_out, void* stream) {
+    if (!g || !partials || !scale_out) return BINHIP_E_ARG;
+    if (numel <= 0 || !(target > 0.f)) return BINHIP_E_SHAPE;
+    long long nb = (numel + 255) / 256;
+    if (nb > CHARB_BLOCKS) nb = CHARB_BLOCKS;
+    hipLaunchKernelGGL(amax_partial_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, g, (long long)numel, partials);
+    hipLaunchKernelGGL(grad_scale_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partials, (int)nb, target, scale_out);
+    BH_CHECK_LAUNCH();
+    return 0;
+}
+
+int binhip_unshuffle_planes(const void* x_hi, const void* x_lo, int N, int H, int W, int nchunks, void* y_hi, void* y_lo,
+                            void* stream) {
+    if (!x_hi || !y_hi || ((x_lo == nullptr) != (y_lo == nullptr))) return BINHIP_E_ARG;
+    if (N <= 0 || H <= 0 || W <= 0 || nchunks <= 0) return BINHIP_E_SHAPE;
+    const long long total = (long long)4 * nchunks * N * H * W * 2;
+    const unsigned nb = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(unshuffle_planes_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x_hi, N, H, W,
+                       nchunks, (_Float16*)y_hi);
+    if (x_lo)
+        hipLaunchKernelGGL(unshuffle_planes_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x_lo, N, H,
+                           W, nchunks, (_Float16*)y_lo);
+    BH_CHECK_LAUNCH();
+    return 0;
+}
+
+int binhip_unpack_input_grads(const void* gx0_hi, const void* gx0_lo, const float* gout, const float* scale,
+                              int n_images, int N, int H, int W, float* const* outs, void* stream) {
+    if (!gout || !outs) return BINHIP_E_ARG;
+    if (n_images < 1 || n_images > 5 || N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return BINHIP_E_SHAPE;
+    UnpackArgs a;
+    for (int i = 0; i < 5; ++i) a.out[i] = (i < n_images) ? outs[i] : nullptr;
+    a.nimg = n_images; a.N = N; a.H = H; a.W = W;
+    const long long total = (long long)N * 3 * H * W;
+    hipLaunchKernelGGL(unpack_input_grads_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       a, (const _Float16*)gx0_hi, (const _Float16*)gx0_lo, gout, scale);
+    BH_CHECK_LAUNCH();
+    return 0;
+}
+
+size_t binhip_convlstm_bwd_workspace_bytes(int N, int H, int W) {
+    if (N <= 0 || H <= 0 || W <= 0) return 0;
+    const size_t tiles = (size_t)((W + CL_TW - 1) / CL_TW) * ((H + CL_TH - 1) / CL_TH) * N;
+    return ((size_t)N * 12 * H * W + tiles * 660) * sizeof(float) + 256;
+}
+
+int binhip_convlstm_bwd(const float* x, const float* c_prev, const float* h_prev, const float* w, const float* b,
+                        float forget_bias, int N, int H, int W, const float* g_h, const float* g_c, void* workspace,
+                        size_t workspace_bytes, float* gx, float* g_hprev, float* g_cprev, float* dw, float* db,
+                        void* stream) {
+    if (!x || !w || !b || !workspace || (!g_h && !g_c)) return BINHIP_E_ARG;
+    if ((c_prev == nullptr) != (h_prev == nullptr)) return BINHIP_E_ARG;
+    if (N <= 0 || H <= 0 || W <= 0) return BINHIP_E_SHAPE;
+    if (workspace_bytes < binhip_convlstm_bwd_workspace_bytes(N, H, W)) return BINHIP_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* dg = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    float* part = dg + (size_t)N * 12 * H * W;
+    const long long total = (long long)N * H * W;
+    const unsigned nb = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(convlstm_bwd_gates_kernel, dim3(nb), dim3(256), 0, s, x, c_prev, h_prev, w, b, forget_bias, N, H, W,
+                       g_h, g_c, dg, g_cprev);
+    if (gx || g_hprev)
+        hipLaunchKernelGGL(convlstm_bwd_input_kernel, dim3(nb), dim3(256), 0, s, dg, w, N, H, W, gx, g_hprev);
+    if (dw && db) {
+        const int tiles_x = (W + CL_TW - 1) / CL_TW, tiles_y = (H + CL_TH - 1) / CL_TH;
+        const int nblk = tiles_x * tiles_y * N;
+        hipLaunchKernelGGL(convlstm_bwd_weight_kernel, dim3((unsigned)nblk), dim3(256), 0, s, dg, x, h_prev, N, H, W, tiles_x,
+                           tiles_y, part);
+        hipLaunchKernelGGL(convlstm_bwd_weight_final_kernel, dim3(3), dim3(256), 0, s, part, nblk, dw, db);
+    }
     BH_CHECK_LAUNCH();
     return 0;
 }

@@ -124,3 +124,184 @@ int binhip_rdn_forward(const BinRdnPlan* p, const float* const* inputs, float* o
 }
 
 }  // extern "C"
+
+// ====================================================================================================
+// Backward of one RDN sub-network (autograd of RDN.py:210-222 / 268-280 / 322-334), again as one fixed launch
+// sequence from C.  Gradient activations are chunk planes like the forward ones, stored multiplied by a per-call
+// power-of-two scale (fp16 range); weight gradients come out as fp32 OIHW.
+//   gOut [1 @HxW] <- gout*scale        gU [4 @HxW]     gUu [16]  (un-shuffled)      gG1, gG0, gF1 [6]
+//   GY [13][6]: GY[0] = grad of SFENet2's output, GY[d+1] = grad of RDB d's output (GFF.0 dgrad + chained RDBs)
+//   gcat [14]: gradient of the current dense block's concat buffer        gX0 [<=4]
+namespace {
+
+struct Bws {
+    int64_t P, PF;
+    int kc0, gx0_chunks;
+    int64_t gout, gu, guu, gg1, gg0, gf1, gy, gcat, gx0, total_halfs;
+    int64_t s_gout, s_gu, s_guu, s_g, s_gy, s_gcat, s_gx0;
+    size_t wg_bytes, sc_off_bytes, wg_off_bytes, total_bytes;
+};
+
+Bws make_bws(int N, int H, int W, int nin, int nt) {
+    Bws b;
+    const int h = H / 2, w = W / 2;
+    b.P = (int64_t)N * h * w * 16;
+    b.PF = (int64_t)N * H * W * 16;
+    b.kc0 = (12 * nin + 15) / 16;
+    b.gx0_chunks = ((12 * nin + 31) / 32) * 2;
+    const int mul = (nt == 3) ? 2 : 1;
+    b.s_gout = b.PF; b.s_gu = 4 * b.PF; b.s_guu = 16 * b.P; b.s_g = 6 * b.P; b.s_gy = (int64_t)13 * 6 * b.P;
+    b.s_gcat = 14 * b.P; b.s_gx0 = (int64_t)b.gx0_chunks * b.P;
+    int64_t o = 0;
+    b.gout = o; o += mul * b.s_gout;
+    b.gu = o; o += mul * b.s_gu;
+    b.guu = o; o += mul * b.s_guu;
+    b.gg1 = o; o += mul * b.s_g;
+    b.gg0 = o; o += mul * b.s_g;
+    b.gf1 = o; o += mul * b.s_g;
+    b.gy = o; o += mul * b.s_gy;
+    b.gcat = o; o += mul * b.s_gcat;
+    b.gx0 = o; o += mul * b.s_gx0;
+    b.total_halfs = o;
+    // weight-gradient partial workspace: max over the layer shapes
+    size_t wg = 0;
+    auto mx = [&](size_t v) { if (v > wg) wg = v; };
+    mx(binhip_wgrad_workspace_bytes(3, N, H, W, 4, 3));          // UPNet.2
+    mx(binhip_wgrad_workspace_bytes(3, N, h, w, 6, 256));        // UPNet.0
+    mx(binhip_wgrad_workspace_bytes(3, N, h, w, 6, 96));         // GFF.1 / SFENet2
+    mx(binhip_wgrad_workspace_bytes(1, N, h, w, 72, 96));        // GFF.0
+    mx(binhip_wgrad_workspace_bytes(1, N, h, w, 14, 96));        // LFF
+    for (int c = 0; c < 4; ++c) mx(binhip_wgrad_workspace_bytes(3, N, h, w, 6 + 2 * c, 32));
+    mx(binhip_wgrad_workspace_bytes(5, N, h, w, b.kc0, 96));     // SFENet1
+    b.wg_bytes = wg;
+    size_t bytes = ((size_t)b.total_halfs * 2 + 255) & ~(size_t)255;
+    b.sc_off_bytes = bytes; bytes += 8192;                       // scale[2] + 1024 amax partials (+pad)
+    b.wg_off_bytes = bytes; bytes += wg;
+    b.total_bytes = bytes + 256;
+    return b;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t binhip_rdn_backward_workspace_bytes(int N, int H, int W, int n_inputs, int nterms) {
+    if (N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return 0;
+    if (n_inputs != 2 && n_inputs != 3 && n_inputs != 5) return 0;
+    return make_bws(N, H, W, n_inputs, nterms).total_bytes;
+}
+
+int binhip_rdn_backward(const BinRdnBwdPlan* p, const void* saved, size_t saved_bytes, const float* gout,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+    if (!p || !saved || !gout || !workspace || !p->zero_bias) return BINHIP_E_ARG;
+    const int N = p->N, H = p->H, W = p->W, nin = p->n_inputs, nt = p->nterms;
+    if (N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return BINHIP_E_SHAPE;
+    if (nin != 2 && nin != 3 && nin != 5) return BINHIP_E_SHAPE;
+    if (nt != 1 && nt != 3) return BINHIP_E_ARG;
+    if (saved_bytes < binhip_rdn_workspace_bytes(N, H, W, nin, nt)) return BINHIP_E_WORKSPACE;
+    const Bws b = make_bws(N, H, W, nin, nt);
+    if (workspace_bytes < b.total_bytes) return BINHIP_E_WORKSPACE;
+    for (int i = 0; i < BINHIP_RDN_LAYERS; ++i)
+        if (!p->wt_hi[i] || (nt == 3 && !p->wt_lo[i]) || !p->dw[i] || !p->db[i]) return BINHIP_E_ARG;
+
+    hipStream_t s = (hipStream_t)stream;
+    const Ws w = make_ws(N, H, W, nin, nt);
+    const int h = H / 2, ww = W / 2;
+    const int64_t P = w.P;
+    _Float16* sbase = (_Float16*)(((uintptr_t)saved + 255) & ~(uintptr_t)255);
+    char* wbytes = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    _Float16* gbase = (_Float16*)wbytes;
+    float* sc = (float*)(wbytes + b.sc_off_bytes);
+    float* amax_part = sc + 16;
+    void* wgws = wbytes + b.wg_off_bytes;
+    const float* inv = sc + 1;
+
+    auto SH = [&](int64_t off) { return (const void*)(sbase + off); };
+    auto SL = [&](int64_t off, int64_t size) { return nt == 3 ? (const void*)(sbase + off + size) : (const void*)nullptr; };
+    auto GH = [&](int64_t off) { return (void*)(gbase + off); };
+    auto GL = [&](int64_t off, int64_t size) { return nt == 3 ? (void*)(gbase + off + size) : (void*)nullptr; };
+
+    int rc;
+    if ((rc = binhip_grad_scale(gout, (int64_t)N * 3 * H * W, 16.f, amax_part, sc, stream))) return rc;
+    if ((rc = binhip_nchw_to_planes_scaled(gout, N, 3, H, W, sc, GH(b.gout), GL(b.gout, b.s_gout), stream))) return rc;
+
+    // weight gradient of forward layer `layer`: X = saved activations, gY = gradient planes
+    auto wgrad = [&](int layer, int ks, int Hc, int Wc, int cin_chunks, int cin, int cout, int64_t x_off, int64_t x_size,
+                     int cpg, int64_t gstride, int64_t g_off, int64_t g_size, int shuffle) -> int {
+        BinConvDesc d;
+        d.N = N; d.H = Hc; d.W = Wc; d.ksize = ks; d.cin_chunks = cin_chunks; d.cout = cout; d.cout_pad = 0;
+        d.nterms = nt; d.epilogue = 0; d.relu = 0; d.x_cpg = cpg; d.x_group_stride = gstride; d.n_images = 0; d.reserved = 0;
+        return binhip_conv2d_bwd_weight(&d, SH(x_off), SL(x_off, x_size), GH(g_off), GL(g_off, g_size), inv, wgws,
+                                        b.wg_bytes, p->dw[layer], p->db[layer], cin, shuffle, 0, stream);
+    };
+    // data gradient through forward layer `layer`: conv with the transposed/flipped weights
+    auto dgrad = [&](int layer, int ks, int Hc, int Wc, int gin_chunks, int gout_ch, int64_t g_off, int64_t g_size,
+                     int64_t y_off, int64_t y_size, int64_t r_off, int64_t r_size, int res_chunks, bool acc_inplace,
+                     int64_t m_off, int mask_from, int y_cpg, int64_t y_gstride) -> int {
+        BhConvCall c;
+        c.d.N = N; c.d.H = Hc; c.d.W = Wc; c.d.ksize = ks; c.d.cin_chunks = gin_chunks; c.d.cout = gout_ch;
+        c.d.cout_pad = ((gout_ch + 31) / 32) * 32; c.d.nterms = nt; c.d.epilogue = BINHIP_EPI_PLANES; c.d.relu = 0;
+        c.d.x_cpg = 0; c.d.x_group_stride = 0; c.d.n_images = 0; c.d.reserved = 0;
+        c.x_hi = GH(g_off); c.x_lo = GL(g_off, g_size);
+        c.w_hi = p->wt_hi[layer]; c.w_lo = p->wt_lo[layer]; c.bias = p->zero_bias;
+        c.r_hi = (r_off >= 0) ? GH(r_off) : nullptr; c.r_lo = (r_off >= 0) ? GL(r_off, r_size) : nullptr;
+        c.res_chunks = res_chunks;
+        c.y_hi = GH(y_off); c.y_lo = GL(y_off, y_size);
+        c.r2_hi = acc_inplace ? c.y_hi : nullptr; c.r2_lo = acc_inplace ? c.y_lo : nullptr;
+        c.m_hi = (m_off >= 0) ? SH(m_off) : nullptr; c.mask_from = mask_from;
+        c.y_cpg = y_cpg; c.y_group_stride = y_gstride;
+        c.y_f32 = nullptr;
+        for (int i = 0; i < 5; ++i) c.images[i] = nullptr;
+        return bh_launch_conv(c, s);
+    };
+
+    // ---- UPNet.2 (64 -> 3 at full res): X = U
+    if ((rc = wgrad(65, 3, H, W, 4, 64, 3, w.u, w.s_u, 0, 0, b.gout, b.s_gout, 0))) return rc;
+    if ((rc = dgrad(65, 3, H, W, 1, 64, b.gout, b.s_gout, b.gu, b.s_gu, -1, 0, 0, false, -1, 0, 0, 0))) return rc;
+    // ---- PixelShuffle backward, then UPNet.0 (96 -> 256): X = G1
+    if ((rc = binhip_unshuffle_planes(GH(b.gu), GL(b.gu, b.s_gu), N, h, ww, 4, GH(b.guu), GL(b.guu, b.s_guu), stream))) return rc;
+    if ((rc = wgrad(64, 3, h, ww, 6, 96, 256, w.g1, w.s_g, 0, 0, b.guu, b.s_guu, 1))) return rc;
+    if ((rc = dgrad(64, 3, h, ww, 16, 96, b.guu, b.s_guu, b.gg1, b.s_g, -1, 0, 0, false, -1, 0, 0, 0))) return rc;
+    // ---- GFF.1 (+ f__1 skip): X = G0
+    if ((rc = wgrad(63, 3, h, ww, 6, 96, 96, w.g0, w.s_g, 0, 0, b.gg1, b.s_g, 0))) return rc;
+    if ((rc = dgrad(63, 3, h, ww, 6, 96, b.gg1, b.s_g, b.gg0, b.s_g, -1, 0, 0, false, -1, 0, 0, 0))) return rc;
+    // ---- GFF.0 over cat(RDB outputs): X = BLK[1..12][0:6]; gradient scattered to GY[1..12]
+    if ((rc = wgrad(62, 1, h, ww, 72, 1152, 96, w.blk + 14 * P, w.s_blk, 6, 14 * P, b.gg0, b.s_g, 0))) return rc;
+    if ((rc = dgrad(62, 1, h, ww, 6, 1152, b.gg0, b.s_g, b.gy + 6 * P, b.s_gy, -1, 0, 0, false, -1, 0, 6, 6 * P))) return rc;
+    // ---- the 12 residual dense blocks, last to first
+    for (int d = 11; d >= 0; --d) {
+        const int64_t blk = w.blk + (int64_t)d * 14 * P;      // saved forward buffer of RDB d
+        const int64_t gy = b.gy + (int64_t)(d + 1) * 6 * P;   // grad of RDB d's output
+        const int L = 2 + 5 * d;
+        // LFF 1x1 224 -> 96 (+x): gcat = W'^T gy (+ gy on the first 6 chunks); ReLU mask of conv 3's output
+        if ((rc = wgrad(L + 4, 1, h, ww, 14, 224, 96, blk, w.s_blk, 0, 0, gy, b.s_gy, 0))) return rc;
+        if ((rc = dgrad(L + 4, 1, h, ww, 6, 224, gy, b.s_gy, b.gcat, b.s_gcat, gy, b.s_gy, 6, false, blk, 12, 0, 0))) return rc;
+        for (int c = 3; c >= 0; --c) {
+            const int64_t gyc = b.gcat + (int64_t)(6 + 2 * c) * P;
+            if ((rc = wgrad(L + c, 3, h, ww, 6 + 2 * c, 96 + 32 * c, 32, blk, w.s_blk, 0, 0, gyc, b.s_gcat, 0))) return rc;
+            if (c > 0) {
+                // accumulate into gcat[0 : 6+2c] in place; conv c-1's output slots (chunks 4+2c, 5+2c) get their mask
+                if ((rc = dgrad(L + c, 3, h, ww, 2, 96 + 32 * c, gyc, b.s_gcat, b.gcat, b.s_gcat, -1, 0, 0, true, blk,
+                                4 + 2 * c, 0, 0))) return rc;
+            } else {
+                // conv 0: result + gcat[0:6] -> grad of the block input = GY[d] (already holds GFF.0's share when d >= 1)
+                if ((rc = dgrad(L, 3, h, ww, 2, 96, gyc, b.s_gcat, b.gy + (int64_t)d * 6 * P, b.s_gy, b.gcat, b.s_gcat, 0,
+                                d >= 1, -1, 0, 0, 0))) return rc;
+            }
+        }
+    }
+    // ---- SFENet2: X = F1; gF1 = dgrad + gG1 (the `x += f__1` skip)
+    if ((rc = wgrad(1, 3, h, ww, 6, 96, 96, w.f1, w.s_f1, 0, 0, b.gy, b.s_gy, 0))) return rc;
+    if ((rc = dgrad(1, 3, h, ww, 6, 96, b.gy, b.s_gy, b.gf1, b.s_g, b.gg1, b.s_g, 0, false, -1, 0, 0, 0))) return rc;
+    // ---- SFENet1 5x5: X = X0
+    if ((rc = wgrad(0, 5, h, ww, w.kc0, 12 * nin, 96, w.x0, w.s_x0, 0, 0, b.gf1, b.s_g, 0))) return rc;
+    bool need_in = false;
+    for (int i = 0; i < nin; ++i) need_in = need_in || (p->gin[i] != nullptr);
+    if (need_in) {
+        if ((rc = dgrad(0, 5, h, ww, 6, 12 * nin, b.gf1, b.s_g, b.gx0, b.s_gx0, -1, 0, 0, false, -1, 0, 0, 0))) return rc;
+        if ((rc = binhip_unpack_input_grads(GH(b.gx0), GL(b.gx0, b.s_gx0), gout, sc, nin, N, H, W, p->gin, stream))) return rc;
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,385 @@
+// binhip_wgrad.hip — weight/bias gradients of the bin_stage4 convolutions on the matrix cores.
+//
+// Stands in for autograd's conv2d weight/bias backward of every F.conv2d on the path (reference
+// models/archs/RDN.py:141,162,187-207, triggered by bin_model.py:140 `l_pix.backward()`):
+//     dW[co][ci][dy][dx] = sum_{n,y,x} gY[co][n,y,x] * X[ci][n,y+dy-p,x+dx-p],   db[co] = sum gY[co]
+// as a GEMM whose contraction dimension is the PIXEL index: per tap, D[ci 32][co 32] += X^T[ci][px16] * gY[px16][co]
+// with v_mfma_f32_32x32x16_f16.  Both operands live in chunk planes ([pixel][16 ch], pixel-major), i.e. with the
+// contraction index on the slow axis, so fragments are fetched with the LDS transpose read ds_read_b64_tr_b16
+// (lane t of a 16-lane group addresses pixel t/4, 8-byte piece t%4 and receives channel t of pixels 0..3 — mapping
+// verified on hardware by tools/probe_tr16.hip).
+//
+// Work split: block (pb, cp, z) owns input-channel pair cp (32 ci), output tile z (32 co, and for 5x5 one tap
+// row), and walks pixel tiles pb, pb+PB, ... (8x32 pixels, halo patch + gY tile DMA'd to LDS, double buffered),
+// keeping all its taps' 32x32 accumulators in registers (K-split over the 4 waves by pixel row).  At the end the
+// 4 waves are reduced through LDS and ONE partial per block is written; a second kernel sums the PB partials in a
+// fixed order (deterministic), un-scales and scatters to OIHW fp32.
+#include "binhip_internal.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef short short4_ __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(3))) short4_ lds_short4_t;
+
+struct WgradKArgs {
+    const _Float16* x_hi;
+    const _Float16* x_lo;
+    const _Float16* g_hi;
+    const _Float16* g_lo;
+    float* partial;
+    float* partial_b;
+    long long x_group_stride;
+    int x_cpg;
+    int N, H, W;
+    int cin_chunks, cout_chunks;
+    int tiles_x, tiles_y, ntiles;
+    int PB, ncp, ncot;
+};
+
+template <int KS, int TR, int NT>
+struct WgCfg {
+    static constexpr int PAD = KS / 2;
+    static constexpr int TH = 8;
+    static constexpr int PH = TH + TR - 1;
+    static constexpr int PW = 32 + KS - 1;
+    static constexpr int NTAP = TR * KS;
+    static constexpr int XP = (PH * PW * 2 + 63) / 64;   // 1-KiB pieces per X chunk patch
+    static constexpr int GP = TH * 32 * 2 / 64;          // 1-KiB pieces per gY chunk tile (= 8)
+    static constexpr int XBYTES = XP * 1024, GBYTES = GP * 1024;
+    static constexpr int PLANE_BYTES = 2 * XBYTES + 2 * GBYTES;
+    static constexpr int NPL = (NT == 3) ? 2 : 1;
+    static constexpr int BUF_BYTES = NPL * PLANE_BYTES;
+    static constexpr int LDS_BYTES = (2 * BUF_BYTES > 16384) ? 2 * BUF_BYTES : 16384;
+    static constexpr int NXJ = (XP + 3) / 4, NGJ = GP / 4;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+// fragment via two transpose reads: lane -> (channel col = lane&15 of chunk (lane>>4)&1, pixels p0 + 8*(lane>>5) + 0..7)
+__device__ __forceinline__ half8 tr_frag(const char* img, int chunk_bytes, int p0, int lane) {
+    const int t = lane & 15;
+    const int ch = (lane >> 4) & 1;
+    const int kg = lane >> 5;
+    const char* base = img + ch * chunk_bytes;
+    half8 r;
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+        const int p = p0 + kg * 8 + rd * 4 + (t >> 2);
+        const int off = p * 32 + (((((t & 3) >> 1)) ^ ((p >> 3) & 1)) << 4) + ((t & 1) << 3);
+        short4_ v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_t*)(base + off));
+        union { short4_ s; _Float16 h[4]; } u;
+        u.s = v;
+        r[rd * 4 + 0] = u.h[0]; r[rd * 4 + 1] = u.h[1]; r[rd * 4 + 2] = u.h[2]; r[rd * 4 + 3] = u.h[3];
+    }
+    return r;
+}
+
+template <int KS, int TR, int NT>
+__device__ __forceinline__ void wg_issue(const WgradKArgs& a, char* smem, int buf, int tile, int cp, int cot, int dy0,
+                                         int wave, int lane, long long plane_elems, unsigned plane_bytes) {
+    using C = WgCfg<KS, TR, NT>;
+    int b = tile;
+    const int tx = b % a.tiles_x; b /= a.tiles_x;
+    const int ty = b % a.tiles_y;
+    const int img = b / a.tiles_y;
+    const int tx0 = tx * 32, ty0 = ty * C::TH;
+    const int H = a.H, W = a.W;
+#pragma unroll
+    for (int pl = 0; pl < C::NPL; ++pl) {
+        char* pbase = smem + buf * C::BUF_BYTES + pl * C::PLANE_BYTES;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // ---- X patch of input chunk 2*cp + h (zeros when the chunk does not exist)
+            const int c = 2 * cp + h;
+            const _Float16* xb = pl ? a.x_lo : a.x_hi;
+            const long long coff = (a.x_cpg > 0)
+                ? (long long)(c / a.x_cpg) * a.x_group_stride + (long long)(c % a.x_cpg) * plane_elems
+                : (long long)c * plane_elems;
+            const bool have = c < a.cin_chunks;
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(have ? xb + coff : xb), 0, have ? plane_bytes : 0u, 0x00020000);
+            char* lds = pbase + h * C::XBYTES;
+#pragma unroll
+            for (int j = 0; j < C::NXJ; ++j) {
+                const int i = wave + 4 * j;
+                if (i < C::XP) {
+                    const int q = i * 64 + lane;
+                    const int p = q >> 1, s = q & 1;
+                    const int py = p / C::PW, px = p - py * C::PW;
+                    const int gy = ty0 + py + dy0 - C::PAD, gx = tx0 + px - C::PAD;
+                    const int cg = s ^ ((p >> 3) & 1);
+                    const bool ok = (p < C::PH * C::PW) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                    const unsigned vo = ok ? (unsigned)((((long long)img * H + gy) * W + gx) * 32 + cg * 16) : 0x80000000u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(lds + i * 1024), 16, vo, 0, 0, 0);
+                }
+            }
+            // ---- gY tile of output chunk 2*cot + h
+            const int gc = 2 * cot + h;
+            const bool haveg = gc < a.cout_chunks;
+            const _Float16* gb = pl ? a.g_lo : a.g_hi;
+            __amdgpu_buffer_rsrc_t gs = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(haveg ? gb + (long long)gc * plane_elems : gb), 0, haveg ? plane_bytes : 0u, 0x00020000);
+            char* gl = pbase + 2 * C::XBYTES + h * C::GBYTES;
+#pragma unroll
+            for (int j = 0; j < C::NGJ; ++j) {
+                const int i = wave + 4 * j;
+                const int q = i * 64 + lane;
+                const int p = q >> 1, s = q & 1;
+                const int py = p >> 5, px = p & 31;
+                const int gy = ty0 + py, gx = tx0 + px;
+                const int cg = s ^ ((p >> 3) & 1);
+                const bool ok = gy < H && gx < W;
+                const unsigned vo = ok ? (unsigned)((((long long)img * H + gy) * W + gx) * 32 + cg * 16) : 0x80000000u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(gs, (lds_void_t*)(gl + i * 1024), 16, vo, 0, 0, 0);
+            }
+        }
+    }
+}
+
+template <int KS, int TR, int NT>
+__global__ void __launch_bounds__(256)
+wgrad_mfma_kernel(const WgradKArgs a) {
+    using C = WgCfg<KS, TR, NT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pb = blockIdx.x, cp = blockIdx.y;
+    const int cot = blockIdx.z % a.ncot;
+    const int dyg = blockIdx.z / a.ncot;
+    const int dy0 = dyg * TR;
+    const long long plane_elems = (long long)a.N * a.H * a.W * 16;
+    const unsigned plane_bytes = (unsigned)(plane_elems * 2);
+    const bool do_bias = (cp == 0) && (dyg == 0);
+
+    floatx16 acc[C::NTAP];
+    floatx16 accb;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) accb[e] = 0.f;
+#pragma unroll
+    for (int t = 0; t < C::NTAP; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    half8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (_Float16)1.0f;
+
+    int tile = pb;
+    if (tile < a.ntiles) wg_issue<KS, TR, NT>(a, smem, 0, tile, cp, cot, dy0, wave, lane, plane_elems, plane_bytes);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (; tile < a.ntiles; tile += a.PB) {
+        const int nxt = tile + a.PB;
+        if (nxt < a.ntiles) wg_issue<KS, TR, NT>(a, smem, cur ^ 1, nxt, cp, cot, dy0, wave, lane, plane_elems, plane_bytes);
+        const char* xb = smem + cur * C::BUF_BYTES;
+        const char* gb = xb + 2 * C::XBYTES;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int row = wave * 2 + rr;
+#pragma unroll
+            for (int xs = 0; xs < 2; ++xs) {
+                const int x0 = xs * 16;
+                const half8 Bh = tr_frag(gb, C::GBYTES, row * 32 + x0, lane);
+                half8 Bl;
+                if constexpr (NT == 3) Bl = tr_frag(gb + C::PLANE_BYTES, C::GBYTES, row * 32 + x0, lane);
+                if (do_bias) {
+                    accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, Bh, accb, 0, 0, 0);
+                    if constexpr (NT == 3) accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, Bl, accb, 0, 0, 0);
+                }
+#pragma unroll
+                for (int dyl = 0; dyl < TR; ++dyl) {
+#pragma unroll
+                    for (int dx = 0; dx < KS; ++dx) {
+                        const int p0 = (row + dyl) * C::PW + x0 + dx;
+                        const half8 Ah = tr_frag(xb, C::XBYTES, p0, lane);
+                        if constexpr (NT == 3) {
+                            const half8 Al = tr_frag(xb + C::PLANE_BYTES, C::XBYTES, p0, lane);
+                            acc[dyl * KS + dx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, acc[dyl * KS + dx], 0, 0, 0);
+                            acc[dyl * KS + dx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, acc[dyl * KS + dx], 0, 0, 0);
+                        }
+                        acc[dyl * KS + dx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, acc[dyl * KS + dx], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- reduce the 4 waves through LDS, one partial per block ----------------------------------
+    float* red = reinterpret_cast<float*>(smem);          // [4 waves][32 m][32 n]
+    const int n = lane & 31, hi = lane >> 5;
+    const long long blk = ((long long)blockIdx.z * a.ncp + cp) * a.PB + pb;
+#pragma unroll
+    for (int t = 0; t < C::NTAP; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = (e & 3) + 8 * (e >> 2) + 4 * hi;
+            red[wave * 1024 + m * 32 + n] = acc[t][e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            a.partial[(blk * C::NTAP + t) * 1024 + idx] =
+                (red[idx] + red[1024 + idx]) + (red[2048 + idx] + red[3072 + idx]);
+        }
+    }
+    if (do_bias) {
+        __syncthreads();
+        // bias: every row m of accb holds sum_k gY[k][n]; keep row 0 (e = 0 of the lanes with hi == 0)
+        if (hi == 0) red[wave * 32 + n] = accb[0];
+        __syncthreads();
+        if (tid < 32)
+            a.partial_b[((long long)cot * a.PB + pb) * 32 + tid] =
+                (red[tid] + red[32 + tid]) + (red[64 + tid] + red[96 + tid]);
+    }
+}
+
+// final deterministic reduction over the PB partials + un-scale + scatter to OIHW
+__global__ void __launch_bounds__(256)
+wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ partial_b, int PB, int ncp, int ncot,
+                    int ks, int tr, int cout, int cin, const float* __restrict__ inv_scale, float* __restrict__ dw,
+                    float* __restrict__ db, int accumulate, int shuffle) {
+    const int ntap_blk = tr * ks;
+    const int ndyg = ks / tr;
+    const long long total = (long long)ndyg * ncot * ncp * ntap_blk * 1024;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const float is = inv_scale ? inv_scale[0] : 1.f;
+    if (t < (long long)ncot * 32 && db) {
+        const int co = (int)t;
+        if (co < cout) {
+            float s = 0.f;
+            for (int p = 0; p < PB; ++p) s += partial_b[((long long)(co >> 5) * PB + p) * 32 + (co & 31)];
+            int cr = co;
+            if (shuffle) { const int cq = cout / 4; cr = (co % cq) * 4 + co / cq; }
+            db[cr] = accumulate ? db[cr] + s * is : s * is;
+        }
+    }
+    if (t >= total) return;
+    const int nn = (int)(t & 31);
+    const int m = (int)((t >> 5) & 31);
+    long long u = t >> 10;
+    const int tap = (int)(u % ntap_blk); u /= ntap_blk;
+    const int cp = (int)(u % ncp); u /= ncp;
+    const int z = (int)u;                       // = dyg * ncot + cot
+    const int cot = z % ncot, dyg = z / ncot;
+    const int co = cot * 32 + nn, ci = cp * 32 + m;
+    if (co >= cout || ci >= cin) return;
+    const int dy = dyg * tr + tap / ks, dx = tap % ks;
+    float s = 0.f;
+    const long long base = (((long long)z * ncp + cp) * PB) * ntap_blk + tap;
+    for (int p = 0; p < PB; ++p) s += partial[(base + (long long)p * ntap_blk) * 1024 + m * 32 + nn];
+    int cr = co;
+    if (shuffle) { const int cq = cout / 4; cr = (co % cq) * 4 + co / cq; }
+    float* o = dw + (((long long)cr * cin + ci) * ks + dy) * ks + dx;
+    *o = accumulate ? *o + s * is : s * is;
+}
+
+namespace {
+
+struct WgGeom { int ncp, ncot, ndyg, tr, ntap, tiles_x, tiles_y, ntiles, PB; size_t partial_floats, bias_floats; };
+
+WgGeom wg_geom(int ksize, int N, int H, int W, int cin_chunks, int cout, int cus) {
+    WgGeom g;
+    g.tr = (ksize == 5) ? 1 : ksize;
+    g.ndyg = ksize / g.tr;
+    g.ntap = g.tr * ksize;
+    g.ncp = (cin_chunks + 1) / 2;
+    g.ncot = (cout + 31) / 32;
+    g.tiles_x = (W + 31) / 32;
+    g.tiles_y = (H + 7) / 8;
+    g.ntiles = g.tiles_x * g.tiles_y * N;
+    const int groups = g.ncp * g.ncot * g.ndyg;
+    int pb = (2 * (cus > 0 ? cus : 256) + groups - 1) / groups;
+    if (pb < 1) pb = 1;
+    if (pb > g.ntiles) pb = g.ntiles;
+    g.PB = pb;
+    g.partial_floats = (size_t)groups * pb * g.ntap * 1024;
+    g.bias_floats = (size_t)g.ncot * pb * 32;
+    return g;
+}
+
+template <int KS, int TR, int NT>
+int launch_wg(const WgradKArgs& a, const WgGeom& g, hipStream_t s) {
+    using C = WgCfg<KS, TR, NT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<KS, TR, NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid((unsigned)g.PB, (unsigned)g.ncp, (unsigned)(g.ncot * g.ndyg));
+    wgrad_mfma_kernel<KS, TR, NT><<<grid, dim3(256), C::LDS_BYTES, s>>>(a);
+    BH_CHECK_LAUNCH();
+    return 0;
+}
+
+int g_cus = 0;
+int cus() {
+    if (g_cus == 0) {
+        int n = binhip_device_cus();
+        g_cus = n > 0 ? n : 256;
+    }
+    return g_cus;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t binhip_wgrad_workspace_bytes(int ksize, int N, int H, int W, int cin_chunks, int cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || cin_chunks <= 0 || cout <= 0) return 0;
+    const WgGeom g = wg_geom(ksize, N, H, W, cin_chunks, cout, cus());
+    return (g.partial_floats + g.bias_floats) * sizeof(float) + 256;
+}
+
+int binhip_conv2d_bwd_weight(const BinConvDesc* d, const void* x_hi, const void* x_lo, const void* gy_hi,
+                             const void* gy_lo, const float* inv_scale, void* workspace, size_t workspace_bytes,
+                             float* dw_oihw, float* dbias, int cin, int shuffle_perm, int accumulate, void* stream) {
+    if (!d || !x_hi || !gy_hi || !workspace || !dw_oihw) return BINHIP_E_ARG;
+    if (d->nterms != 1 && d->nterms != 3) return BINHIP_E_ARG;
+    if (d->nterms == 3 && (!x_lo || !gy_lo)) return BINHIP_E_ARG;
+    if (d->ksize != 1 && d->ksize != 3 && d->ksize != 5) return BINHIP_E_SHAPE;
+    if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->cin_chunks <= 0 || d->cout <= 0) return BINHIP_E_SHAPE;
+    if ((long long)d->N * d->H * d->W >= (1ll << 26)) return BINHIP_E_SHAPE;
+    if (cin <= 0 || cin > d->cin_chunks * 16) return BINHIP_E_SHAPE;
+    if (shuffle_perm && d->cout % 4) return BINHIP_E_SHAPE;
+    const WgGeom g = wg_geom(d->ksize, d->N, d->H, d->W, d->cin_chunks, d->cout, cus());
+    const size_t need = (g.partial_floats + g.bias_floats) * sizeof(float) + 256;
+    if (workspace_bytes < need) return BINHIP_E_WORKSPACE;
+    float* part = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    WgradKArgs a;
+    a.x_hi = (const _Float16*)x_hi; a.x_lo = (const _Float16*)x_lo;
+    a.g_hi = (const _Float16*)gy_hi; a.g_lo = (const _Float16*)gy_lo;
+    a.partial = part; a.partial_b = part + g.partial_floats;
+    a.x_group_stride = d->x_group_stride; a.x_cpg = d->x_cpg;
+    a.N = d->N; a.H = d->H; a.W = d->W;
+    a.cin_chunks = d->cin_chunks; a.cout_chunks = (d->cout + 15) / 16;
+    a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.ntiles = g.ntiles;
+    a.PB = g.PB; a.ncp = g.ncp; a.ncot = g.ncot;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = BINHIP_E_SHAPE;
+    if (d->nterms == 1) {
+        if (d->ksize == 3) rc = launch_wg<3, 3, 1>(a, g, s);
+        else if (d->ksize == 1) rc = launch_wg<1, 1, 1>(a, g, s);
+        else rc = launch_wg<5, 1, 1>(a, g, s);
+    } else {
+        if (d->ksize == 3) rc = launch_wg<3, 3, 3>(a, g, s);
+        else if (d->ksize == 1) rc = launch_wg<1, 1, 3>(a, g, s);
+        else rc = launch_wg<5, 1, 3>(a, g, s);
+    }
+    if (rc) return rc;
+    const long long total = (long long)g.ndyg * g.ncot * g.ncp * g.ntap * 1024;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.partial,
+                       a.partial_b, g.PB, g.ncp, g.ncot, d->ksize, g.tr, d->cout, cin, inv_scale, dw_oihw, dbias,
+                       accumulate, shuffle_perm);
+    BH_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

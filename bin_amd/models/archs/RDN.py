@@ -46,6 +46,9 @@ class ConvLSTMCell(nn.Module):
         self.Gates.bias.data.zero_()
 
     def forward(self, input_, prev_state):
+        if torch.is_grad_enabled() and (input_.requires_grad or self.Gates.weight.requires_grad):
+            from ...autograd import convlstm_apply
+            return convlstm_apply(input_, prev_state, self.Gates.weight, self.Gates.bias, self._forget_bias)
         return ops.convlstm_cell(input_, prev_state, self.Gates.weight, self.Gates.bias, self._forget_bias)
 
 

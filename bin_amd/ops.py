@@ -174,3 +174,64 @@ def charbonnier_grad(x, y, gloss, eps=1e-6):
     L.check(L.lib().binhip_charbonnier_bwd(_ptr(x), _ptr(y), x.numel(), float(eps), _ptr(g), _ptr(gx),
                                            C.c_void_p(0), _stream()), "charbonnier_bwd")
     return gx
+
+
+# --------------------------------------------------------------------------------------------- backward ops
+class DgradWeights:
+    """Backward-data weights of one convolution (binhip_weights_relayout_dgrad)."""
+
+    def __init__(self, weight, nterms=1, shuffle=False):
+        _need_cuda(weight)
+        cout, cin, ks, _ = weight.shape
+        lib = L.lib()
+        self.ks, self.nterms = ks, nterms
+        self.cout = cin                                   # the dgrad conv's outputs = original inputs
+        self.cout_pad = ((cin + 31) // 32) * 32
+        self.cin_chunks = chunks(cout)
+        cb = lib.binhip_conv_cout_block(ks, self.cout_pad, nterms)
+        nbytes = lib.binhip_weights_bytes(self.cout_pad, self.cin_chunks, ks)
+        dev = weight.device
+        self.w_hi = torch.empty(nbytes // 2, dtype=torch.float16, device=dev)
+        self.w_lo = torch.empty(nbytes // 2, dtype=torch.float16, device=dev) if nterms == 3 else None
+        self.bias = torch.empty(self.cout_pad, dtype=torch.float32, device=dev)
+        w = weight.detach().contiguous().float()
+        L.check(lib.binhip_weights_relayout_dgrad(_ptr(w), cout, cin, ks, self.cout_pad, self.cin_chunks, cb,
+                                                  1 if shuffle else 0, _ptr(self.w_hi), _ptr(self.w_lo),
+                                                  _ptr(self.bias), _stream()), "weights_relayout_dgrad")
+
+
+def conv2d_bwd_data(gy, dw, res=None, res_chunks=0, acc=None, mask=None, mask_from=0, out=None):
+    """gx = [mask](conv_{W'}(gy) [+ res] [+ acc]) on chunk planes (binhip_conv2d_bwd_data)."""
+    _, n, h, w, _ = gy.hi.shape
+    d = L.BinConvDesc()
+    d.N, d.H, d.W, d.ksize = n, h, w, dw.ks
+    d.cin_chunks, d.cout, d.cout_pad, d.nterms = dw.cin_chunks, dw.cout, dw.cout_pad, dw.nterms
+    d.epilogue, d.relu, d.x_cpg, d.x_group_stride, d.n_images = L.EPI_PLANES, 0, 0, 0, 0
+    if out is None:
+        out = CP.empty(dw.cout_pad // 16, n, h, w, dw.nterms, gy.hi.device, dw.cout)
+    z = C.c_void_p(0)
+    rc = L.lib().binhip_conv2d_bwd_data(
+        C.byref(d), _ptr(gy.hi), _ptr(gy.lo), _ptr(dw.w_hi), _ptr(dw.w_lo), _ptr(dw.bias),
+        _ptr(res.hi) if res is not None else z, _ptr(res.lo) if res is not None else z, res_chunks,
+        _ptr(acc.hi) if acc is not None else z, _ptr(acc.lo) if acc is not None else z,
+        _ptr(mask.hi) if mask is not None else z, mask_from, 0, 0, _ptr(out.hi), _ptr(out.lo), _stream())
+    L.check(rc, "conv2d_bwd_data")
+    return out
+
+
+def conv2d_bwd_weight(x, gy, cout, cin, ks, nterms, inv_scale=None, shuffle=False):
+    """(dW [cout,cin,ks,ks], db [cout]) fp32 from saved input planes x and gradient planes gy."""
+    _, n, h, w, _ = x.hi.shape
+    lib = L.lib()
+    d = L.BinConvDesc()
+    d.N, d.H, d.W, d.ksize = n, h, w, ks
+    d.cin_chunks, d.cout, d.cout_pad, d.nterms = chunks(cin), cout, 0, nterms
+    d.epilogue, d.relu, d.x_cpg, d.x_group_stride, d.n_images = 0, 0, 0, 0, 0
+    dev = x.hi.device
+    ws = torch.empty(lib.binhip_wgrad_workspace_bytes(ks, n, h, w, chunks(cin), cout), dtype=torch.uint8, device=dev)
+    dw = torch.empty((cout, cin, ks, ks), dtype=torch.float32, device=dev)
+    db = torch.empty((cout,), dtype=torch.float32, device=dev)
+    L.check(lib.binhip_conv2d_bwd_weight(C.byref(d), _ptr(x.hi), _ptr(x.lo), _ptr(gy.hi), _ptr(gy.lo),
+                                         _ptr(inv_scale), _ptr(ws), ws.numel(), _ptr(dw), _ptr(db), cin,
+                                         1 if shuffle else 0, 0, _stream()), "conv2d_bwd_weight")
+    return dw, db

@@ -35,19 +35,60 @@ class RdnWeights:
             self.layers.append(ConvWeights(w, b, nterms=nterms, shuffle=shuffle, cin_chunks=cin_chunks))
         assert len(self.layers) == L.RDN_LAYERS
 
+        self._dgrad = None
+
     def fill_plan(self, plan):
         for i, cw in enumerate(self.layers):
             plan.w_hi[i] = cw.w_hi.data_ptr()
             plan.w_lo[i] = cw.w_lo.data_ptr() if cw.w_lo is not None else None
             plan.bias[i] = cw.bias.data_ptr()
 
+    def dgrad(self, module):
+        """Backward-data weights (transposed + flipped), built on first use for the same parameter version."""
+        if self._dgrad is None:
+            with torch.no_grad():
+                self._dgrad = RdnDgradWeights(dict(module.named_parameters()), self.n_inputs, self.nterms)
+        return self._dgrad
+
+
+class RdnDgradWeights:
+    """W'[ci][co][dy][dx] = W[co][ci][k-1-dy][k-1-dx] of the 66 layers in kernel layout (binhip_weights_relayout_dgrad)."""
+
+    def __init__(self, params, n_inputs, nterms, prefix=""):
+        lib = L.lib()
+        self.w_hi, self.w_lo = [], []
+        dev = None
+        for nm in layer_names():
+            w = params[f"{prefix}{nm}.weight"].detach().contiguous().float()
+            dev = w.device
+            cout, cin, ks, _ = w.shape
+            rows_pad = ((cin + 31) // 32) * 32
+            cin_chunks = (cout + 15) // 16
+            cb = lib.binhip_conv_cout_block(ks, rows_pad, nterms)
+            nbytes = lib.binhip_weights_bytes(rows_pad, cin_chunks, ks)
+            hi = torch.empty(nbytes // 2, dtype=torch.float16, device=dev)
+            lo = torch.empty(nbytes // 2, dtype=torch.float16, device=dev) if nterms == 3 else None
+            zb = torch.empty(rows_pad, dtype=torch.float32, device=dev)
+            L.check(lib.binhip_weights_relayout_dgrad(_ptr(w), cout, cin, ks, rows_pad, cin_chunks, cb,
+                                                      1 if nm == "UPNet.0" else 0, _ptr(hi), _ptr(lo), _ptr(zb),
+                                                      _stream()), "weights_relayout_dgrad")
+            self.w_hi.append(hi)
+            self.w_lo.append(lo)
+        self.zero_bias = torch.zeros(1152, dtype=torch.float32, device=dev)
+
+    def fill_plan(self, plan):
+        for i in range(L.RDN_LAYERS):
+            plan.wt_hi[i] = self.w_hi[i].data_ptr()
+            plan.wt_lo[i] = self.w_lo[i].data_ptr() if self.w_lo[i] is not None else None
+        plan.zero_bias = self.zero_bias.data_ptr()
+
 
 _workspaces = {}
 
 
-def workspace(nbytes, device):
-    """One cached workspace per device, grown on demand (activations of a single RDN call)."""
-    key = (device.type, device.index)
+def workspace(nbytes, device, key="fwd"):
+    """One cached workspace per (device, purpose), grown on demand."""
+    key = (device.type, device.index, key)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)

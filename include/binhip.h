@@ -82,6 +82,27 @@ int binhip_conv2d_fwd(const BinConvDesc* d,
                       float* y_f32, const float* const* images,    /* FINAL output + host array */
                       void* stream);                               /*   of n_images device ptrs */
 
+/* ---- backward-data (dgrad) of the same convolution (autograd of RDN.py's conv2d calls) -----------
+ * dgrad(conv_W)(gy) = conv_{W'}(gy) with W'[ci][co][dy][dx] = W[co][ci][k-1-dy][k-1-dx]; it runs on the
+ * forward kernel.  relayout_dgrad builds W' (rows = original input channels padded to rows_pad, input
+ * chunks = original output channels; shuffle_perm: those are in UPNet.0's PixelShuffle-permuted order).
+ * bwd_data: gx = [mask](conv_{W'}(gy) [+ res on chunks < res_chunks] [+ acc])
+ *   res   — e.g. the RDB skip path gradient (RDN.py:165 `+ x`)
+ *   acc   — running gradient of the dense block input being accumulated; may alias gx (in place)
+ *   mask  — saved forward activation planes: output chunks >= mask_from are zeroed where it is <= 0
+ *           (ReLU backward, RDN.py:142), applied when the last contribution to that chunk lands
+ *   y_cpg / y_group_stride — output chunk grouping (GFF.0 dgrad scatters to the 12 block buffers)     */
+int binhip_weights_relayout_dgrad(const float* w_oihw, int cout, int cin, int ksize, int rows_pad,
+                                  int cin_chunks, int cout_block, int shuffle_perm, void* w_hi, void* w_lo,
+                                  float* bias_out, void* stream);
+int binhip_conv2d_bwd_data(const BinConvDesc* d, const void* gy_hi, const void* gy_lo,
+                           const void* wt_hi, const void* wt_lo, const float* zero_bias,
+                           const void* res_hi, const void* res_lo, int res_chunks,
+                           const void* acc_hi, const void* acc_lo,
+                           const void* mask_hi, int mask_from,
+                           int y_cpg, int64_t y_group_stride,
+                           void* gx_hi, void* gx_lo, void* stream);
+
 /* ---- layout glue ------------------------------------------------------------------------------ */
 /* fp32 NCHW [N,C,H,W] -> chunk planes (C padded with zeros to 16).                              */
 int binhip_nchw_to_planes(const float* x, int N, int C, int H, int W, void* y_hi, void* y_lo,
@@ -126,6 +147,59 @@ size_t binhip_rdn_workspace_bytes(int N, int H, int W, int n_inputs, int nterms)
 int binhip_rdn_forward(const BinRdnPlan* plan, const float* const* inputs /* host array of
                        n_inputs device ptrs, fp32 [N,3,H,W] */, float* out /* fp32 [N,3,H,W] */,
                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- weight / bias gradients (autograd of RDN.py's conv2d calls; bin_model.py:140) ---------------
+ * dW[co][ci][dy][dx] = sum_px gY[co][px] * X[ci][px + tap], db[co] = sum_px gY[co][px], MFMA GEMM over the
+ * pixel index with LDS transpose reads; deterministic two-stage reduction.  d describes the FORWARD conv
+ * (N,H,W, ksize, cin_chunks, cout, nterms, x_cpg/x_group_stride).  The result is multiplied by
+ * inv_scale[0] (device scalar, may be NULL) and written (or added, accumulate != 0) to OIHW fp32.
+ * shuffle_perm != 0: gY's channels are in UPNet.0's PixelShuffle-permuted order.                      */
+size_t binhip_wgrad_workspace_bytes(int ksize, int N, int H, int W, int cin_chunks, int cout);
+int binhip_conv2d_bwd_weight(const BinConvDesc* d, const void* x_hi, const void* x_lo,
+                             const void* gy_hi, const void* gy_lo, const float* inv_scale,
+                             void* workspace, size_t workspace_bytes, float* dw_oihw, float* dbias,
+                             int cin, int shuffle_perm, int accumulate, void* stream);
+
+/* ---- backward glue -------------------------------------------------------------------------------- */
+/* scale_out[0] = 2^floor(log2(target/amax|g|)), scale_out[1] = 1/scale_out[0] (fp16 gradient planes
+ * are stored multiplied by scale_out[0]); partials: binhip_charbonnier_partials() floats.            */
+int binhip_grad_scale(const float* g, int64_t numel, float target, float* partials, float* scale_out,
+                      void* stream);
+int binhip_nchw_to_planes_scaled(const float* x, int N, int C, int H, int W, const float* scale,
+                                 void* y_hi, void* y_lo, void* stream);
+/* inverse PixelShuffle(2) on planes: nchunks planes at 2H x 2W -> 4*nchunks planes at H x W           */
+int binhip_unshuffle_planes(const void* x_hi, const void* x_lo, int N, int H, int W, int nchunks,
+                            void* y_hi, void* y_lo, void* stream);
+/* input-frame gradients of one RDN: outs[i] = unshuffle(gX0)[frame i] * scale[1] + gout / n_images
+ * (gx0 may be NULL: skip path only; outs[i] may be NULL: frame i needs no gradient)                   */
+int binhip_unpack_input_grads(const void* gx0_hi, const void* gx0_lo, const float* gout,
+                              const float* scale, int n_images, int N, int H, int W,
+                              float* const* outs, void* stream);
+
+/* ---- ConvLSTM cell backward (autograd of RDN.py:74-82) ---------------------------------------------
+ * Inputs as forward + g_h (grad of h', may be NULL) and g_c (grad of c', may be NULL); any output
+ * pointer may be NULL.  dw [12,6,3,3], db [12] fp32 are overwritten.                                   */
+size_t binhip_convlstm_bwd_workspace_bytes(int N, int H, int W);
+int binhip_convlstm_bwd(const float* x, const float* c_prev, const float* h_prev, const float* w,
+                        const float* b, float forget_bias, int N, int H, int W, const float* g_h,
+                        const float* g_c, void* workspace, size_t workspace_bytes, float* gx,
+                        float* g_hprev, float* g_cprev, float* dw, float* db, void* stream);
+
+/* ---- backward of one whole RDN sub-network ----------------------------------------------------------
+ * `saved` is the workspace binhip_rdn_forward filled (kept by the caller between forward and backward).
+ * dw[i]/db[i]: OIHW fp32 gradients of layer i (overwritten).  gin[i]: fp32 [N,3,H,W] or NULL.           */
+typedef struct BinRdnBwdPlan {
+    int32_t N, H, W, n_inputs, nterms, reserved;
+    const void* wt_hi[BINHIP_RDN_LAYERS];   /* binhip_weights_relayout_dgrad outputs                  */
+    const void* wt_lo[BINHIP_RDN_LAYERS];
+    const float* zero_bias;                 /* >= 1152 zero floats                                    */
+    float* dw[BINHIP_RDN_LAYERS];
+    float* db[BINHIP_RDN_LAYERS];
+    float* gin[5];
+} BinRdnBwdPlan;
+size_t binhip_rdn_backward_workspace_bytes(int N, int H, int W, int n_inputs, int nterms);
+int binhip_rdn_backward(const BinRdnBwdPlan* plan, const void* saved, size_t saved_bytes,
+                        const float* gout, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- live kernel timing (bench.py roofline leg) --------------------------------------------------
  * Between begin/end every conv launch whose (ksize, cout_pad, epilogue) matches is bracketed by a
