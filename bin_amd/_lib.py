@@ -75,6 +75,7 @@ _SIGNATURES = {
     "binhip_rdn_backward_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
     "binhip_rdn_backward": (C.c_int, [C.POINTER(BinRdnBwdPlan), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                       C.c_size_t, C.c_void_p]),
+    "binhip_set_variant": (C.c_int, [C.c_int, C.c_int]),
     "binhip_profile_begin": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "binhip_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "binhip_rdn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -43,6 +43,7 @@ struct ConvKArgs {
     int cpg;
     int tiles_x, tiles_y;
     int relu, has_res, nimg, cout;
+    int xcd_remap;
     int res_chunks;           // residual r applies to output chunks < res_chunks
     int mask_from;            // mask applies to output chunks >= mask_from (when m_hi != null)
     int y_cpg;                // output chunk grouping (<=0: one group)
@@ -62,21 +63,27 @@ struct ConvCfg {
     static constexpr int NPL = (NT == 3) ? 2 : 1;
     static constexpr int PLANE_BYTES = KC * CHUNK_BYTES;
     static constexpr int BUF_BYTES = NPL * PLANE_BYTES;
-    static constexpr int LDS_BYTES = NBUF * BUF_BYTES;
-    static constexpr int NPJ = (PP + 3) / 4;
-    static constexpr int NWJ = (WP + 3) / 4;
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static constexpr int NW = WM * WN;                   // waves per workgroup (4 or 8)
+    static constexpr int LDS_BYTES = NBUF * BUF_BYTES + 1024;   // + 1 KiB dummy DMA target
+    static constexpr int NPJ = (PP + NW - 1) / NW;
+    static constexpr int NWJ = (WP + NW - 1) / NW;
+    static constexpr int PS = NPL * KC * (NPJ + NWJ);    // DMA instructions per wave per full stage
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(NBUF <= 2 || (NBUF - 2) * PS <= 63, "vmcnt immediate range");
 };
 
 __device__ __forceinline__ half8 lds_ld8(const char* p) { return *reinterpret_cast<const half8*>(p); }
 
 // Issue the LDS-DMA of K-stage `st` (KC chunks x NPL planes: input patch + weight slab) into buffer `buf`.
+// Every wave issues exactly NPJ + NWJ instructions per (plane, chunk) so that s_waitcnt vmcnt(N) can count
+// whole stages; surplus lanes read out of range (zero fill, no memory traffic) into a dummy 1-KiB LDS area.
 template <class C, int KS, int KC>
 __device__ __forceinline__ void issue_stage(const ConvKArgs& a, char* smem, int st, int buf, int wave, int lane, int z,
                                             const unsigned (&voff)[C::NPJ], long long plane_elems,
                                             unsigned plane_bytes) {
     char* bbase = smem + buf * C::BUF_BYTES;
+    char* dummy = smem + (C::LDS_BYTES - 1024);
     const int nchunks = a.nchunks;
 #pragma unroll
     for (int pl = 0; pl < C::NPL; ++pl) {
@@ -93,10 +100,10 @@ __device__ __forceinline__ void issue_stage(const ConvKArgs& a, char* smem, int 
                 char* lds = bbase + pl * C::PLANE_BYTES + kc * C::CHUNK_BYTES;
 #pragma unroll
                 for (int j = 0; j < C::NPJ; ++j) {
-                    const int i = wave + 4 * j;
-                    if (i < C::PP)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(lds + i * 1024), 16,
-                                                                 voff[j], 0, 0, 0);
+                    const int i = wave + C::NW * j;
+                    const bool real = (C::PP % C::NW == 0) || (i < C::PP);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(real ? lds + i * 1024 : dummy), 16,
+                                                             real ? voff[j] : 0x80000000u, 0, 0, 0);
                 }
                 const _Float16* wb = (pl ? a.w_lo : a.w_hi) +
                                      ((long long)z * nchunks + c) * (KS * KS * C::COUTB * 16);
@@ -104,14 +111,20 @@ __device__ __forceinline__ void issue_stage(const ConvKArgs& a, char* smem, int 
                     (void*)wb, 0, KS * KS * C::COUTB * 32, 0x00020000);
 #pragma unroll
                 for (int j = 0; j < C::NWJ; ++j) {
-                    const int i = wave + 4 * j;
-                    if (i < C::WP)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(ws, (lds_void_t*)(lds + (C::PP + i) * 1024), 16,
-                                                                 lane * 16, i * 1024, 0, 0);
+                    const int i = wave + C::NW * j;
+                    const bool real = (C::WP % C::NW == 0) || (i < C::WP);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ws, (lds_void_t*)(real ? lds + (C::PP + i) * 1024 : dummy), 16,
+                                                             real ? (unsigned)(lane * 16) : 0x80000000u,
+                                                             real ? i * 1024 : 0, 0, 0);
                 }
             }
         }
     }
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // All MFMAs of K-stage `st` out of LDS buffer `buf`.
@@ -164,7 +177,7 @@ __device__ __forceinline__ void compute_stage(const char* smem, int st, int buf,
 }
 
 template <int KS, int MT, int WM, int R, int WN, int KC, int NT, int NBUF, int EPI>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * WM * WN)
 conv_mfma_kernel(const ConvKArgs a) {
     using C = ConvCfg<KS, MT, WM, R, WN, KC, NT, NBUF, EPI>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -178,6 +191,12 @@ conv_mfma_kernel(const ConvKArgs a) {
     const int kg = lane >> 5;    // which 8-channel half of the 16-channel chunk
 
     int bid = blockIdx.x;
+    if (a.xcd_remap) {
+        // consecutive workgroup ids land on different XCDs (private L2s): give each XCD a contiguous band of tiles
+        // so the halo rows/columns neighbouring tiles share are L2 hits (bijective for any grid size)
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
     const int tx = bid % a.tiles_x;
     bid /= a.tiles_x;
     const int ty = bid % a.tiles_y;
@@ -192,7 +211,7 @@ conv_mfma_kernel(const ConvKArgs a) {
     unsigned voff[C::NPJ];
 #pragma unroll
     for (int j = 0; j < C::NPJ; ++j) {
-        const int i = wave + 4 * j;
+        const int i = wave + C::NW * j;
         const int q = i * 64 + lane;          // 16-byte slot index in the LDS patch image
         const int p = q >> 1;                 // patch pixel
         const int s = q & 1;                  // slot within the pixel
@@ -218,16 +237,27 @@ conv_mfma_kernel(const ConvKArgs a) {
     const int a_lane_off = n * 32 + ((kg ^ ((n >> 3) & 1)) << 4);
     const int b_lane_p = wn * R * C::PW + n;
 
-    if (NBUF == 2) {
-        issue_stage<C, KS, KC>(a, smem, 0, 0, wave, lane, z, voff, plane_elems, plane_bytes);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+    if constexpr (NBUF >= 2) {
+        // ring of NBUF stage buffers; up to NBUF-1 stages of DMA in flight, counted waits, one barrier per stage
+        const int nfull = nchunks / KC;       // stages that issue the full C::PS instructions per wave
+#pragma unroll
+        for (int s0 = 0; s0 < NBUF - 1; ++s0)
+            if (s0 < nst) issue_stage<C, KS, KC>(a, smem, s0, s0, wave, lane, z, voff, plane_elems, plane_bytes);
+        int cur = 0, nxt = NBUF - 1;
         for (int st = 0; st < nst; ++st) {
-            const int cur = st & 1;
-            if (st + 1 < nst) issue_stage<C, KS, KC>(a, smem, st + 1, cur ^ 1, wave, lane, z, voff, plane_elems, plane_bytes);
+            // younger full-size stages still allowed in flight while stage st must have landed
+            int yf = nfull - 1 - st;
+            yf = yf < 0 ? 0 : (yf > NBUF - 2 ? NBUF - 2 : yf);
+            if (NBUF >= 4 && yf >= 2) wait_vmcnt<(NBUF >= 4 ? 2 : 0) * C::PS>();
+            else if (NBUF >= 3 && yf >= 1) wait_vmcnt<(NBUF >= 3 ? 1 : 0) * C::PS>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (st + NBUF - 1 < nst)
+                issue_stage<C, KS, KC>(a, smem, st + NBUF - 1, nxt, wave, lane, z, voff, plane_elems, plane_bytes);
             compute_stage<C, KS, MT, R, KC, NT>(smem, st, cur, nchunks, wm, a_lane_off, b_lane_p, kg, acc);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            cur = (cur + 1 == NBUF) ? 0 : cur + 1;
+            nxt = (nxt + 1 == NBUF) ? 0 : nxt + 1;
         }
     } else {
         for (int st = 0; st < nst; ++st) {
@@ -343,7 +373,7 @@ static int launch_cfg(const ConvKArgs& ka, int cout_pad, hipStream_t s) {
     a.tiles_x = (a.W + 31) / 32;
     a.tiles_y = (a.H + C::TH - 1) / C::TH;
     dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N), (unsigned)(cout_pad / C::COUTB));
-    conv_mfma_kernel<KS, MT, WM, R, WN, KC, NT, NBUF, EPI><<<grid, dim3(256), C::LDS_BYTES, s>>>(a);
+    conv_mfma_kernel<KS, MT, WM, R, WN, KC, NT, NBUF, EPI><<<grid, dim3(64 * C::NW), C::LDS_BYTES, s>>>(a);
     BH_CHECK_LAUNCH();
     return 0;
 }
@@ -398,6 +428,7 @@ int bh_launch_conv(const BhConvCall& c, hipStream_t s) {
     a.cpg = d.x_cpg;
     a.relu = d.relu; a.has_res = (c.r_hi != nullptr); a.nimg = d.n_images; a.cout = d.cout;
     a.tiles_x = a.tiles_y = 0;
+    a.xcd_remap = 0;
     const int P = BINHIP_EPI_PLANES, S = BINHIP_EPI_SHUFFLE, F = BINHIP_EPI_FINAL;
     if (d.epilogue == P) {
         if (!c.y_hi || (d.nterms == 3 && !c.y_lo)) return BINHIP_E_ARG;
@@ -423,28 +454,84 @@ int bh_launch_conv(const BhConvCall& c, hipStream_t s) {
     return bh_dispatch_conv(a, k, cp, nt, e, s);
 }
 
-static int bh_dispatch_conv(const ConvKArgs& a, int k, int cp, int nt, int e, hipStream_t s) {
+// Kernel-configuration variants per layer class (tuning knob, see tools/bench_layers.py); the defaults below are
+// the measured-best ones on MI355X.
+// -1 = automatic (measured-best on MI355X at the 720p working size, see profiles/r01_layer_variants.md)
+static int g_variant[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+static int g_xcd_remap = 1;
+enum { CLS_K3C32 = 0, CLS_K1C96 = 1, CLS_K3C96 = 2, CLS_SHUFFLE = 3, CLS_FINAL = 4, CLS_K5 = 5 };
+
+static int bh_dispatch_conv(const ConvKArgs& a0, int k, int cp, int nt, int e, hipStream_t s) {
     const int P = BINHIP_EPI_PLANES, S = BINHIP_EPI_SHUFFLE, F = BINHIP_EPI_FINAL;
     const int cb = bh_conv_cout_block(k, cp, nt);
     if (cb <= 0 || cp % cb) return BINHIP_E_SHAPE;
+    ConvKArgs a = a0;
+    a.xcd_remap = g_xcd_remap;
     //                                   KS MT WM R WN KC NT NBUF EPI
     if (nt == 1) {
         if (e == F && k == 3 && cp == 32)  return launch_cfg<3, 1, 1, 4, 4, 1, 1, 2, F>(a, cp, s);
-        if (e == S && k == 3 && cp == 256) return launch_cfg<3, 2, 2, 4, 2, 1, 1, 2, S>(a, cp, s);
-        if (e == P && k == 3 && cb == 32)  return launch_cfg<3, 1, 1, 4, 4, 1, 1, 2, P>(a, cp, s);
+        if (e == S && k == 3 && cp == 256) {
+            switch (g_variant[CLS_SHUFFLE]) {
+                case 0: return launch_cfg<3, 2, 2, 4, 2, 1, 1, 2, S>(a, cp, s);
+                default: return launch_cfg<3, 2, 2, 4, 4, 1, 1, 2, S>(a, cp, s);     // 8 waves, 16x32 tile
+            }
+        }
+        if (e == P && k == 3 && cb == 32) {
+            switch (g_variant[CLS_K3C32]) {
+                case 1: return launch_cfg<3, 1, 1, 4, 4, 1, 1, 3, P>(a, cp, s);
+                case 2: return launch_cfg<3, 1, 1, 4, 4, 1, 1, 4, P>(a, cp, s);
+                case 3: return launch_cfg<3, 1, 1, 4, 8, 1, 1, 2, P>(a, cp, s);
+                case 4: return launch_cfg<3, 1, 1, 4, 8, 1, 1, 3, P>(a, cp, s);
+                case 5: return launch_cfg<3, 1, 1, 2, 4, 1, 1, 2, P>(a, cp, s);
+                case 6: return launch_cfg<3, 1, 1, 2, 4, 1, 1, 3, P>(a, cp, s);
+                case 7: return launch_cfg<3, 1, 1, 2, 8, 1, 1, 2, P>(a, cp, s);
+                case 8: return launch_cfg<3, 1, 1, 3, 4, 1, 1, 2, P>(a, cp, s);
+                case 9: return launch_cfg<3, 1, 1, 2, 8, 1, 1, 3, P>(a, cp, s);
+                case 0: return launch_cfg<3, 1, 1, 4, 4, 1, 1, 2, P>(a, cp, s);
+                default: return launch_cfg<3, 1, 1, 2, 8, 1, 1, 2, P>(a, cp, s);     // 8 waves x 2 rows, 16x32 tile
+            }
+        }
         if (e == P && k == 3 && cb == 64)  return launch_cfg<3, 2, 1, 2, 4, 1, 1, 2, P>(a, cp, s);
-        if (e == P && k == 3 && cb == 96)  return launch_cfg<3, 3, 1, 2, 4, 1, 1, 2, P>(a, cp, s);
+        if (e == P && k == 3 && cb == 96) {
+            switch (g_variant[CLS_K3C96]) {
+                case 1: return launch_cfg<3, 3, 1, 2, 4, 1, 1, 3, P>(a, cp, s);
+                default: return launch_cfg<3, 3, 1, 2, 4, 1, 1, 2, P>(a, cp, s);
+            }
+        }
         if (e == P && k == 1 && cb == 32)  return launch_cfg<1, 1, 1, 4, 4, 4, 1, 2, P>(a, cp, s);
-        if (e == P && k == 1 && cb == 96)  return launch_cfg<1, 3, 1, 2, 4, 4, 1, 2, P>(a, cp, s);
+        if (e == P && k == 1 && cb == 96) {
+            switch (g_variant[CLS_K1C96]) {
+                case 1: return launch_cfg<1, 3, 1, 2, 4, 2, 1, 2, P>(a, cp, s);
+                case 2: return launch_cfg<1, 3, 1, 2, 4, 2, 1, 3, P>(a, cp, s);
+                case 3: return launch_cfg<1, 3, 1, 4, 4, 2, 1, 2, P>(a, cp, s);
+                case 4: return launch_cfg<1, 3, 1, 2, 4, 1, 1, 4, P>(a, cp, s);
+                case 5: return launch_cfg<1, 3, 1, 4, 4, 2, 1, 3, P>(a, cp, s);
+                case 0: return launch_cfg<1, 3, 1, 2, 4, 4, 1, 2, P>(a, cp, s);
+                default: return launch_cfg<1, 3, 1, 2, 4, 2, 1, 2, P>(a, cp, s);     // 44 KB LDS -> 3 blocks/CU
+            }
+        }
         if (e == P && k == 5 && cb == 32)  return launch_cfg<5, 1, 1, 4, 4, 1, 1, 2, P>(a, cp, s);
     } else {
         if (e == F && k == 3 && cp == 32)  return launch_cfg<3, 1, 1, 4, 4, 1, 3, 2, F>(a, cp, s);
         if (e == S && k == 3 && cp == 256) return launch_cfg<3, 1, 2, 4, 2, 1, 3, 2, S>(a, cp, s);
-        if (e == P && k == 3 && cb == 32)  return launch_cfg<3, 1, 1, 4, 4, 1, 3, 2, P>(a, cp, s);
+        if (e == P && k == 3 && cb == 32) {
+            switch (g_variant[CLS_K3C32]) {
+                case 1: return launch_cfg<3, 1, 1, 2, 4, 1, 3, 3, P>(a, cp, s);
+                case 2: return launch_cfg<3, 1, 1, 2, 4, 1, 3, 2, P>(a, cp, s);
+                case 0: return launch_cfg<3, 1, 1, 4, 4, 1, 3, 2, P>(a, cp, s);
+                default: return launch_cfg<3, 1, 1, 2, 8, 1, 3, 2, P>(a, cp, s);
+            }
+        }
         if (e == P && k == 3 && cb == 64)  return launch_cfg<3, 2, 1, 2, 4, 1, 3, 2, P>(a, cp, s);
         if (e == P && k == 3 && cb == 96)  return launch_cfg<3, 3, 1, 2, 4, 1, 3, 2, P>(a, cp, s);
         if (e == P && k == 1 && cb == 32)  return launch_cfg<1, 1, 1, 4, 4, 2, 3, 2, P>(a, cp, s);
-        if (e == P && k == 1 && cb == 96)  return launch_cfg<1, 3, 1, 2, 4, 2, 3, 2, P>(a, cp, s);
+        if (e == P && k == 1 && cb == 96) {
+            switch (g_variant[CLS_K1C96]) {
+                case 1: return launch_cfg<1, 3, 1, 2, 4, 1, 3, 3, P>(a, cp, s);
+                case 0: return launch_cfg<1, 3, 1, 2, 4, 2, 3, 2, P>(a, cp, s);
+                default: return launch_cfg<1, 3, 1, 2, 4, 1, 3, 2, P>(a, cp, s);
+            }
+        }
         if (e == P && k == 5 && cb == 32)  return launch_cfg<5, 1, 1, 4, 4, 1, 3, 1, P>(a, cp, s);
     }
     return BINHIP_E_SHAPE;
@@ -555,6 +642,13 @@ int binhip_conv2d_bwd_data(const BinConvDesc* d, const void* gy_hi, const void* 
     c.y_hi = gx_hi; c.y_lo = gx_lo; c.y_f32 = nullptr;
     for (int i = 0; i < 5; ++i) c.images[i] = nullptr;
     return bh_launch_conv(c, (hipStream_t)stream);
+}
+
+int binhip_set_variant(int layer_class, int variant) {
+    if (layer_class == -1) { g_xcd_remap = variant; return 0; }
+    if (layer_class < 0 || layer_class >= 8) return BINHIP_E_ARG;
+    g_variant[layer_class] = variant;
+    return 0;
 }
 
 int binhip_profile_begin(int ksize, int cout_pad, int epilogue, int max_launches) {

@@ -206,6 +206,10 @@ int binhip_rdn_backward(const BinRdnBwdPlan* plan, const void* saved, size_t sav
  * hipEvent pair recorded on the launch stream; end() synchronises on them and returns the summed
  * kernel time.  Host-side only; at most `max_launches` (<= 16384) launches are recorded.           */
 int binhip_profile_begin(int ksize, int cout_pad, int epilogue, int max_launches);
+/* tuning knob: pick kernel-configuration `variant` for a layer class (0 RDB conv, 1 1x1->96, 2 3x3->96,
+ * 3 UPNet.0, 4 final, 5 5x5); layer_class -1 toggles the XCD-aware tile order.  Results are identical
+ * for every variant (same arithmetic order per output); process-global.                               */
+int binhip_set_variant(int layer_class, int variant);
 int binhip_profile_end(double* total_ms, int* launches);
 
 #ifdef __cplusplus

@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Per-layer microbenchmark at the 720p working size (half-res 384x672): times each distinct layer class of the
+RDN forward for every kernel variant (binhip_set_variant) with events on the launch stream, checks that all
+variants produce identical results, and prints us / actual fp16 GB/s / TFLOP/s."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from bin_amd import _lib as L, ops
+
+
+def time_fn(fn, iters=30, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3   # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nterms", type=int, default=1)
+    ap.add_argument("--h", type=int, default=384)
+    ap.add_argument("--w", type=int, default=672)
+    ap.add_argument("--n", type=int, default=1)
+    ap.add_argument("--classes", default="0,1,2,3,4,5")
+    args = ap.parse_args()
+    nt, n, h, w = args.nterms, args.n, args.h, args.w
+    lib = L.lib()
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(0)
+    px = n * h * w
+    bpe = 2 if nt == 1 else 4
+
+    def mk(c, hh=h, ww=w):
+        return ops.nchw_to_planes(torch.rand(n, c, hh, ww, generator=g).to(dev) - 0.3, nt)
+
+    def wts(cout, cin, ks, shuffle=False):
+        wt = (torch.rand(cout, cin, ks, ks, generator=g) - 0.5) / (cin * ks * ks) ** 0.5
+        return ops.ConvWeights(wt.to(dev), (torch.rand(cout, generator=g) - 0.5).to(dev), nterms=nt, shuffle=shuffle)
+
+    cases = []   # (class id, name, variants, fn factory, flops, bytes)
+    x224 = mk(224)
+    res96 = mk(96)
+    for cin in (96, 192):
+        cw = wts(32, cin, 3)
+        out = ops.CP.empty(2, n, h, w, nt, dev)
+        cases.append((0, f"RDB conv3x3 {cin}->32 +ReLU", [0, 3, 5, 6, 7, 8, 9] if nt == 1 else [0, 1, 2, 3],
+                      (lambda cw=cw, cin=cin, out=out: ops.conv2d(x224, cw, relu=True, out=out, cin_chunks=cin // 16)),
+                      2 * 9 * cin * 32 * px, (cin + 32) * bpe * px, out))
+    cw = wts(96, 224, 1)
+    out96 = ops.CP.empty(6, n, h, w, nt, dev)
+    cases.append((1, "LFF 1x1 224->96 +res", [0, 1, 4] if nt == 1 else [0, 1, 2],
+                  (lambda cw=cw: ops.conv2d(x224, cw, residual=res96, out=out96)), 2 * 224 * 96 * px,
+                  (224 + 96 + 96) * bpe * px, out96))
+    x1152 = mk(1152)
+    cwg = wts(96, 1152, 1)
+    outg = ops.CP.empty(6, n, h, w, nt, dev)
+    cases.append((1, "GFF.0 1x1 1152->96", [0, 1, 4] if nt == 1 else [0, 1, 2],
+                  (lambda: ops.conv2d(x1152, cwg, out=outg)), 2 * 1152 * 96 * px, (1152 + 96) * bpe * px, outg))
+    cw3 = wts(96, 96, 3)
+    out3 = ops.CP.empty(6, n, h, w, nt, dev)
+    cases.append((2, "3x3 96->96 +res", [0, 1] if nt == 1 else [0],
+                  (lambda: ops.conv2d(res96, cw3, residual=x224, out=out3)), 2 * 9 * 96 * 96 * px,
+                  (96 + 96 + 96) * bpe * px, out3))
+    cwu = wts(256, 96, 3, shuffle=True)
+    outu = ops.CP.empty(4, n, 2 * h, 2 * w, nt, dev)
+    cases.append((3, "UPNet.0 3x3 96->256 +shuffle", [0, 1] if nt == 1 else [0],
+                  (lambda: ops.conv2d(res96, cwu, out=outu, epilogue=L.EPI_SHUFFLE)), 2 * 9 * 96 * 256 * px,
+                  (96 + 256) * bpe * px, outu))
+    xu = mk(64, 2 * h, 2 * w)
+    cwf = wts(3, 64, 3)
+    imgs = [torch.rand(n, 3, 2 * h, 2 * w, generator=g).to(dev) for _ in range(2)]
+    cases.append((4, "UPNet.2 3x3 64->3 +mean (final)", [0],
+                  (lambda: ops.conv2d(xu, cwf, epilogue=L.EPI_FINAL, images=imgs)), 2 * 9 * 64 * 3 * 4 * px,
+                  (64 * bpe + 3 * 4 * 3) * 4 * px, None))
+    x48 = mk(48)
+    cw5 = wts(96, 36, 5)
+    out5 = ops.CP.empty(6, n, h, w, nt, dev)
+    cases.append((5, "SFENet1 5x5 36->96", [0], (lambda: ops.conv2d(x48, cw5, out=out5, cin_chunks=3)),
+                  2 * 25 * 36 * 96 * px, (48 + 96) * bpe * px, out5))
+
+    want = {int(c) for c in args.classes.split(",")}
+    print(f"nterms={nt} N={n} {h}x{w}")
+    for xcd in (1,):
+        lib.binhip_set_variant(-1, xcd)
+        for cls, name, variants, fn, flops, nbytes, outbuf in cases:
+            if cls not in want:
+                continue
+            ref = None
+            for v in variants:
+                lib.binhip_set_variant(cls, v)
+                r = fn()
+                torch.cuda.synchronize()
+                cur = (outbuf.hi.clone() if outbuf is not None else r.clone())
+                if ref is None:
+                    ref = cur
+                same = bool(torch.equal(ref, cur))
+                us = time_fn(fn)
+                print(f"xcd={xcd} {name:34s} v{v}: {us:8.1f} us  {nbytes / us / 1e3:7.0f} GB/s(actual)  "
+                      f"{flops / us / 1e6:7.0f} TF/s  same={same}")
+            lib.binhip_set_variant(cls, 0)
+    lib.binhip_set_variant(-1, 0)
+
+
+if __name__ == "__main__":
+    main()
