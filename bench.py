@@ -34,10 +34,11 @@ BYTES_20, BYTES_17 = 304.5e9, 259.0e9
 
 
 def rdb_conv_algorithmic_bytes(n, h2, w2):
-    """fp32 layer-wise minimum of ONE launch of the dominant kernel, averaged over the four RDB convs
-    (Cin = 96,128,160,192 -> 32): read Cin planes once, write 32 once, weights once."""
+    """fp32 layer-wise minimum of ONE launch of the dominant kernel, averaged over the RDB convs it runs
+    (Cin = 96,128,160 -> 32; conv #3, Cin = 192, lives in the fused conv+LFF kernel): read Cin planes once,
+    write 32 once, weights once (SURVEY.md §8d per-layer figure)."""
     px = n * h2 * w2
-    per = [(cin + 32) * 4 * px + (cin * 32 * 9 + 32) * 4 for cin in (96, 128, 160, 192)]
+    per = [(cin + 32) * 4 * px + (cin * 32 * 9 + 32) * 4 for cin in (96, 128, 160)]
     return sum(per) / len(per)
 
 
@@ -126,6 +127,8 @@ def main():
     ap.add_argument("--precision", default=os.environ.get("BIN_AMD_BENCH_PRECISION", "f16"),
                     choices=["f16", "f16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--calib", action="store_true",
+                    help="also run one 256 MiB device copy (known HBM bytes) to calibrate rocprofv3 FETCH/WRITE_SIZE")
     ap.add_argument("--reference-schedule", action="store_true",
                     help="run the reference's literal 20 RDN calls + 12 cells instead of the exact 17 + 6")
     args = ap.parse_args()
@@ -162,9 +165,15 @@ def main():
     with torch.no_grad():
         for _ in range(args.warmup):
             out = net(*frames)
+        if args.calib:
+            src = torch.empty(64 << 20, dtype=torch.float32, device=dev).normal_()
+            dst = torch.empty_like(src)
+            for _ in range(3):
+                dst.copy_(src)
+            del src, dst
         sync_all()
         lib = L.lib()
-        launches_per_step = (17 if net.reuse_schedule else 20) * 48
+        launches_per_step = (17 if net.reuse_schedule else 20) * 36
         prof = rank == 0 and args.steps * launches_per_step <= 16384
         if prof:
             L.check(lib.binhip_profile_begin(3, 32, L.EPI_PLANES, args.steps * launches_per_step), "profile_begin")
@@ -193,7 +202,7 @@ def main():
             avg_s = kern_ms.value / kern_n.value * 1e-3
             ab = rdb_conv_algorithmic_bytes(1, hp // 2, wp // 2)
             ach = ab / avg_s / 1e9
-            roof = {"bound": "hbm", "kernel": "conv_mfma_kernel<3,1,1,4,4,1,NT,2,PLANES> (RDB conv3x3 Cin->32 +ReLU)",
+            roof = {"bound": "hbm", "kernel": "conv_mfma_kernel<3,1,1,2,8,1,NT,2,0> (RDB conv3x3 Cin->32 +ReLU, convs 0-2 of each dense block)",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                     "traffic": None, "avg_kernel_us": round(avg_s * 1e6, 2), "launches": kern_n.value,
                     "algorithmic_bytes_per_launch": int(ab),

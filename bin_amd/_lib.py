@@ -6,6 +6,7 @@ import os
 from .build import LIB_PATH
 
 RDN_LAYERS = 66
+PLAN_KEEP_ACTS, PLAN_NO_FUSE = 1, 2
 EPI_PLANES, EPI_SHUFFLE, EPI_FINAL = 0, 1, 2
 
 
@@ -78,6 +79,8 @@ _SIGNATURES = {
     "binhip_set_variant": (C.c_int, [C.c_int, C.c_int]),
     "binhip_profile_begin": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "binhip_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "binhip_rdb_tail_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 10 + [C.c_int, C.c_void_p]),
+    "binhip_set_tail_depth": (C.c_int, [C.c_int]),
     "binhip_rdn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "binhip_rdn_forward": (C.c_int, [C.POINTER(BinRdnPlan), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p,
                                      C.c_size_t, C.c_void_p]),

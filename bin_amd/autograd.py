@@ -37,7 +37,8 @@ class _RdnFn(torch.autograd.Function):
         if nbytes == 0:
             raise RuntimeError(f"bin_amd: unsupported RDN shape N={n} H={h} W={w}")
         saved = torch.empty(nbytes, dtype=torch.uint8, device=frames[0].device)
-        out = rdn_forward(weights, frames, ws=saved)
+        from . import rdn_plan
+        out = rdn_forward(weights, frames, ws=saved, flags=rdn_plan.PLAN_FLAGS | L.PLAN_KEEP_ACTS)
         ctx.module, ctx.nterms, ctx.n_frames = module, nterms, n_frames
         ctx.saved_ws = saved
         ctx.dims = (n, h, w)

@@ -105,11 +105,19 @@ int binhip_rdn_forward(const BinRdnPlan* p, const float* const* inputs, float* o
     // 12 residual dense blocks (RDN.py:149-165)
     for (int d = 0; d < 12; ++d) {
         const int64_t b = w.blk + (int64_t)d * 14 * P;
-        for (int c = 0; c < 4; ++c) {
+        const bool fuse = !(p->reserved & BINHIP_PLAN_NO_FUSE);
+        for (int c = 0; c < (fuse ? 3 : 4); ++c) {
             if ((rc = conv(2 + 5 * d + c, 3, 6 + 2 * c, 32, 32, P_, 1, h, ww, b, w.s_blk, 0, 0,
                            b + (int64_t)(6 + 2 * c) * P, w.s_blk, -1, 0))) return rc;
         }
-        if ((rc = conv(2 + 5 * d + 4, 1, 14, 96, 96, P_, 0, h, ww, b, w.s_blk, 0, 0, b + 14 * P, w.s_blk, b, w.s_blk)))
+        if (fuse) {
+            // conv #3 + LFF + residual in one kernel (binhip_fused.hip); o3 is only written out for training
+            const int L = 2 + 5 * d;
+            if ((rc = binhip_rdb_tail_fwd(N, h, ww, nt, HI(b), LO(b, w.s_blk), p->w_hi[L + 3], p->w_lo[L + 3], p->bias[L + 3],
+                                          p->w_hi[L + 4], p->w_lo[L + 4], p->bias[L + 4], HI(b + 14 * P),
+                                          LO(b + 14 * P, w.s_blk), (p->reserved & BINHIP_PLAN_KEEP_ACTS) ? 1 : 0, stream)))
+                return rc;
+        } else if ((rc = conv(2 + 5 * d + 4, 1, 14, 96, 96, P_, 0, h, ww, b, w.s_blk, 0, 0, b + 14 * P, w.s_blk, b, w.s_blk)))
             return rc;
     }
     // GFF.0 1x1 over cat(RDBs_out) (RDN.py:199, 218): 12 groups of 6 chunks, one per dense block

@@ -96,7 +96,10 @@ def workspace(nbytes, device, key="fwd"):
     return ws
 
 
-def rdn_forward(weights, inputs, out=None, ws=None):
+PLAN_FLAGS = 0          # module-level default (tests flip BINHIP_PLAN_NO_FUSE through this)
+
+
+def rdn_forward(weights, inputs, out=None, ws=None, flags=None):
     """inputs: list of fp32 [N,3,H,W] device tensors -> fp32 [N,3,H,W]."""
     _need_cuda(*inputs)
     inputs = [t.contiguous().float() for t in inputs]
@@ -105,6 +108,7 @@ def rdn_forward(weights, inputs, out=None, ws=None):
     lib = L.lib()
     plan = L.BinRdnPlan()
     plan.N, plan.H, plan.W, plan.n_inputs, plan.nterms = n, h, w, weights.n_inputs, weights.nterms
+    plan.reserved = PLAN_FLAGS if flags is None else flags
     weights.fill_plan(plan)
     nbytes = lib.binhip_rdn_workspace_bytes(n, h, w, weights.n_inputs, weights.nterms)
     if nbytes == 0:

@@ -131,13 +131,25 @@ int binhip_charbonnier_fwd(const float* x, const float* y, int64_t numel, float 
 int binhip_charbonnier_bwd(const float* x, const float* y, int64_t numel, float eps,
                            const float* gloss, float* gx, float* gy, void* stream);
 
+/* ---- fused tail of a residual dense block: o3 = relu(conv3x3(blk[0:192])), y = LFF(cat(blk[0:192], o3)) + blk[0:96]
+ * (RDN.py:141-147 for conv #3, :162-165 for LFF + residual) in one kernel; blk = 14-chunk dense-block buffer,
+ * wc/wl = binhip_weights_relayout outputs of conv #3 (cout_block 32) and LFF (cout_block 96); y = 6 planes.
+ * store_o3 != 0 also writes o3 to blk planes 12, 13 (needed by the backward pass only).               */
+int binhip_rdb_tail_fwd(int N, int H, int W, int nterms, const void* blk_hi, const void* blk_lo,
+                        const void* wc_hi, const void* wc_lo, const float* bias_c,
+                        const void* wl_hi, const void* wl_lo, const float* bias_l,
+                        void* y_hi, void* y_lo, int store_o3, void* stream);
+int binhip_set_tail_depth(int depth);   /* tuning knob: LDS ring depth 2/3/4 of the fused kernel (f16) */
+
 /* ---- one whole RDN sub-network (RDN.py:210-222 / 268-280 / 322-334) ---------------------------
  * 66 convolutions launched back-to-back on `stream` from C (no Python between layers).           */
+#define BINHIP_PLAN_KEEP_ACTS 1   /* training: keep every activation binhip_rdn_backward needs      */
+#define BINHIP_PLAN_NO_FUSE   2   /* run conv #3 and LFF of each RDB as two kernels (A/B + tests)   */
 typedef struct BinRdnPlan {
     int32_t N, H, W;          /* full-resolution frame size (H, W even)                          */
     int32_t n_inputs;         /* 2, 3 or 5 input frames                                          */
     int32_t nterms;           /* 1 or 3                                                          */
-    int32_t reserved;
+    int32_t reserved;         /* BINHIP_PLAN_* flags                                             */
     const void* w_hi[BINHIP_RDN_LAYERS];   /* relayouted weights per layer                       */
     const void* w_lo[BINHIP_RDN_LAYERS];   /* NULL when nterms == 1                              */
     const float* bias[BINHIP_RDN_LAYERS];

@@ -111,3 +111,20 @@ def test_cpu_tensor_raises():
     net = _net("f16")
     with pytest.raises(RuntimeError):
         net(*synthetic_frames(1, 1, 32, 32, 6))
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "f16"])
+def test_fused_rdb_tail_equals_unfused(prec, canon_gpu):
+    """binhip_rdb_tail_fwd (conv #3 + LFF + residual in one kernel) is bit-identical to the two-kernel path
+    (same accumulation order), with and without keeping o3 for the backward pass."""
+    from bin_amd import _lib as L, rdn_plan
+    from bin_amd.models.archs.RDN import PRECISIONS
+    from bin_amd.rdn_plan import RdnWeights, rdn_forward
+    g = torch.Generator().manual_seed(21)
+    for (n, h, w) in ((1, 64, 96), (2, 40, 72)):
+        ins = [torch.rand(n, 3, h, w, generator=g).cuda() for _ in range(3)]
+        wts = RdnWeights(canon_gpu, 3, PRECISIONS[prec], prefix="model2.")
+        a = rdn_forward(wts, ins, flags=0)
+        b = rdn_forward(wts, ins, flags=L.PLAN_NO_FUSE)
+        c = rdn_forward(wts, ins, flags=L.PLAN_KEEP_ACTS)
+        assert torch.equal(a, b) and torch.equal(a, c)

@@ -88,6 +88,35 @@ def main():
     cases.append((5, "SFENet1 5x5 36->96", [0], (lambda: ops.conv2d(x48, cw5, out=out5, cin_chunks=3)),
                   2 * 25 * 36 * 96 * px, (48 + 96) * bpe * px, out5))
 
+    # fused conv#3 + LFF vs the two separate kernels
+    import ctypes as C
+    blk = mk(224)
+    cw3b = wts(32, 192, 3)
+    cwlb = wts(96, 224, 1)
+    ynext = ops.CP.empty(6, n, h, w, nt, dev)
+
+    def fused(store=0):
+        L.check(lib.binhip_rdb_tail_fwd(n, h, w, nt, blk.hi.data_ptr(), blk.lo.data_ptr() if blk.lo is not None else None,
+                                        cw3b.w_hi.data_ptr(), cw3b.w_lo.data_ptr() if cw3b.w_lo is not None else None,
+                                        cw3b.bias.data_ptr(), cwlb.w_hi.data_ptr(),
+                                        cwlb.w_lo.data_ptr() if cwlb.w_lo is not None else None, cwlb.bias.data_ptr(),
+                                        ynext.hi.data_ptr(), ynext.lo.data_ptr() if ynext.lo is not None else None, store,
+                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)), "tail")
+
+    def unfused():
+        ops.conv2d(blk, cw3b, relu=True, out=blk.sub(12, 2), cin_chunks=12)
+        ops.conv2d(blk, cwlb, residual=blk.sub(0, 6), out=ynext)
+
+    fl = (2 * 9 * 192 * 32 + 2 * 224 * 96) * px
+    for d in ((2, 3, 4) if nt == 1 else (2,)):
+        lib.binhip_set_tail_depth(d)
+        us = time_fn(fused)
+        print(f"fused conv3+LFF depth {d}: {us:8.1f} us  {(192 + 96) * bpe * px / us / 1e3:7.0f} GB/s(actual)  {fl / us / 1e6:7.0f} TF/s")
+    us = time_fn(lambda: fused(1))
+    print(f"fused conv3+LFF (+store o3):  {us:8.1f} us")
+    lib.binhip_set_tail_depth(0)
+    us = time_fn(unfused)
+    print(f"unfused conv3 ; LFF:          {us:8.1f} us")
     want = {int(c) for c in args.classes.split(",")}
     print(f"nterms={nt} N={n} {h}x{w}")
     for xcd in (1,):
