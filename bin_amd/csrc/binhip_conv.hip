@@ -44,6 +44,7 @@ struct ConvKArgs {
     int tiles_x, tiles_y;
     int relu, has_res, nimg, cout;
     int xcd_remap;
+    int dbg;                  // ablation switches (timing experiments only): 1 skip weight DMA, 2 skip patch DMA, 4 skip MFMA
     int res_chunks;           // residual r applies to output chunks < res_chunks
     int mask_from;            // mask applies to output chunks >= mask_from (when m_hi != null)
     int y_cpg;                // output chunk grouping (<=0: one group)
@@ -101,7 +102,7 @@ __device__ __forceinline__ void issue_stage(const ConvKArgs& a, char* smem, int 
 #pragma unroll
                 for (int j = 0; j < C::NPJ; ++j) {
                     const int i = wave + C::NW * j;
-                    const bool real = (C::PP % C::NW == 0) || (i < C::PP);
+                    const bool real = ((C::PP % C::NW == 0) || (i < C::PP)) && !(a.dbg & 2);
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(real ? lds + i * 1024 : dummy), 16,
                                                              real ? voff[j] : 0x80000000u, 0, 0, 0);
                 }
@@ -112,7 +113,7 @@ __device__ __forceinline__ void issue_stage(const ConvKArgs& a, char* smem, int 
 #pragma unroll
                 for (int j = 0; j < C::NWJ; ++j) {
                     const int i = wave + C::NW * j;
-                    const bool real = (C::WP % C::NW == 0) || (i < C::WP);
+                    const bool real = ((C::WP % C::NW == 0) || (i < C::WP)) && !(a.dbg & 1);
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(ws, (lds_void_t*)(real ? lds + (C::PP + i) * 1024 : dummy), 16,
                                                              real ? (unsigned)(lane * 16) : 0x80000000u,
                                                              real ? i * 1024 : 0, 0, 0);
@@ -255,7 +256,7 @@ conv_mfma_kernel(const ConvKArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             if (st + NBUF - 1 < nst)
                 issue_stage<C, KS, KC>(a, smem, st + NBUF - 1, nxt, wave, lane, z, voff, plane_elems, plane_bytes);
-            compute_stage<C, KS, MT, R, KC, NT>(smem, st, cur, nchunks, wm, a_lane_off, b_lane_p, kg, acc);
+            if (!(a.dbg & 4)) compute_stage<C, KS, MT, R, KC, NT>(smem, st, cur, nchunks, wm, a_lane_off, b_lane_p, kg, acc);
             cur = (cur + 1 == NBUF) ? 0 : cur + 1;
             nxt = (nxt + 1 == NBUF) ? 0 : nxt + 1;
         }
@@ -270,88 +271,121 @@ conv_mfma_kernel(const ConvKArgs a) {
     }
 
     // ---- epilogue -------------------------------------------------------------------------------
-    // acc[mt][r][4g+j] = D[cout = 8g + 4*kg + j][pixel = n]  (32x32 MFMA C/D layout)
+    // acc[mt][r][4g+j] = D[cout = 8g + 4*kg + j][pixel = n]  (32x32 MFMA C/D layout): a lane holds 4 consecutive
+    // channels of one pixel per g, and lanes n / n+32 hold the two halves of each 8-channel slot.  One
+    // v_permlane32_swap per dword turns a (g even, g odd) pair into full 16-byte slots — lanes 0-31 get slot 0, lanes
+    // 32-63 slot 1 of the same pixel — so every store instruction writes 32 pixels x 32 B = 1 KiB contiguous.
     const int gx = tx0 + n;
+    if constexpr (EPI == BINHIP_EPI_FINAL) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int gy = ty0 + wn * R + r;
-        const bool ok = (gy < H) && (gx < W);
-        if (!ok) continue;
+        for (int r = 0; r < R; ++r) {
+            const int gy = ty0 + wn * R + r;
+            if (!((gy < H) && (gx < W)) || kg != 0 || z != 0 || wm != 0) continue;
+            const float4 bv = *reinterpret_cast<const float4*>(a.bias);
+            const float v[4] = {acc[0][r][0] + bv.x, acc[0][r][1] + bv.y, acc[0][r][2] + bv.z, acc[0][r][3] + bv.w};
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
+            for (int j = 0; j < 4; ++j) {
+                if (j >= a.cout) break;
+                const long long idx = (((long long)img * a.cout + j) * H + gy) * W + gx;
+                float s = 0.f;
+                if (a.nimg > 0) {
+                    s = a.img[0][idx];
+                    for (int t = 1; t < a.nimg; ++t) s += a.img[t][idx];
+                    s = s / (float)a.nimg;
+                }
+                a.out_f32[idx] = v[j] + s;
+            }
+        }
+    } else {
+        union H4 { half4 h; unsigned u[2]; };
+        const int gxc = gx < W ? gx : W - 1;     // clamped coordinates: loads need no branch, stores are predicated
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = z * C::COUTB + (wm * MT + mt) * 32 + 8 * g + 4 * kg;
-                const float4 bv = *reinterpret_cast<const float4*>(a.bias + co);
-                float v[4] = {acc[mt][r][4 * g + 0] + bv.x, acc[mt][r][4 * g + 1] + bv.y,
-                              acc[mt][r][4 * g + 2] + bv.z, acc[mt][r][4 * g + 3] + bv.w};
-                if constexpr (EPI == BINHIP_EPI_FINAL) {
-                    if (co == 0) {
+        for (int r = 0; r < R; ++r) {
+            const int gy = ty0 + wn * R + r;
+            const bool ok = (gy < H) && (gx < W);
+            const int gyc = gy < H ? gy : H - 1;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    H4 hv[2], lv[2];
+                    long long o_slot = 0;        // element offset of this lane's 16-byte slot after the swap
+#pragma unroll
+                    for (int ge = 0; ge < 2; ++ge) {
+                        const int g = 2 * gp + ge;
+                        const int co = z * C::COUTB + (wm * MT + mt) * 32 + 8 * g + 4 * kg;
+                        const float4 bv = *reinterpret_cast<const float4*>(a.bias + co);
+                        float v[4] = {acc[mt][r][4 * g + 0] + bv.x, acc[mt][r][4 * g + 1] + bv.y,
+                                      acc[mt][r][4 * g + 2] + bv.z, acc[mt][r][4 * g + 3] + bv.w};
+                        long long o;
+                        if constexpr (EPI == BINHIP_EPI_SHUFFLE) {
+                            const int cq = (a.cout + 3) / 4;      // channels after the shuffle
+                            const int sub = co / cq, cc = co - sub * cq;
+                            const int oy = 2 * gyc + (sub >> 1), ox = 2 * gxc + (sub & 1);
+                            o = (long long)(cc >> 4) * (plane_elems * 4) +
+                                ((((long long)img * 2 * H + oy) * (2 * W) + ox) << 4) + (cc & 15);
+                        } else {
+                            const int och = co >> 4;
+                            const long long pix16 = ((((long long)img * H + gyc) * W + gxc) << 4) + (co & 15);
+                            o = (a.y_cpg > 0)
+                                ? (long long)(och / a.y_cpg) * a.y_group_stride + (long long)(och % a.y_cpg) * plane_elems + pix16
+                                : (long long)och * plane_elems + pix16;
+                            {
+                                if (a.has_res && och < a.res_chunks) {
+                                    const half4 rh = *reinterpret_cast<const half4*>(a.r_hi + o);
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) v[j] += (float)rh[j];
+                                    if constexpr (NT == 3) {
+                                        const half4 rl = *reinterpret_cast<const half4*>(a.r_lo + o);
+#pragma unroll
+                                        for (int j = 0; j < 4; ++j) v[j] += (float)rl[j];
+                                    }
+                                }
+                                if (a.r2_hi) {
+                                    const half4 rh = *reinterpret_cast<const half4*>(a.r2_hi + o);
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) v[j] += (float)rh[j];
+                                    if constexpr (NT == 3) {
+                                        const half4 rl = *reinterpret_cast<const half4*>(a.r2_lo + o);
+#pragma unroll
+                                        for (int j = 0; j < 4; ++j) v[j] += (float)rl[j];
+                                    }
+                                }
+                            }
+                            if (a.relu) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                            }
+                            if (a.m_hi && och >= a.mask_from) {
+                                const half4 mh = *reinterpret_cast<const half4*>(a.m_hi + o);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v[j] = ((float)mh[j] > 0.f) ? v[j] : 0.f;
+                            }
+                        }
+                        // after the swap, lanes 0-31 own slot 0 (g even) and lanes 32-63 slot 1 (g odd) of pixel n:
+                        // the slot start is this (g, kg=0) element offset
+                        if (ge == kg) o_slot = o - 4 * kg;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            if (j >= a.cout) break;
-                            const long long idx = (((long long)img * a.cout + j) * H + gy) * W + gx;
-                            float s = 0.f;
-                            if (a.nimg > 0) {
-                                s = a.img[0][idx];
-                                for (int t = 1; t < a.nimg; ++t) s += a.img[t][idx];
-                                s = s / (float)a.nimg;
-                            }
-                            a.out_f32[idx] = v[j] + s;
+                            hv[ge].h[j] = (_Float16)v[j];
+                            lv[ge].h[j] = (_Float16)(v[j] - (float)hv[ge].h[j]);
                         }
                     }
-                } else {
-                    long long o;
-                    if constexpr (EPI == BINHIP_EPI_SHUFFLE) {
-                        const int cq = (a.cout + 3) / 4;      // channels after the shuffle
-                        const int sub = co / cq, cc = co - sub * cq;
-                        const int oy = 2 * gy + (sub >> 1), ox = 2 * gx + (sub & 1);
-                        o = (long long)(cc >> 4) * (plane_elems * 4) +
-                            ((((long long)img * 2 * H + oy) * (2 * W) + ox) << 4) + (cc & 15);
-                    } else {
-                        const int och = co >> 4;
-                        const long long pix16 = ((((long long)img * H + gy) * W + gx) << 4) + (co & 15);
-                        o = (a.y_cpg > 0)
-                            ? (long long)(och / a.y_cpg) * a.y_group_stride + (long long)(och % a.y_cpg) * plane_elems + pix16
-                            : (long long)och * plane_elems + pix16;
-                        if (a.has_res && och < a.res_chunks) {
-                            const half4 rh = *reinterpret_cast<const half4*>(a.r_hi + o);
+                    // vdst = even group, src = odd group: upper half of vdst <-> lower half of src
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] += (float)rh[j];
-                            if constexpr (NT == 3) {
-                                const half4 rl = *reinterpret_cast<const half4*>(a.r_lo + o);
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) v[j] += (float)rl[j];
-                            }
-                        }
-                        if (a.r2_hi) {
-                            const half4 rh = *reinterpret_cast<const half4*>(a.r2_hi + o);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] += (float)rh[j];
-                            if constexpr (NT == 3) {
-                                const half4 rl = *reinterpret_cast<const half4*>(a.r2_lo + o);
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) v[j] += (float)rl[j];
-                            }
-                        }
-                        if (a.relu) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-                        }
-                        if (a.m_hi && och >= a.mask_from) {
-                            const half4 mh = *reinterpret_cast<const half4*>(a.m_hi + o);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] = ((float)mh[j] > 0.f) ? v[j] : 0.f;
+                    for (int k = 0; k < 2; ++k) {
+                        auto sw = __builtin_amdgcn_permlane32_swap(hv[0].u[k], hv[1].u[k], false, false);
+                        hv[0].u[k] = sw[0]; hv[1].u[k] = sw[1];
+                        if constexpr (NT == 3) {
+                            auto sl = __builtin_amdgcn_permlane32_swap(lv[0].u[k], lv[1].u[k], false, false);
+                            lv[0].u[k] = sl[0]; lv[1].u[k] = sl[1];
                         }
                     }
-                    half4 hv, lv;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        hv[j] = (_Float16)v[j];
-                        lv[j] = (_Float16)(v[j] - (float)hv[j]);
+                    if (ok) {
+                        *reinterpret_cast<uint4*>(a.y_hi + o_slot) = make_uint4(hv[0].u[0], hv[0].u[1], hv[1].u[0], hv[1].u[1]);
+                        if constexpr (NT == 3)
+                            *reinterpret_cast<uint4*>(a.y_lo + o_slot) = make_uint4(lv[0].u[0], lv[0].u[1], lv[1].u[0], lv[1].u[1]);
                     }
-                    *reinterpret_cast<half4*>(a.y_hi + o) = hv;
-                    if constexpr (NT == 3) *reinterpret_cast<half4*>(a.y_lo + o) = lv;
                 }
             }
         }
@@ -429,6 +463,7 @@ int bh_launch_conv(const BhConvCall& c, hipStream_t s) {
     a.relu = d.relu; a.has_res = (c.r_hi != nullptr); a.nimg = d.n_images; a.cout = d.cout;
     a.tiles_x = a.tiles_y = 0;
     a.xcd_remap = 0;
+    a.dbg = 0;
     const int P = BINHIP_EPI_PLANES, S = BINHIP_EPI_SHUFFLE, F = BINHIP_EPI_FINAL;
     if (d.epilogue == P) {
         if (!c.y_hi || (d.nterms == 3 && !c.y_lo)) return BINHIP_E_ARG;
@@ -459,6 +494,7 @@ int bh_launch_conv(const BhConvCall& c, hipStream_t s) {
 // -1 = automatic (measured-best on MI355X at the 720p working size, see profiles/r01_layer_variants.md)
 static int g_variant[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
 static int g_xcd_remap = 1;
+static int g_dbg = 0;
 enum { CLS_K3C32 = 0, CLS_K1C96 = 1, CLS_K3C96 = 2, CLS_SHUFFLE = 3, CLS_FINAL = 4, CLS_K5 = 5 };
 
 static int bh_dispatch_conv(const ConvKArgs& a0, int k, int cp, int nt, int e, hipStream_t s) {
@@ -467,6 +503,7 @@ static int bh_dispatch_conv(const ConvKArgs& a0, int k, int cp, int nt, int e, h
     if (cb <= 0 || cp % cb) return BINHIP_E_SHAPE;
     ConvKArgs a = a0;
     a.xcd_remap = g_xcd_remap;
+    a.dbg = g_dbg;
     //                                   KS MT WM R WN KC NT NBUF EPI
     if (nt == 1) {
         if (e == F && k == 3 && cp == 32)  return launch_cfg<3, 1, 1, 4, 4, 1, 1, 2, F>(a, cp, s);
@@ -646,6 +683,7 @@ int binhip_conv2d_bwd_data(const BinConvDesc* d, const void* gy_hi, const void* 
 
 int binhip_set_variant(int layer_class, int variant) {
     if (layer_class == -1) { g_xcd_remap = variant; return 0; }
+    if (layer_class == -2) { g_dbg = variant; return 0; }
     if (layer_class < 0 || layer_class >= 8) return BINHIP_E_ARG;
     g_variant[layer_class] = variant;
     return 0;

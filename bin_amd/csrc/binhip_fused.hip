@@ -214,29 +214,46 @@ rdb_tail_kernel(const TailKArgs a) {
     char* o3 = smem + cur * C::BUF_BYTES + wave * (C::R * 2 * 32 * 32);
     constexpr int O3_PLANE = C::NW * C::R * 2 * 32 * 32;     // hi tiles of all waves, then lo tiles
     const int gx = tx0 + n;
+    union H4 { half4 h; unsigned u[2]; };
 #pragma unroll
     for (int r = 0; r < C::R; ++r) {
         const int gy = ty0 + wave * C::R + r;
         const bool ok = (gy < H) && (gx < W);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int co = 8 * g + 4 * kg;
-            const float4 bv = *reinterpret_cast<const float4*>(a.bc + co);
-            float v[4] = {fmaxf(accc[r][4 * g + 0] + bv.x, 0.f), fmaxf(accc[r][4 * g + 1] + bv.y, 0.f),
-                          fmaxf(accc[r][4 * g + 2] + bv.z, 0.f), fmaxf(accc[r][4 * g + 3] + bv.w, 0.f)};
-            half4 hv, lv;
+        for (int gp = 0; gp < 2; ++gp) {
+            H4 hv[2], lv[2];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                hv[j] = (_Float16)v[j];
-                lv[j] = (_Float16)(v[j] - (float)hv[j]);
+            for (int ge = 0; ge < 2; ++ge) {
+                const int g = 2 * gp + ge;
+                const int co = 8 * g + 4 * kg;
+                const float4 bv = *reinterpret_cast<const float4*>(a.bc + co);
+                const float v[4] = {fmaxf(accc[r][4 * g + 0] + bv.x, 0.f), fmaxf(accc[r][4 * g + 1] + bv.y, 0.f),
+                                    fmaxf(accc[r][4 * g + 2] + bv.z, 0.f), fmaxf(accc[r][4 * g + 3] + bv.w, 0.f)};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    hv[ge].h[j] = (_Float16)v[j];
+                    lv[ge].h[j] = (_Float16)(v[j] - (float)hv[ge].h[j]);
+                }
+                const int off = ((gp * C::R + r) * 32 + n) * 32 + ((ge ^ ((n >> 3) & 1)) << 4) + kg * 8;
+                *reinterpret_cast<half4*>(o3 + off) = hv[ge].h;
+                if constexpr (NT == 3) *reinterpret_cast<half4*>(o3 + O3_PLANE + off) = lv[ge].h;
             }
-            const int off = (((g >> 1) * C::R + r) * 32 + n) * 32 + (((g & 1) ^ ((n >> 3) & 1)) << 4) + kg * 8;
-            *reinterpret_cast<half4*>(o3 + off) = hv;
-            if constexpr (NT == 3) *reinterpret_cast<half4*>(o3 + O3_PLANE + off) = lv;
-            if (a.o3_hi && ok) {
-                const long long o = (long long)(g >> 1) * plane_elems + ((((long long)img * H + gy) * W + gx) << 4) + (co & 15);
-                *reinterpret_cast<half4*>(a.o3_hi + o) = hv;
-                if constexpr (NT == 3) *reinterpret_cast<half4*>(a.o3_lo + o) = lv;
+            if (a.o3_hi) {      // training only: keep o3 for the backward pass (16-byte coalesced stores, see binhip_conv.hip)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    auto sw = __builtin_amdgcn_permlane32_swap(hv[0].u[k], hv[1].u[k], false, false);
+                    hv[0].u[k] = sw[0]; hv[1].u[k] = sw[1];
+                    if constexpr (NT == 3) {
+                        auto sl = __builtin_amdgcn_permlane32_swap(lv[0].u[k], lv[1].u[k], false, false);
+                        lv[0].u[k] = sl[0]; lv[1].u[k] = sl[1];
+                    }
+                }
+                if (ok) {
+                    const long long o = (long long)gp * plane_elems + ((((long long)img * H + gy) * W + gx) << 4) + kg * 8;
+                    *reinterpret_cast<uint4*>(a.o3_hi + o) = make_uint4(hv[0].u[0], hv[0].u[1], hv[1].u[0], hv[1].u[1]);
+                    if constexpr (NT == 3)
+                        *reinterpret_cast<uint4*>(a.o3_lo + o) = make_uint4(lv[0].u[0], lv[0].u[1], lv[1].u[0], lv[1].u[1]);
+                }
             }
         }
     }
@@ -271,35 +288,58 @@ rdb_tail_kernel(const TailKArgs a) {
     }
 
     // ---- LFF epilogue: bias + block input (the RDB residual) -> next block's first 6 planes ----------------------
+    const int gxc = gx < W ? gx : W - 1;
 #pragma unroll
     for (int r = 0; r < C::R; ++r) {
         const int gy = ty0 + wave * C::R + r;
-        if (!((gy < H) && (gx < W))) continue;
+        const bool ok = (gy < H) && (gx < W);
+        const int gyc = gy < H ? gy : H - 1;
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = mt * 32 + 8 * g + 4 * kg;
-                const float4 bv = *reinterpret_cast<const float4*>(a.bl + co);
-                float v[4] = {accl[mt][r][4 * g + 0] + bv.x, accl[mt][r][4 * g + 1] + bv.y,
-                              accl[mt][r][4 * g + 2] + bv.z, accl[mt][r][4 * g + 3] + bv.w};
-                const long long o = (long long)(co >> 4) * plane_elems + ((((long long)img * H + gy) * W + gx) << 4) + (co & 15);
-                const half4 rh = *reinterpret_cast<const half4*>(a.x_hi + o);
+            for (int gp = 0; gp < 2; ++gp) {
+                H4 hv[2], lv[2];
+                long long o_slot = 0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] += (float)rh[j];
-                if constexpr (NT == 3) {
-                    const half4 rl = *reinterpret_cast<const half4*>(a.x_lo + o);
+                for (int ge = 0; ge < 2; ++ge) {
+                    const int g = 2 * gp + ge;
+                    const int co = mt * 32 + 8 * g + 4 * kg;
+                    const float4 bv = *reinterpret_cast<const float4*>(a.bl + co);
+                    float v[4] = {accl[mt][r][4 * g + 0] + bv.x, accl[mt][r][4 * g + 1] + bv.y,
+                                  accl[mt][r][4 * g + 2] + bv.z, accl[mt][r][4 * g + 3] + bv.w};
+                    // addresses are clamped into the image so the residual loads need no branch (stores are predicated)
+                    const long long o = (long long)(co >> 4) * plane_elems + ((((long long)img * H + gyc) * W + gxc) << 4) + (co & 15);
+                    {
+                        const half4 rh = *reinterpret_cast<const half4*>(a.x_hi + o);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += (float)rl[j];
+                        for (int j = 0; j < 4; ++j) v[j] += (float)rh[j];
+                        if constexpr (NT == 3) {
+                            const half4 rl = *reinterpret_cast<const half4*>(a.x_lo + o);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] += (float)rl[j];
+                        }
+                    }
+                    if (ge == kg) o_slot = o - 4 * kg;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        hv[ge].h[j] = (_Float16)v[j];
+                        lv[ge].h[j] = (_Float16)(v[j] - (float)hv[ge].h[j]);
+                    }
                 }
-                half4 hv, lv;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    hv[j] = (_Float16)v[j];
-                    lv[j] = (_Float16)(v[j] - (float)hv[j]);
+                for (int k = 0; k < 2; ++k) {
+                    auto sw = __builtin_amdgcn_permlane32_swap(hv[0].u[k], hv[1].u[k], false, false);
+                    hv[0].u[k] = sw[0]; hv[1].u[k] = sw[1];
+                    if constexpr (NT == 3) {
+                        auto sl = __builtin_amdgcn_permlane32_swap(lv[0].u[k], lv[1].u[k], false, false);
+                        lv[0].u[k] = sl[0]; lv[1].u[k] = sl[1];
+                    }
                 }
-                *reinterpret_cast<half4*>(a.y_hi + o) = hv;
-                if constexpr (NT == 3) *reinterpret_cast<half4*>(a.y_lo + o) = lv;
+                if (ok) {
+                    *reinterpret_cast<uint4*>(a.y_hi + o_slot) = make_uint4(hv[0].u[0], hv[0].u[1], hv[1].u[0], hv[1].u[1]);
+                    if constexpr (NT == 3)
+                        *reinterpret_cast<uint4*>(a.y_lo + o_slot) = make_uint4(lv[0].u[0], lv[0].u[1], lv[1].u[0], lv[1].u[1]);
+                }
             }
         }
     }

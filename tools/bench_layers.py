@@ -117,6 +117,19 @@ def main():
     lib.binhip_set_tail_depth(0)
     us = time_fn(unfused)
     print(f"unfused conv3 ; LFF:          {us:8.1f} us")
+    if os.environ.get("ABLATE"):
+        for cin in (96, 192):
+            cw = wts(32, cin, 3)
+            out = ops.CP.empty(2, n, h, w, nt, dev)
+            f = (lambda cw=cw, cin=cin, out=out: ops.conv2d(x224, cw, relu=True, out=out, cin_chunks=cin // 16))
+            for v in (-1, 0, 3):
+                lib.binhip_set_variant(0, v)
+                for dbg, nm in ((0, "full"), (1, "no weight DMA"), (2, "no patch DMA"), (3, "no DMA at all"), (4, "no MFMA"),
+                                (7, "nothing (launch+epilogue)")):
+                    lib.binhip_set_variant(-2, dbg)
+                    print(f"ablate RDB conv {cin}->32 variant {v:2d} {nm:28s}: {time_fn(f):7.1f} us")
+        lib.binhip_set_variant(-2, 0)
+        lib.binhip_set_variant(0, -1)
     want = {int(c) for c in args.classes.split(",")}
     print(f"nterms={nt} N={n} {h}x{w}")
     for xcd in (1,):
