@@ -42,6 +42,17 @@ def rdb_conv_algorithmic_bytes(n, h2, w2):
     return sum(per) / len(per)
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01_pmc_traffic.md: separate FETCH_SIZE / WRITE_SIZE runs, FETCH doubled per the gfx950 calibration).
+    PMC counters cannot be read from inside the process, so bench.py reports the profiled figure (or null)."""
+    try:
+        with open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")) as f:
+            return int(json.load(f)["traffic_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def _host_cores():
     """Cores this process may really use: affinity mask, clipped by the cgroup CPU quota if there is one."""
     try:
@@ -119,6 +130,61 @@ def cpu_baseline(timeout_s=150):
                 "sample": f"cpu baseline exceeded {timeout_s}s and was cut"}
 
 
+def train_bench(args, rank, world, dev):
+    """Secondary metric (BASELINE.json config 4): training samples/s, one process per GPU, DP gradient all-reduce."""
+    import tempfile
+    import torch.distributed as dist
+    from bin_amd.models import create_model
+    from bin_amd.weights import reference_state_dict
+    prec = "f16x3" if args.precision == "f16" and "BIN_AMD_BENCH_PRECISION" not in os.environ and "--precision" not in sys.argv \
+        else args.precision
+    tmp = tempfile.mkdtemp()
+    opt = {"model": "bin", "gpu_ids": [0], "is_train": True, "dist": world > 1,
+           "network_G": {"which_model_G": "bin_stage4", "nframes": 6, "version": 2, "precision": prec},
+           "path": {"pretrain_model_G": None, "strict_load": True, "models": tmp, "training_state": tmp},
+           "train": {"pixel_criterion": "cb", "pixel_weight": 1.0, "weight_decay_G": 0, "ft_tsa_only": None,
+                     "lr_G": 1e-4, "beta1": 0.9, "beta2": 0.99, "lr_scheme": "MultiStepLR", "lr_steps": [100000],
+                     "restarts": None, "restart_weights": None, "lr_gamma": 0.5, "clear_state": False}}
+    m = create_model(opt)
+    m.netG.module.load_state_dict(reference_state_dict(0), strict=True)
+    g = torch.Generator().manual_seed(7 + rank)
+    B, S = args.batch, 256
+    batch = {"LQs": torch.rand(B, 6, 3, S, S, generator=g), "GTenh": torch.rand(B, 6, 3, S, S, generator=g),
+             "GTinp": torch.rand(B, 5, 3, S, S, generator=g)}
+    m.feed_data(batch)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        m.optimize_parameters(i + 1)
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        m.optimize_parameters(args.warmup + i + 1)
+    sync_all()
+    dt = time.perf_counter() - t0
+    t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    dt = float(t_max.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "training samples/sec (256x256 crops, 6-frame windows)", "value": round(world * B * args.steps / dt, 4),
+            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": prec, "data": "synthetic", "loss": float(m.loss.detach()),
+            "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2),
+            "config": {"workload": f"Adobe240 training, 256x256 crops, batch {B} per GPU, Charbonnier x17, Adam, "
+                                   f"DP flat gradient all-reduce (45.77 MB)", "precision": prec}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,6 +195,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--calib", action="store_true",
                     help="also run one 256 MiB device copy (known HBM bytes) to calibrate rocprofv3 FETCH/WRITE_SIZE")
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
+                    help="train: BASELINE config 4 — one optimize_parameters() (fwd + Charbonnier + bwd + grad "
+                         "all-reduce + Adam) on 256x256 crops, --batch samples per GPU (secondary metric, own JSON line)")
+    ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--reference-schedule", action="store_true",
                     help="run the reference's literal 20 RDN calls + 12 cells instead of the exact 17 + 6")
     args = ap.parse_args()
@@ -141,6 +211,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    if args.mode == "train":
+        return train_bench(args, rank, world, dev)
 
     from bin_amd import _lib as L
     from bin_amd.models.archs.RDN import bin_stage4_lstm
@@ -204,7 +277,7 @@ def main():
             ach = ab / avg_s / 1e9
             roof = {"bound": "hbm", "kernel": "conv_mfma_kernel<3,1,1,2,8,1,NT,2,0> (RDB conv3x3 Cin->32 +ReLU, convs 0-2 of each dense block)",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": None, "avg_kernel_us": round(avg_s * 1e6, 2), "launches": kern_n.value,
+                    "traffic": pmc_traffic(), "avg_kernel_us": round(avg_s * 1e6, 2), "launches": kern_n.value,
                     "algorithmic_bytes_per_launch": int(ab),
                     "whole_forward": {"algorithmic_GB": abytes / 1e9, "achieved_GBs": round(abytes / (ms * 1e-3) / 1e9, 1),
                                       "frac_hbm": round(abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

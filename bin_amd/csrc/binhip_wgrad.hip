@@ -239,44 +239,51 @@ wgrad_mfma_kernel(const WgradKArgs a) {
     }
 }
 
-// final deterministic reduction over the PB partials + un-scale + scatter to OIHW
+// final deterministic reduction over the PB partials + un-scale + scatter to OIHW.
+// One 256-thread block per (z, cp, tap, m) row of 32 outputs: thread (nn, ps) sums every 8th partial (coalesced 128-B
+// reads), the 8 slices are combined through LDS in a fixed order.  Rows >= nrows handle the bias (one per co tile).
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ partial_b, int PB, int ncp, int ncot,
                     int ks, int tr, int cout, int cin, const float* __restrict__ inv_scale, float* __restrict__ dw,
-                    float* __restrict__ db, int accumulate, int shuffle) {
+                    float* __restrict__ db, int accumulate, int shuffle, long long nrows) {
+    __shared__ float sm[8][32];
     const int ntap_blk = tr * ks;
-    const int ndyg = ks / tr;
-    const long long total = (long long)ndyg * ncot * ncp * ntap_blk * 1024;
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nn = threadIdx.x & 31, ps = threadIdx.x >> 5;
     const float is = inv_scale ? inv_scale[0] : 1.f;
-    if (t < (long long)ncot * 32 && db) {
-        const int co = (int)t;
-        if (co < cout) {
-            float s = 0.f;
-            for (int p = 0; p < PB; ++p) s += partial_b[((long long)(co >> 5) * PB + p) * 32 + (co & 31)];
-            int cr = co;
-            if (shuffle) { const int cq = cout / 4; cr = (co % cq) * 4 + co / cq; }
-            db[cr] = accumulate ? db[cr] + s * is : s * is;
-        }
-    }
-    if (t >= total) return;
-    const int nn = (int)(t & 31);
-    const int m = (int)((t >> 5) & 31);
-    long long u = t >> 10;
-    const int tap = (int)(u % ntap_blk); u /= ntap_blk;
-    const int cp = (int)(u % ncp); u /= ncp;
-    const int z = (int)u;                       // = dyg * ncot + cot
-    const int cot = z % ncot, dyg = z / ncot;
-    const int co = cot * 32 + nn, ci = cp * 32 + m;
-    if (co >= cout || ci >= cin) return;
-    const int dy = dyg * tr + tap / ks, dx = tap % ks;
+    const long long row = blockIdx.x;
     float s = 0.f;
-    const long long base = (((long long)z * ncp + cp) * PB) * ntap_blk + tap;
-    for (int p = 0; p < PB; ++p) s += partial[(base + (long long)p * ntap_blk) * 1024 + m * 32 + nn];
+    int co, ci = 0, dy = 0, dx = 0;
+    bool is_bias = row >= nrows;
+    if (!is_bias) {
+        const int m = (int)(row & 31);
+        long long u = row >> 5;
+        const int tap = (int)(u % ntap_blk); u /= ntap_blk;
+        const int cp = (int)(u % ncp); u /= ncp;
+        const int z = (int)u;                       // = dyg * ncot + cot
+        const int cot = z % ncot, dyg = z / ncot;
+        co = cot * 32 + nn; ci = cp * 32 + m;
+        dy = dyg * tr + tap / ks; dx = tap % ks;
+        const long long base = (((long long)z * ncp + cp) * PB) * ntap_blk + tap;
+        for (int p = ps; p < PB; p += 8) s += partial[(base + (long long)p * ntap_blk) * 1024 + m * 32 + nn];
+    } else {
+        const int cot = (int)(row - nrows);
+        co = cot * 32 + nn;
+        for (int p = ps; p < PB; p += 8) s += partial_b[((long long)cot * PB + p) * 32 + nn];
+    }
+    sm[ps][nn] = s;
+    __syncthreads();
+    if (ps != 0) return;
+    const float tot = ((sm[0][nn] + sm[1][nn]) + (sm[2][nn] + sm[3][nn])) + ((sm[4][nn] + sm[5][nn]) + (sm[6][nn] + sm[7][nn]));
+    if (co >= cout) return;
     int cr = co;
     if (shuffle) { const int cq = cout / 4; cr = (co % cq) * 4 + co / cq; }
+    if (is_bias) {
+        if (db) db[cr] = accumulate ? db[cr] + tot * is : tot * is;
+        return;
+    }
+    if (ci >= cin) return;
     float* o = dw + (((long long)cr * cin + ci) * ks + dy) * ks + dx;
-    *o = accumulate ? *o + s * is : s * is;
+    *o = accumulate ? *o + tot * is : tot * is;
 }
 
 namespace {
@@ -374,10 +381,10 @@ int binhip_conv2d_bwd_weight(const BinConvDesc* d, const void* x_hi, const void*
         else rc = launch_wg<5, 1, 3>(a, g, s);
     }
     if (rc) return rc;
-    const long long total = (long long)g.ndyg * g.ncot * g.ncp * g.ntap * 1024;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.partial,
+    const long long nrows = (long long)g.ndyg * g.ncot * g.ncp * g.ntap * 32;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(nrows + g.ncot)), dim3(256), 0, s, a.partial,
                        a.partial_b, g.PB, g.ncp, g.ncot, d->ksize, g.tr, d->cout, cin, inv_scale, dw_oihw, dbias,
-                       accumulate, shuffle_perm);
+                       accumulate, shuffle_perm, nrows);
     BH_CHECK_LAUNCH();
     return 0;
 }
