@@ -216,6 +216,8 @@ class RDN_residual_interp_5_input_ConvLSTM_L(nn.Module):
         self.hidden_state = None
         self.reuse_schedule = True
         self.precision = None
+        self.n_streams = int(os.environ.get("BIN_AMD_STREAMS", "3"))   # concurrent RDN calls in inference
+        self._streams = None
 
     def set_precision(self, precision):
         if precision is not None and precision not in PRECISIONS:
@@ -231,6 +233,9 @@ class RDN_residual_interp_5_input_ConvLSTM_L(nn.Module):
             if not t.is_cuda:
                 raise RuntimeError("bin_amd: bin_stage4 runs on a HIP device only (no CPU fallback; "
                                    "see oracle/ for the test-only CPU restatement)")
+        if self.n_streams > 1 and self.reuse_schedule and self.modelType == "lstm" and not (
+                torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+            return self._forward_streams((B1, B3, B5, B7, B9, B11))
         cells = (self.clstm_4_prime, self.clstm_6_prime, self.clstm_8_prime, self.clstm_5_prime_prime,
                  self.clstm_7_prime_prime, self.clstm_6_prime_prime_prime)
         picks = (1, 2, 3, 5, 6, 8)
@@ -255,6 +260,86 @@ class RDN_residual_interp_5_input_ConvLSTM_L(nn.Module):
             res.append(out)
         return (res[0][0], res[0][1], res[0][2], res[0][3], res[0][4], res[0][5], res[0][6],
                 res[0][7], res[0][8], res[0][9], res[1][3], res[1][6], res[1][8], res[1][9])
+
+
+def _forward_streams(self, B):
+    """Inference schedule that runs the INDEPENDENT RDN calls of each pyramid stage on separate HIP streams
+    (stage 1: 4 calls, stage 2: 3, stage 3: 2; window 2's only new stage-1 call rides along with window 1's stage 4).
+    Every kernel of one call still runs in order on its stream; calls on different streams overlap, so one call's
+    kernel tail / launch gap / prologue is filled by another call's workgroups.  Same kernels, same arithmetic
+    => bit-identical to the serial schedule (tests/test_gpu_net.py)."""
+    from ...rdn_plan import rdn_forward, workspace
+    from ... import _lib as L
+    dev = B[0].device
+    main = torch.cuda.current_stream(dev)
+    if self._streams is None or len(self._streams) != self.n_streams:
+        self._streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_streams)]
+    streams = self._streams
+    m = self.model
+    mods = {1: m.model1_1, 2: m.model2_1, 3: m.model3_1, 4: m.model4_1}
+    nterms = {k: PRECISIONS[v.precision or default_precision()] for k, v in mods.items()}
+    kw = {k: v.kernel_weights(nterms[k]) for k, v in mods.items()}       # relayouts (if any) on the main stream
+    lib = L.lib()
+    n, _, h, w = B[0].shape
+    ready = {}                                                          # id(tensor) -> event
+
+    def launch(si, fn, ins):
+        s = streams[si % len(streams)]
+        for t in ins:
+            ev = ready.get(id(t))
+            if ev is not None:
+                s.wait_event(ev)
+        with torch.cuda.stream(s):
+            out = fn()
+        for o in (out if isinstance(out, (tuple, list)) else (out,)):
+            e = torch.cuda.Event()
+            e.record(s)
+            ready[id(o)] = e
+        return out
+
+    def rdn(si, k, *ins):
+        ins = [t.contiguous().float() for t in ins]
+        nb = lib.binhip_rdn_workspace_bytes(n, h, w, len(ins), nterms[k])
+
+        def fn():
+            ws = workspace(nb, dev, key=f"fwd-stream{si % len(streams)}")
+            return rdn_forward(kw[k], ins, ws=ws)
+        return launch(si, fn, ins)
+
+    for s in streams:
+        s.wait_stream(main)
+    cells = (self.clstm_4_prime, self.clstm_6_prime, self.clstm_8_prime, self.clstm_5_prime_prime,
+             self.clstm_7_prime_prime, self.clstm_6_prime_prime_prime)
+
+    def cell(si, c, x):
+        return launch(si, lambda: c(x, None)[0], [x])
+
+    B1, B3, B5, B7, B9, B11 = B
+    # ---- window 1
+    I2 = rdn(0, 1, B1, B3); I4 = rdn(1, 1, B3, B5); I6 = rdn(2, 1, B5, B7); I8 = rdn(3, 1, B7, B9)
+    I3 = rdn(0, 2, I2, I2, I4); I5 = rdn(1, 2, I4, I4, I6); I7 = rdn(2, 2, I6, I6, I8)
+    h4 = cell(3, cells[0], I4); h6 = cell(3, cells[1], I6); h8 = cell(3, cells[2], I8)
+    I4pp = rdn(0, 3, I3, B3, I3, I5, B5); I6pp = rdn(1, 3, I5, B5, I5, I7, B7)
+    h5 = cell(2, cells[3], I5); h7 = cell(2, cells[4], I7)
+    I8b = rdn(2, 1, B9, B11)                                            # window 2's only new stage-1 call
+    I5ppp = rdn(0, 4, I4, I4, I4pp, I6pp, I6)
+    h6pp = cell(1, cells[5], I6pp)
+    # ---- window 2 (stage-1 outputs I4, I6, I8 of window 1 are its I2', I4', I6')
+    J3 = rdn(0, 2, h4, I4, I6); J5 = rdn(1, 2, h6, I6, I8); J7 = rdn(2, 2, h8, I8, I8b)
+    J4pp = rdn(0, 3, h5, B5, J3, J5, B7); J6pp = rdn(1, 3, h7, B7, J5, J7, B9)
+    J5ppp = rdn(0, 4, h6pp, I6, J4pp, J6pp, I8)
+    for s in streams:
+        main.wait_stream(s)
+    outs = (I2, I4, I6, I8, I3, I5, I7, I4pp, I6pp, I5ppp, I8b, J7, J6pp, J5ppp)
+    for t in outs + (h4, h6, h8, h5, h7, h6pp, J3, J5, J4pp):
+        for s in streams:
+            t.record_stream(s)
+        t.record_stream(main)
+    self.Ft_p_1 = (I6, I8, I8b, None, J3, J5, J7, J4pp, J6pp, J5ppp)
+    return outs
+
+
+RDN_residual_interp_5_input_ConvLSTM_L._forward_streams = _forward_streams
 
 
 def bin_stage4_lstm():
