@@ -128,51 +128,75 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// All MFMAs of K-stage `st` out of LDS buffer `buf`.
+// Operand fragments of one (chunk, dx) step: R+KS-1 patch rows (B) and the KS x MT weight tiles of this tap column (A).
+template <class C, int KS, int MT, int R, int NT>
+__device__ __forceinline__ void load_frags(const char* bbase, int kc, int dx, int wm, int a_lane_off, int b_lane_p, int kg,
+                                           half8 (&Bh)[R + KS - 1], half8 (&Bl)[R + KS - 1],
+                                           half8 (&Ah)[KS][MT], half8 (&Al)[KS][MT]) {
+    const char* pb = bbase + kc * C::CHUNK_BYTES;
+    const char* wb = pb + C::PP * 1024 + wm * (MT * 32 * 32);
+#pragma unroll
+    for (int rr = 0; rr < R + KS - 1; ++rr) {
+        const int p = b_lane_p + rr * C::PW + dx;
+        const int off = p * 32 + ((kg ^ ((p >> 3) & 1)) << 4);
+        Bh[rr] = lds_ld8(pb + off);
+        if constexpr (NT == 3) Bl[rr] = lds_ld8(pb + C::PLANE_BYTES + off);
+    }
+#pragma unroll
+    for (int dy = 0; dy < KS; ++dy)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int off = ((dy * KS + dx) * C::COUTB + mt * 32) * 32 + a_lane_off;
+            Ah[dy][mt] = lds_ld8(wb + off);
+            if constexpr (NT == 3) Al[dy][mt] = lds_ld8(wb + C::PLANE_BYTES + off);
+        }
+}
+
+// All MFMAs of K-stage `st` out of LDS buffer `buf`, software-pipelined over its KC*KS (chunk, dx) steps: the
+// fragments of step s+1 are fetched into the other register set before the MFMAs of step s issue.  The
+// sched_barriers pin that order — left alone, the scheduler sinks every ds_read next to its MFMA to save registers
+// (it assumes 8 waves/SIMD because the LDS size is dynamic) and the loop degenerates into read -> wait -> MFMA.
 template <class C, int KS, int MT, int R, int KC, int NT>
 __device__ __forceinline__ void compute_stage(const char* smem, int st, int buf, int nchunks, int wm,
                                               int a_lane_off, int b_lane_p, int kg, floatx16 (&acc)[MT][R]) {
     const char* bbase = smem + buf * C::BUF_BYTES;
+    constexpr int NSTEP = KC * KS;
+    // register estimate: accumulators + two fragment sets; fall back to one set (no prefetch) when it would spill
+    constexpr int FRAG_REGS = ((R + KS - 1) + KS * MT) * 4 * ((NT == 3) ? 2 : 1);
+    constexpr bool PIPE = (MT * R * 16 + 2 * FRAG_REGS + 40) <= 232;
+    constexpr int NSET = PIPE ? 2 : 1;
+    half8 Bh[NSET][R + KS - 1], Bl[NSET][R + KS - 1], Ah[NSET][KS][MT], Al[NSET][KS][MT];
+    int nvalid = NSTEP;
+    if constexpr (KC > 1) {
+        const int left = nchunks - st * KC;
+        nvalid = (left < KC ? left : KC) * KS;
+    }
+    if constexpr (PIPE)
+        load_frags<C, KS, MT, R, NT>(bbase, 0, 0, wm, a_lane_off, b_lane_p, kg, Bh[0], Bl[0], Ah[0], Al[0]);
 #pragma unroll
-    for (int kc = 0; kc < KC; ++kc) {
-        const int c = st * KC + kc;
-        if (c < nchunks) {
-            const char* pb = bbase + kc * C::CHUNK_BYTES;
-            const char* wb = pb + C::PP * 1024 + wm * (MT * 32 * 32);
-#pragma unroll
-            for (int dx = 0; dx < KS; ++dx) {
-                half8 Bh[R + KS - 1];
-                half8 Bl[R + KS - 1];
-#pragma unroll
-                for (int rr = 0; rr < R + KS - 1; ++rr) {
-                    const int p = b_lane_p + rr * C::PW + dx;
-                    const int off = p * 32 + ((kg ^ ((p >> 3) & 1)) << 4);
-                    Bh[rr] = lds_ld8(pb + off);
-                    if constexpr (NT == 3) Bl[rr] = lds_ld8(pb + C::PLANE_BYTES + off);
-                }
-#pragma unroll
-                for (int dy = 0; dy < KS; ++dy) {
-                    const int tap = dy * KS + dx;
-                    half8 Ah[MT];
-                    half8 Al[MT];
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        const int off = (tap * C::COUTB + mt * 32) * 32 + a_lane_off;
-                        Ah[mt] = lds_ld8(wb + off);
-                        if constexpr (NT == 3) Al[mt] = lds_ld8(wb + C::PLANE_BYTES + off);
-                    }
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int r = 0; r < R; ++r) {
-                            if constexpr (NT == 3) {
-                                acc[mt][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[mt], Bh[r + dy], acc[mt][r], 0, 0, 0);
-                                acc[mt][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[mt], Bl[r + dy], acc[mt][r], 0, 0, 0);
-                            }
-                            acc[mt][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[mt], Bh[r + dy], acc[mt][r], 0, 0, 0);
-                        }
-                }
+    for (int s = 0; s < NSTEP; ++s) {
+        if (KC == 1 || s < nvalid) {
+            if constexpr (PIPE) {
+                if (s + 1 < NSTEP && (KC == 1 || s + 1 < nvalid))
+                    load_frags<C, KS, MT, R, NT>(bbase, (s + 1) / KS, (s + 1) % KS, wm, a_lane_off, b_lane_p, kg,
+                                                 Bh[(s + 1) & 1], Bl[(s + 1) & 1], Ah[(s + 1) & 1], Al[(s + 1) & 1]);
+            } else {
+                load_frags<C, KS, MT, R, NT>(bbase, s / KS, s % KS, wm, a_lane_off, b_lane_p, kg, Bh[0], Bl[0], Ah[0], Al[0]);
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int dy = 0; dy < KS; ++dy)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        if constexpr (NT == 3) {
+                            acc[mt][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[s & (NSET - 1)][dy][mt], Bh[s & (NSET - 1)][r + dy], acc[mt][r], 0, 0, 0);
+                            acc[mt][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[s & (NSET - 1)][dy][mt], Bl[s & (NSET - 1)][r + dy], acc[mt][r], 0, 0, 0);
+                        }
+                        acc[mt][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[s & (NSET - 1)][dy][mt], Bh[s & (NSET - 1)][r + dy], acc[mt][r], 0, 0, 0);
+                    }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -256,7 +280,7 @@ conv_mfma_kernel(const ConvKArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             if (st + NBUF - 1 < nst)
                 issue_stage<C, KS, KC>(a, smem, st + NBUF - 1, nxt, wave, lane, z, voff, plane_elems, plane_bytes);
-            if (!(a.dbg & 4)) compute_stage<C, KS, MT, R, KC, NT>(smem, st, cur, nchunks, wm, a_lane_off, b_lane_p, kg, acc);
+            compute_stage<C, KS, MT, R, KC, NT>(smem, st, cur, nchunks, wm, a_lane_off, b_lane_p, kg, acc);
             cur = (cur + 1 == NBUF) ? 0 : cur + 1;
             nxt = (nxt + 1 == NBUF) ? 0 : nxt + 1;
         }
@@ -524,6 +548,8 @@ static int bh_dispatch_conv(const ConvKArgs& a0, int k, int cp, int nt, int e, h
                 case 7: return launch_cfg<3, 1, 1, 2, 8, 1, 1, 2, P>(a, cp, s);
                 case 8: return launch_cfg<3, 1, 1, 3, 4, 1, 1, 2, P>(a, cp, s);
                 case 9: return launch_cfg<3, 1, 1, 2, 8, 1, 1, 3, P>(a, cp, s);
+                case 10: return launch_cfg<3, 1, 1, 3, 4, 1, 1, 3, P>(a, cp, s);   // 12x32 tile, depth 3, 73 KB -> 2 wg/CU
+                case 11: return launch_cfg<3, 1, 1, 2, 4, 1, 1, 4, P>(a, cp, s);   // 8x32 tile, depth 4, 81 KB
                 case 0: return launch_cfg<3, 1, 1, 4, 4, 1, 1, 2, P>(a, cp, s);
                 default: return launch_cfg<3, 1, 1, 2, 8, 1, 1, 2, P>(a, cp, s);     // 8 waves x 2 rows, 16x32 tile
             }

@@ -174,34 +174,48 @@ wgrad_mfma_kernel(const WgradKArgs a) {
         if (nxt < a.ntiles) wg_issue<KS, TR, NT>(a, smem, cur ^ 1, nxt, cp, cot, dy0, wave, lane, plane_elems, plane_bytes);
         const char* xb = smem + cur * C::BUF_BYTES;
         const char* gb = xb + 2 * C::XBYTES;
+        // 4 K-steps per wave and tile (2 rows x 2 half-rows of 16 pixels), software-pipelined: the transpose reads of
+        // K-step s+1 are issued before the MFMAs of K-step s (a workgroup is alone on its CU, one wave per SIMD, so
+        // nothing else hides the LDS latency); sched_barriers keep the scheduler from sinking the reads again.
+        half8 Bh[2], Bl[2], Ah[2][C::NTAP], Al[2][C::NTAP];
+        {
+            const int row = wave * 2, x0 = 0;
+            Bh[0] = tr_frag(gb, C::GBYTES, row * 32 + x0, lane);
+            if constexpr (NT == 3) Bl[0] = tr_frag(gb + C::PLANE_BYTES, C::GBYTES, row * 32 + x0, lane);
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int row = wave * 2 + rr;
+            for (int t = 0; t < C::NTAP; ++t) {
+                const int p0 = (row + t / KS) * C::PW + x0 + t % KS;
+                Ah[0][t] = tr_frag(xb, C::XBYTES, p0, lane);
+                if constexpr (NT == 3) Al[0][t] = tr_frag(xb + C::PLANE_BYTES, C::XBYTES, p0, lane);
+            }
+        }
 #pragma unroll
-            for (int xs = 0; xs < 2; ++xs) {
-                const int x0 = xs * 16;
-                const half8 Bh = tr_frag(gb, C::GBYTES, row * 32 + x0, lane);
-                half8 Bl;
-                if constexpr (NT == 3) Bl = tr_frag(gb + C::PLANE_BYTES, C::GBYTES, row * 32 + x0, lane);
-                if (do_bias) {
-                    accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, Bh, accb, 0, 0, 0);
-                    if constexpr (NT == 3) accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, Bl, accb, 0, 0, 0);
-                }
+        for (int s4 = 0; s4 < 4; ++s4) {
+            if (s4 + 1 < 4) {
+                const int row = wave * 2 + ((s4 + 1) >> 1), x0 = ((s4 + 1) & 1) * 16;
+                Bh[(s4 + 1) & 1] = tr_frag(gb, C::GBYTES, row * 32 + x0, lane);
+                if constexpr (NT == 3) Bl[(s4 + 1) & 1] = tr_frag(gb + C::PLANE_BYTES, C::GBYTES, row * 32 + x0, lane);
 #pragma unroll
-                for (int dyl = 0; dyl < TR; ++dyl) {
-#pragma unroll
-                    for (int dx = 0; dx < KS; ++dx) {
-                        const int p0 = (row + dyl) * C::PW + x0 + dx;
-                        const half8 Ah = tr_frag(xb, C::XBYTES, p0, lane);
-                        if constexpr (NT == 3) {
-                            const half8 Al = tr_frag(xb + C::PLANE_BYTES, C::XBYTES, p0, lane);
-                            acc[dyl * KS + dx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, acc[dyl * KS + dx], 0, 0, 0);
-                            acc[dyl * KS + dx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, acc[dyl * KS + dx], 0, 0, 0);
-                        }
-                        acc[dyl * KS + dx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, acc[dyl * KS + dx], 0, 0, 0);
-                    }
+                for (int t = 0; t < C::NTAP; ++t) {
+                    const int p0 = (row + t / KS) * C::PW + x0 + t % KS;
+                    Ah[(s4 + 1) & 1][t] = tr_frag(xb, C::XBYTES, p0, lane);
+                    if constexpr (NT == 3) Al[(s4 + 1) & 1][t] = tr_frag(xb + C::PLANE_BYTES, C::XBYTES, p0, lane);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (do_bias) {
+                accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, Bh[s4 & 1], accb, 0, 0, 0);
+                if constexpr (NT == 3) accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, Bl[s4 & 1], accb, 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < C::NTAP; ++t) {
+                if constexpr (NT == 3) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[s4 & 1][t], Bh[s4 & 1], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[s4 & 1][t], Bl[s4 & 1], acc[t], 0, 0, 0);
+                }
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[s4 & 1][t], Bh[s4 & 1], acc[t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
