@@ -44,6 +44,7 @@ struct ConvKArgs {
     int tiles_x, tiles_y;
     int relu, has_res, nimg, cout;
     int xcd_remap;
+    int och_limit;            // output chunks that exist at the destination (rows beyond are padding: not stored)
     int dbg;                  // ablation switches (timing experiments only): 1 skip weight DMA, 2 skip patch DMA, 4 skip MFMA
     int res_chunks;           // residual r applies to output chunks < res_chunks
     int mask_from;            // mask applies to output chunks >= mask_from (when m_hi != null)
@@ -355,7 +356,7 @@ conv_mfma_kernel(const ConvKArgs a) {
                                 ? (long long)(och / a.y_cpg) * a.y_group_stride + (long long)(och % a.y_cpg) * plane_elems + pix16
                                 : (long long)och * plane_elems + pix16;
                             {
-                                if (a.has_res && och < a.res_chunks) {
+                                if (a.has_res && och < a.res_chunks && och < a.och_limit) {
                                     const half4 rh = *reinterpret_cast<const half4*>(a.r_hi + o);
 #pragma unroll
                                     for (int j = 0; j < 4; ++j) v[j] += (float)rh[j];
@@ -365,7 +366,7 @@ conv_mfma_kernel(const ConvKArgs a) {
                                         for (int j = 0; j < 4; ++j) v[j] += (float)rl[j];
                                     }
                                 }
-                                if (a.r2_hi) {
+                                if (a.r2_hi && och < a.och_limit) {
                                     const half4 rh = *reinterpret_cast<const half4*>(a.r2_hi + o);
 #pragma unroll
                                     for (int j = 0; j < 4; ++j) v[j] += (float)rh[j];
@@ -380,7 +381,7 @@ conv_mfma_kernel(const ConvKArgs a) {
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
                             }
-                            if (a.m_hi && och >= a.mask_from) {
+                            if (a.m_hi && och >= a.mask_from && och < a.och_limit) {
                                 const half4 mh = *reinterpret_cast<const half4*>(a.m_hi + o);
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) v[j] = ((float)mh[j] > 0.f) ? v[j] : 0.f;
@@ -405,7 +406,7 @@ conv_mfma_kernel(const ConvKArgs a) {
                             lv[0].u[k] = sl[0]; lv[1].u[k] = sl[1];
                         }
                     }
-                    if (ok) {
+                    if (ok && ((z * C::COUTB + (wm * MT + mt) * 32 + 16 * gp) >> 4) < a.och_limit) {
                         *reinterpret_cast<uint4*>(a.y_hi + o_slot) = make_uint4(hv[0].u[0], hv[0].u[1], hv[1].u[0], hv[1].u[1]);
                         if constexpr (NT == 3)
                             *reinterpret_cast<uint4*>(a.y_lo + o_slot) = make_uint4(lv[0].u[0], lv[0].u[1], lv[1].u[0], lv[1].u[1]);
@@ -485,6 +486,7 @@ int bh_launch_conv(const BhConvCall& c, hipStream_t s) {
     a.nchunks = d.cin_chunks;
     a.cpg = d.x_cpg;
     a.relu = d.relu; a.has_res = (c.r_hi != nullptr); a.nimg = d.n_images; a.cout = d.cout;
+    a.och_limit = (d.epilogue == BINHIP_EPI_PLANES) ? (d.cout + 15) / 16 : (1 << 30);
     a.tiles_x = a.tiles_y = 0;
     a.xcd_remap = 0;
     a.dbg = 0;
@@ -673,6 +675,14 @@ __global__ void relayout_dgrad_kernel(const float* __restrict__ w, int cout, int
 }
 
 extern "C" {
+
+int binhip_dgrad_rows_pad(int ksize, int cin) {
+    // rows of the backward-data conv = original input channels, padded to the kernel's cout granularity.  The LFF
+    // dgrad (224 rows) is padded to 288 = 3 x 96 so it runs 3 wide workgroup columns instead of 7 narrow ones
+    // (its input, the 96-channel output gradient, is re-read once per column).
+    if (ksize == 1 && cin == 224) return 288;
+    return ((cin + 31) / 32) * 32;
+}
 
 int binhip_weights_relayout_dgrad(const float* w_oihw, int cout, int cin, int ksize, int rows_pad, int cin_chunks,
                                   int cout_block, int shuffle_perm, void* w_hi, void* w_lo, float* bias_out,

@@ -248,7 +248,7 @@ int binhip_rdn_backward(const BinRdnBwdPlan* p, const void* saved, size_t saved_
                      int64_t m_off, int mask_from, int y_cpg, int64_t y_gstride) -> int {
         BhConvCall c;
         c.d.N = N; c.d.H = Hc; c.d.W = Wc; c.d.ksize = ks; c.d.cin_chunks = gin_chunks; c.d.cout = gout_ch;
-        c.d.cout_pad = ((gout_ch + 31) / 32) * 32; c.d.nterms = nt; c.d.epilogue = BINHIP_EPI_PLANES; c.d.relu = 0;
+        c.d.cout_pad = binhip_dgrad_rows_pad(ks, gout_ch); c.d.nterms = nt; c.d.epilogue = BINHIP_EPI_PLANES; c.d.relu = 0;
         c.d.x_cpg = 0; c.d.x_group_stride = 0; c.d.n_images = 0; c.d.reserved = 0;
         c.x_hi = GH(g_off); c.x_lo = GL(g_off, g_size);
         c.w_hi = p->wt_hi[layer]; c.w_lo = p->wt_lo[layer]; c.bias = p->zero_bias;

@@ -186,7 +186,7 @@ class DgradWeights:
         lib = L.lib()
         self.ks, self.nterms = ks, nterms
         self.cout = cin                                   # the dgrad conv's outputs = original inputs
-        self.cout_pad = ((cin + 31) // 32) * 32
+        self.cout_pad = lib.binhip_dgrad_rows_pad(ks, cin)
         self.cin_chunks = chunks(cout)
         cb = lib.binhip_conv_cout_block(ks, self.cout_pad, nterms)
         nbytes = lib.binhip_weights_bytes(self.cout_pad, self.cin_chunks, ks)
@@ -208,7 +208,7 @@ def conv2d_bwd_data(gy, dw, res=None, res_chunks=0, acc=None, mask=None, mask_fr
     d.cin_chunks, d.cout, d.cout_pad, d.nterms = dw.cin_chunks, dw.cout, dw.cout_pad, dw.nterms
     d.epilogue, d.relu, d.x_cpg, d.x_group_stride, d.n_images = L.EPI_PLANES, 0, 0, 0, 0
     if out is None:
-        out = CP.empty(dw.cout_pad // 16, n, h, w, dw.nterms, gy.hi.device, dw.cout)
+        out = CP.empty(chunks(dw.cout), n, h, w, dw.nterms, gy.hi.device, dw.cout)
     z = C.c_void_p(0)
     rc = L.lib().binhip_conv2d_bwd_data(
         C.byref(d), _ptr(gy.hi), _ptr(gy.lo), _ptr(dw.w_hi), _ptr(dw.w_lo), _ptr(dw.bias),

@@ -62,7 +62,7 @@ class RdnDgradWeights:
             w = params[f"{prefix}{nm}.weight"].detach().contiguous().float()
             dev = w.device
             cout, cin, ks, _ = w.shape
-            rows_pad = ((cin + 31) // 32) * 32
+            rows_pad = lib.binhip_dgrad_rows_pad(ks, cin)
             cin_chunks = (cout + 15) // 16
             cb = lib.binhip_conv_cout_block(ks, rows_pad, nterms)
             nbytes = lib.binhip_weights_bytes(rows_pad, cin_chunks, ks)

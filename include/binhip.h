@@ -92,6 +92,7 @@ int binhip_conv2d_fwd(const BinConvDesc* d,
  *   mask  — saved forward activation planes: output chunks >= mask_from are zeroed where it is <= 0
  *           (ReLU backward, RDN.py:142), applied when the last contribution to that chunk lands
  *   y_cpg / y_group_stride — output chunk grouping (GFF.0 dgrad scatters to the 12 block buffers)     */
+int binhip_dgrad_rows_pad(int ksize, int cin);   /* rows_pad the library expects for a layer's dgrad weights */
 int binhip_weights_relayout_dgrad(const float* w_oihw, int cout, int cin, int ksize, int rows_pad,
                                   int cin_chunks, int cout_block, int shuffle_perm, void* w_hi, void* w_lo,
                                   float* bias_out, void* stream);
