@@ -61,6 +61,7 @@ _SIGNATURES = {
     "binhip_conv2d_bwd_data": (C.c_int, [C.POINTER(BinConvDesc)] + [C.c_void_p] * 7 + [C.c_int, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p,
                                          C.c_void_p, C.c_void_p]),
+    "binhip_wgrad_set_debug": (C.c_int, [C.c_int]),
     "binhip_wgrad_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
     "binhip_conv2d_bwd_weight": (C.c_int, [C.POINTER(BinConvDesc)] + [C.c_void_p] * 6 + [C.c_size_t, C.c_void_p,
                                            C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

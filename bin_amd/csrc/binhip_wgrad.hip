@@ -35,6 +35,7 @@ struct WgradKArgs {
     int cin_chunks, cout_chunks;
     int tiles_x, tiles_y, ntiles;
     int PB, ncp, ncot;
+    int dbg;      // ablation (timing experiments): 1 skip DMA, 2 skip MFMA/LDS reads, 4 skip the final reduction+store
 };
 
 template <int KS, int TR, int NT>
@@ -165,13 +166,14 @@ wgrad_mfma_kernel(const WgradKArgs a) {
     for (int e = 0; e < 8; ++e) ones[e] = (_Float16)1.0f;
 
     int tile = pb;
-    if (tile < a.ntiles) wg_issue<KS, TR, NT>(a, smem, 0, tile, cp, cot, dy0, wave, lane, plane_elems, plane_bytes);
+    if (tile < a.ntiles && !(a.dbg & 1)) wg_issue<KS, TR, NT>(a, smem, 0, tile, cp, cot, dy0, wave, lane, plane_elems, plane_bytes);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
     for (; tile < a.ntiles; tile += a.PB) {
         const int nxt = tile + a.PB;
-        if (nxt < a.ntiles) wg_issue<KS, TR, NT>(a, smem, cur ^ 1, nxt, cp, cot, dy0, wave, lane, plane_elems, plane_bytes);
+        if (nxt < a.ntiles && !(a.dbg & 1)) wg_issue<KS, TR, NT>(a, smem, cur ^ 1, nxt, cp, cot, dy0, wave, lane, plane_elems, plane_bytes);
+        if (a.dbg & 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); cur ^= 1; continue; }
         const char* xb = smem + cur * C::BUF_BYTES;
         const char* gb = xb + 2 * C::XBYTES;
         // 4 K-steps per wave and tile (2 rows x 2 half-rows of 16 pixels), software-pipelined: the transpose reads of
@@ -222,6 +224,7 @@ wgrad_mfma_kernel(const WgradKArgs a) {
         cur ^= 1;
     }
 
+    if (a.dbg & 4) { if (acc[0][0] == 12345.f) a.partial[0] = accb[0]; return; }
     // ---- reduce the 4 waves through LDS, one partial per block ----------------------------------
     float* red = reinterpret_cast<float*>(smem);          // [4 waves][32 m][32 n]
     const int n = lane & 31, hi = lane >> 5;
@@ -250,6 +253,211 @@ wgrad_mfma_kernel(const WgradKArgs a) {
         if (tid < 32)
             a.partial_b[((long long)cot * a.PB + pb) * 32 + tid] =
                 (red[tid] + red[32 + tid]) + (red[64 + tid] + red[96 + tid]);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// 1x1 convolutions (LFF 224->96, GFF.0 1152->96): with a single tap the whole [NCPB x 32 ci] x [96 co] gradient tile
+// fits in registers (NCPB*3 accumulators), so one workgroup keeps ALL three output tiles and NCPB = 4 input-channel
+// pairs: X and gY are each streamed through LDS exactly once (the generic kernel re-reads X per output tile and gY
+// per channel pair: 705 MB instead of 168 MB for LFF at 8x128x128).  Pixel tile 4 x 32, wave w owns row w.
+constexpr int W1_NCPB = 4, W1_NCOT = 3, W1_TH = 4;   // 12 accumulator tiles = 192 registers
+
+template <int NT>
+struct W1Cfg {
+    static constexpr int NPL = (NT == 3) ? 2 : 1;
+    static constexpr int CH_BYTES = W1_TH * 32 * 32;                 // one chunk tile: 4 KiB
+    static constexpr int G_BYTES = NPL * 2 * W1_NCOT * CH_BYTES;     // gY tile, 6 chunks per plane
+    static constexpr int X_BYTES = NPL * 2 * CH_BYTES;               // one channel pair of X
+    static constexpr int LDS_BYTES = 2 * G_BYTES + 2 * X_BYTES;      // both double buffered
+    static_assert(LDS_BYTES >= 16384 && LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+template <int NT>
+__device__ __forceinline__ void w1_issue_chunk(const _Float16* base, long long off, bool have, unsigned plane_bytes, char* lds,
+                                               int img, int ty0, int tx0, int H, int W, int wave, int lane) {
+    // one 4 x 32 pixel chunk tile = 4 KiB = 4 DMA pieces, one per wave
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(have ? base + off : base), 0,
+                                                                  have ? plane_bytes : 0u, 0x00020000);
+    const int q = wave * 64 + lane;
+    const int p = q >> 1, s = q & 1;
+    const int gy = ty0 + (p >> 5), gx = tx0 + (p & 31);
+    const int cg = s ^ ((p >> 3) & 1);
+    const bool ok = gy < H && gx < W;
+    const unsigned vo = ok ? (unsigned)((((long long)img * H + gy) * W + gx) * 32 + cg * 16) : 0x80000000u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(lds + wave * 1024), 16, vo, 0, 0, 0);
+}
+
+template <int NT>
+__global__ void __launch_bounds__(256)
+wgrad1x1_kernel(const WgradKArgs a) {
+    using C = W1Cfg<NT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pb = blockIdx.x;
+    const int cpg = blockIdx.y;                   // group of W1_NCPB channel pairs
+    const int cp0 = cpg * W1_NCPB;
+    const long long plane_elems = (long long)a.N * a.H * a.W * 16;
+    const unsigned plane_bytes = (unsigned)(plane_elems * 2);
+    const bool do_bias = (cpg == 0);
+    char* gbuf = smem;                            // [2][NPL][6 chunks][4 KiB]
+    char* xbuf = smem + 2 * C::G_BYTES;           // [2][NPL][2 chunks][4 KiB]
+
+    floatx16 acc[W1_NCPB][W1_NCOT];
+    float bsum[W1_NCOT] = {0.f, 0.f, 0.f};   // bias: per-lane sum of this lane's gY fragment elements (co = lane & 31)
+#pragma unroll
+    for (int i = 0; i < W1_NCPB; ++i)
+#pragma unroll
+        for (int j = 0; j < W1_NCOT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // issue helpers are inlined by hand (no lambdas in kernels): gY tile of `tile` into g-buffer gb, X pair cp into x-buffer xb
+#define W1_TILE_COORDS(tile_)                                   \
+    int b_ = (tile_);                                           \
+    const int tx_ = b_ % a.tiles_x; b_ /= a.tiles_x;            \
+    const int ty_ = b_ % a.tiles_y;                             \
+    const int img_ = b_ / a.tiles_y;                            \
+    const int tx0_ = tx_ * 32, ty0_ = ty_ * W1_TH;
+#define W1_ISSUE_G(tile_, gb_)                                                                                         \
+    {                                                                                                                  \
+        W1_TILE_COORDS(tile_)                                                                                          \
+        _Pragma("unroll") for (int pl = 0; pl < C::NPL; ++pl)                                                          \
+        _Pragma("unroll") for (int c6 = 0; c6 < 2 * W1_NCOT; ++c6)                                                     \
+            w1_issue_chunk<NT>(pl ? a.g_lo : a.g_hi, (long long)c6 * plane_elems, c6 < a.cout_chunks, plane_bytes,     \
+                               gbuf + (gb_) * C::G_BYTES + (pl * 2 * W1_NCOT + c6) * C::CH_BYTES, img_, ty0_, tx0_,    \
+                               a.H, a.W, wave, lane);                                                                  \
+    }
+#define W1_ISSUE_X(tile_, cp_, xb_)                                                                                    \
+    {                                                                                                                  \
+        W1_TILE_COORDS(tile_)                                                                                          \
+        _Pragma("unroll") for (int pl = 0; pl < C::NPL; ++pl)                                                          \
+        _Pragma("unroll") for (int hh = 0; hh < 2; ++hh) {                                                             \
+            const int c = 2 * (cp_) + hh;                                                                              \
+            const long long coff = (a.x_cpg > 0)                                                                       \
+                ? (long long)(c / a.x_cpg) * a.x_group_stride + (long long)(c % a.x_cpg) * plane_elems                 \
+                : (long long)c * plane_elems;                                                                          \
+            w1_issue_chunk<NT>(pl ? a.x_lo : a.x_hi, coff, c < a.cin_chunks, plane_bytes,                              \
+                               xbuf + (xb_) * C::X_BYTES + (pl * 2 + hh) * C::CH_BYTES, img_, ty0_, tx0_, a.H, a.W,    \
+                               wave, lane);                                                                            \
+        }                                                                                                              \
+    }
+
+    int tile = pb;
+    int gb = 0, xb = 0;
+    if (tile < a.ntiles && !(a.dbg & 1)) {
+        W1_ISSUE_G(tile, 0)
+        W1_ISSUE_X(tile, cp0, 0)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (; tile < a.ntiles; tile += a.PB) {
+        const int nxt_tile = tile + a.PB;
+        half8 Bh[2][W1_NCOT], Bl[2][W1_NCOT];
+        if (!(a.dbg & 2)) {
+            const char* gbase = gbuf + gb * C::G_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < W1_NCOT; ++j) {
+                    Bh[ks][j] = tr_frag(gbase + j * 2 * C::CH_BYTES, C::CH_BYTES, wave * 32 + ks * 16, lane);
+                    if constexpr (NT == 3)
+                        Bl[ks][j] = tr_frag(gbase + (2 * W1_NCOT + j * 2) * C::CH_BYTES, C::CH_BYTES, wave * 32 + ks * 16, lane);
+                }
+            if (do_bias) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int j = 0; j < W1_NCOT; ++j) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            bsum[j] += (float)Bh[ks][j][e];
+                            if constexpr (NT == 3) bsum[j] += (float)Bl[ks][j][e];
+                        }
+                    }
+            }
+        }
+#pragma unroll
+        for (int cpl = 0; cpl < W1_NCPB; ++cpl) {
+            // prefetch: next channel pair of this tile, or the next tile's gY + first pair
+            if (!(a.dbg & 1)) {
+                if (cpl + 1 < W1_NCPB) {
+                    if (cp0 + cpl + 1 < a.ncp) W1_ISSUE_X(tile, cp0 + cpl + 1, xb ^ 1)
+                } else if (nxt_tile < a.ntiles) {
+                    W1_ISSUE_G(nxt_tile, gb ^ 1)
+                    W1_ISSUE_X(nxt_tile, cp0, xb ^ 1)
+                }
+            }
+            if (cp0 + cpl < a.ncp && !(a.dbg & 2)) {
+                const char* xbase = xbuf + xb * C::X_BYTES;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const half8 Ah = tr_frag(xbase, C::CH_BYTES, wave * 32 + ks * 16, lane);
+                    half8 Al;
+                    if constexpr (NT == 3) Al = tr_frag(xbase + 2 * C::CH_BYTES, C::CH_BYTES, wave * 32 + ks * 16, lane);
+#pragma unroll
+                    for (int j = 0; j < W1_NCOT; ++j) {
+                        if constexpr (NT == 3) {
+                            acc[cpl][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh[ks][j], acc[cpl][j], 0, 0, 0);
+                            acc[cpl][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl[ks][j], acc[cpl][j], 0, 0, 0);
+                        }
+                        acc[cpl][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh[ks][j], acc[cpl][j], 0, 0, 0);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            xb ^= 1;
+        }
+        gb ^= 1;
+    }
+#undef W1_ISSUE_G
+#undef W1_ISSUE_X
+#undef W1_TILE_COORDS
+
+    if (a.dbg & 4) { if (acc[0][0][0] == 12345.f) a.partial[0] = bsum[0]; return; }
+    // ---- reduce the 4 waves through LDS; partial layout identical to the generic kernel (ntap = 1, z = co tile)
+    float* red = reinterpret_cast<float*>(smem);
+    const int n = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int cpl = 0; cpl < W1_NCPB; ++cpl) {
+        const bool cp_valid = cp0 + cpl < a.ncp;          // block-uniform
+#pragma unroll
+        for (int j = 0; j < W1_NCOT; ++j) {
+            if (!cp_valid) continue;
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = (e & 3) + 8 * (e >> 2) + 4 * hi;
+                red[wave * 1024 + m * 32 + n] = acc[cpl][j][e];
+            }
+            __syncthreads();
+            if (j < a.ncot) {
+                const long long blk = ((long long)j * a.ncp + (cp0 + cpl)) * a.PB + pb;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int idx = tid + 256 * i;
+                    a.partial[blk * 1024 + idx] = (red[idx] + red[1024 + idx]) + (red[2048 + idx] + red[3072 + idx]);
+                }
+            }
+        }
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int j = 0; j < W1_NCOT; ++j) {
+            __syncthreads();
+            red[tid] = bsum[j];                       // [wave][kg][co]
+            __syncthreads();
+            if (tid < 32 && j < a.ncot) {
+                float t = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t += red[k * 32 + tid];
+                a.partial_b[((long long)j * a.PB + pb) * 32 + tid] = t;
+            }
+        }
     }
 }
 
@@ -304,8 +512,26 @@ namespace {
 
 struct WgGeom { int ncp, ncot, ndyg, tr, ntap, tiles_x, tiles_y, ntiles, PB; size_t partial_floats, bias_floats; };
 
+bool use_w1(int ksize, int cout) { return ksize == 1 && cout <= 32 * W1_NCOT; }
+
 WgGeom wg_geom(int ksize, int N, int H, int W, int cin_chunks, int cout, int cus) {
     WgGeom g;
+    if (use_w1(ksize, cout)) {
+        g.tr = 1; g.ndyg = 1; g.ntap = 1;
+        g.ncp = (cin_chunks + 1) / 2;
+        g.ncot = (cout + 31) / 32;
+        g.tiles_x = (W + 31) / 32;
+        g.tiles_y = (H + W1_TH - 1) / W1_TH;
+        g.ntiles = g.tiles_x * g.tiles_y * N;
+        const int cgroups = (g.ncp + W1_NCPB - 1) / W1_NCPB;
+        int pb = (cus > 0 ? cus : 256) / cgroups;
+        if (pb < 1) pb = 1;
+        if (pb > g.ntiles) pb = g.ntiles;
+        g.PB = pb;
+        g.partial_floats = (size_t)g.ncp * g.ncot * pb * 1024;
+        g.bias_floats = (size_t)g.ncot * pb * 32;
+        return g;
+    }
     g.tr = (ksize == 5) ? 1 : ksize;
     g.ndyg = ksize / g.tr;
     g.ntap = g.tr * ksize;
@@ -315,7 +541,7 @@ WgGeom wg_geom(int ksize, int N, int H, int W, int cin_chunks, int cout, int cus
     g.tiles_y = (H + 7) / 8;
     g.ntiles = g.tiles_x * g.tiles_y * N;
     const int groups = g.ncp * g.ncot * g.ndyg;
-    int pb = (2 * (cus > 0 ? cus : 256) + groups - 1) / groups;
+    int pb = (2 * (cus > 0 ? cus : 256)) / groups;     // floor: never one straggler workgroup in an extra round
     if (pb < 1) pb = 1;
     if (pb > g.ntiles) pb = g.ntiles;
     g.PB = pb;
@@ -340,6 +566,7 @@ int launch_wg(const WgradKArgs& a, const WgGeom& g, hipStream_t s) {
     return 0;
 }
 
+int g_wg_dbg = 0;
 int g_cus = 0;
 int cus() {
     if (g_cus == 0) {
@@ -352,6 +579,8 @@ int cus() {
 }  // namespace
 
 extern "C" {
+
+int binhip_wgrad_set_debug(int flags) { g_wg_dbg = flags; return 0; }
 
 size_t binhip_wgrad_workspace_bytes(int ksize, int N, int H, int W, int cin_chunks, int cout) {
     if (N <= 0 || H <= 0 || W <= 0 || cin_chunks <= 0 || cout <= 0) return 0;
@@ -383,9 +612,24 @@ int binhip_conv2d_bwd_weight(const BinConvDesc* d, const void* x_hi, const void*
     a.cin_chunks = d->cin_chunks; a.cout_chunks = (d->cout + 15) / 16;
     a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.ntiles = g.ntiles;
     a.PB = g.PB; a.ncp = g.ncp; a.ncot = g.ncot;
+    a.dbg = g_wg_dbg;
     hipStream_t s = (hipStream_t)stream;
     int rc = BINHIP_E_SHAPE;
-    if (d->nterms == 1) {
+    if (use_w1(d->ksize, d->cout)) {
+        const int cgroups = (g.ncp + W1_NCPB - 1) / W1_NCPB;
+        dim3 grid((unsigned)g.PB, (unsigned)cgroups);
+        if (d->nterms == 1) {
+            static bool set1 = false;
+            if (!set1) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad1x1_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, W1Cfg<1>::LDS_BYTES); set1 = true; }
+            wgrad1x1_kernel<1><<<grid, dim3(256), W1Cfg<1>::LDS_BYTES, s>>>(a);
+        } else {
+            static bool set3 = false;
+            if (!set3) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad1x1_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, W1Cfg<3>::LDS_BYTES); set3 = true; }
+            wgrad1x1_kernel<3><<<grid, dim3(256), W1Cfg<3>::LDS_BYTES, s>>>(a);
+        }
+        BH_CHECK_LAUNCH();
+        rc = 0;
+    } else if (d->nterms == 1) {
         if (d->ksize == 3) rc = launch_wg<3, 3, 1>(a, g, s);
         else if (d->ksize == 1) rc = launch_wg<1, 1, 1>(a, g, s);
         else rc = launch_wg<5, 1, 1>(a, g, s);

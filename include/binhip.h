@@ -167,6 +167,7 @@ int binhip_rdn_forward(const BinRdnPlan* plan, const float* const* inputs /* hos
  * (N,H,W, ksize, cin_chunks, cout, nterms, x_cpg/x_group_stride).  The result is multiplied by
  * inv_scale[0] (device scalar, may be NULL) and written (or added, accumulate != 0) to OIHW fp32.
  * shuffle_perm != 0: gY's channels are in UPNet.0's PixelShuffle-permuted order.                      */
+int binhip_wgrad_set_debug(int flags);   /* ablation switches for timing experiments (results invalid when != 0) */
 size_t binhip_wgrad_workspace_bytes(int ksize, int N, int H, int W, int cin_chunks, int cout);
 int binhip_conv2d_bwd_weight(const BinConvDesc* d, const void* x_hi, const void* x_lo,
                              const void* gy_hi, const void* gy_lo, const float* inv_scale,

@@ -117,6 +117,19 @@ def main():
     lib.binhip_set_tail_depth(0)
     us = time_fn(unfused)
     print(f"unfused conv3 ; LFF:          {us:8.1f} us")
+    if os.environ.get("WGRAD"):
+        # weight-gradient kernels at the training working size (8 x 128 x 128 half-res pixels)
+        nn_, hh_, ww_ = 8, 128, 128
+        gg = torch.Generator().manual_seed(1)
+        for (ks, cin, cout) in ((3, 96, 32), (3, 192, 32), (1, 224, 96), (3, 96, 96), (1, 1152, 96)):
+            xx = ops.nchw_to_planes(torch.rand(nn_, cin, hh_, ww_, generator=gg).to(dev), nt)
+            gy = ops.nchw_to_planes(torch.rand(nn_, cout, hh_, ww_, generator=gg).to(dev) - 0.5, nt)
+            f = (lambda xx=xx, gy=gy, ks=ks, cin=cin, cout=cout: ops.conv2d_bwd_weight(xx, gy, cout, cin, ks, nt))
+            for dbg, nm in ((0, "full"), (1, "no DMA"), (2, "no MFMA"), (4, "no reduce/store"), (7, "nothing")):
+                lib.binhip_wgrad_set_debug(dbg)
+                us = time_fn(f, iters=10, warm=2)
+                print(f"wgrad k{ks} {cin}->{cout} nt={nt} {nm:16s}: {us:8.1f} us   {2*ks*ks*cin*cout*nn_*hh_*ww_*(3 if nt==3 else 1)/us/1e6:7.0f} TF-eq/s")
+            lib.binhip_wgrad_set_debug(0)
     if os.environ.get("ABLATE"):
         for cin in (96, 192):
             cw = wts(32, cin, 3)
