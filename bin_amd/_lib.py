@@ -48,6 +48,10 @@ _SIGNATURES = {
                                         C.c_void_p]),
     "binhip_pack_inputs": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
+    "binhip_u8_to_frame": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                     C.c_void_p]),
+    "binhip_frame_to_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                     C.c_void_p]),
     "binhip_convlstm_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                                           C.c_void_p, C.c_void_p]),
     "binhip_charbonnier_partials": (C.c_int, [C.c_int64]),

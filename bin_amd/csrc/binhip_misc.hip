@@ -86,6 +86,31 @@ __global__ void pack_inputs_kernel(PackArgs a, _Float16* __restrict__ y_hi, _Flo
     if (y_lo) *reinterpret_cast<half8*>(y_lo + t * 8) = lv;
 }
 
+// ---- harness glue: the per-frame host work of test.py moved onto the device -----------------
+// u8 HWC BGR image -> fp32 CHW RGB in [0,1] (read_image, test.py:44-56) + ReplicationPad2d (test.py:348-371)
+__global__ void u8_to_frame_kernel(const unsigned char* __restrict__ img, int H, int W, int pl, int pt, int Hp, int Wp,
+                                   float* __restrict__ out) {
+    const long long total = (long long)3 * Hp * Wp;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int x = (int)(t % Wp), y = (int)((t / Wp) % Hp), c = (int)(t / ((long long)Wp * Hp));
+    int sy = y - pt, sx = x - pl;
+    sy = sy < 0 ? 0 : (sy >= H ? H - 1 : sy);
+    sx = sx < 0 ? 0 : (sx >= W ? W - 1 : sx);
+    out[t] = (float)img[((long long)sy * W + sx) * 3 + (2 - c)] / 255.f;
+}
+// fp32 CHW RGB -> cropped u8 HWC BGR: clamp [0,1], x255, round-half-even (utils/util.py:113-137), crop (test.py:394-402)
+__global__ void frame_to_u8_kernel(const float* __restrict__ x, int Hp, int Wp, int top, int left, int H, int W,
+                                   unsigned char* __restrict__ out) {
+    const long long total = (long long)H * W * 3;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int c = (int)(t % 3), xx = (int)((t / 3) % W), yy = (int)(t / (3LL * W));
+    float v = x[((long long)(2 - c) * Hp + (yy + top)) * Wp + (xx + left)];
+    v = fminf(fmaxf(v, 0.f), 1.f);
+    out[t] = (unsigned char)rintf(v * 255.0f);
+}
+
 // ---- ConvLSTM cell ------------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
 
@@ -492,6 +517,29 @@ int binhip_charbonnier_bwd(const float* x, const float* y, int64_t numel, float 
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(charb_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, y,
                        (long long)numel, eps, gloss, gx, gy);
+    BH_CHECK_LAUNCH();
+    return 0;
+}
+
+int binhip_u8_to_frame(const unsigned char* bgr_hwc, int H, int W, int pad_left, int pad_right, int pad_top,
+                       int pad_bottom, float* out_chw, void* stream) {
+    if (!bgr_hwc || !out_chw) return BINHIP_E_ARG;
+    if (H <= 0 || W <= 0 || pad_left < 0 || pad_right < 0 || pad_top < 0 || pad_bottom < 0) return BINHIP_E_SHAPE;
+    const int Hp = H + pad_top + pad_bottom, Wp = W + pad_left + pad_right;
+    const long long total = (long long)3 * Hp * Wp;
+    hipLaunchKernelGGL(u8_to_frame_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, bgr_hwc, H,
+                       W, pad_left, pad_top, Hp, Wp, out_chw);
+    BH_CHECK_LAUNCH();
+    return 0;
+}
+
+int binhip_frame_to_u8(const float* chw, int Hp, int Wp, int top, int left, int H, int W, unsigned char* bgr_hwc,
+                       void* stream) {
+    if (!chw || !bgr_hwc) return BINHIP_E_ARG;
+    if (H <= 0 || W <= 0 || top < 0 || left < 0 || top + H > Hp || left + W > Wp) return BINHIP_E_SHAPE;
+    const long long total = (long long)H * W * 3;
+    hipLaunchKernelGGL(frame_to_u8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, chw, Hp, Wp,
+                       top, left, H, W, bgr_hwc);
     BH_CHECK_LAUNCH();
     return 0;
 }

@@ -22,21 +22,36 @@ def window_frame_ids(index, n_frames):
 
 @torch.no_grad()
 def interpolate_clip(netG, clip, rank=0, world=1):
-    """Run the test.py inner loop over `clip` ([T,3,H,W] fp32 in [0,1], any device) for this rank's share
-    of the T-1 windows.  Returns {window index: (interp, deblur_first, deblur_second)} as cropped HWC BGR
-    uint8 images (what test.py writes with cv2.imwrite), all computed on `netG`'s device."""
-    T, _, h, w = clip.shape
+    """Run the test.py inner loop over a clip for this rank's share of its T-1 windows.
+    `clip`: [T,H,W,3] uint8 BGR (what cv2.imread yields; decoded, padded and re-encoded ON THE DEVICE by the
+    u8_to_frame / frame_to_u8 kernels, each padded frame cached because 5 of a window's 6 frames recur in the
+    next window) or [T,3,H,W] fp32 RGB in [0,1].  Returns {window index: (interp, deblur_first, deblur_second)}
+    as cropped HWC BGR uint8 images — what test.py writes with cv2.imwrite (test.py:380-402)."""
+    from . import ops
     dev = next(netG.parameters()).device
+    is_u8 = clip.dtype == torch.uint8
+    if is_u8:
+        T, h, w, _ = clip.shape
+    else:
+        T, _, h, w = clip.shape
     pads = util.pad_sizes(h, w)
     l, r, t, b = pads
     begin, end = shard_windows(T - 1, rank, world)
+    cache = {}
+
+    def frame(i):
+        if i not in cache:
+            if is_u8:
+                cache[i] = ops.u8_to_frame(clip[i].to(dev), pads)
+            else:
+                cache[i] = util.replicate_pad(clip[i:i + 1].to(dev), pads)
+        return cache[i]
+
     out = {}
     for index in range(begin, end):
         ids = window_frame_ids(index, T)
-        frames = [util.replicate_pad(clip[i:i + 1].to(dev), pads) for i in ids]
-        Ft_p = netG(*frames)
-        imgs = []
-        for k in (13, 8, 12):
-            imgs.append(util.tensor2img(Ft_p[k][0])[t:t + h, l:l + w, :])
-        out[index] = tuple(imgs)
+        for k in [k for k in cache if k < min(ids)]:
+            del cache[k]
+        Ft_p = netG(*[frame(i) for i in ids])
+        out[index] = tuple(ops.frame_to_u8(Ft_p[k], t, l, h, w).cpu().numpy() for k in (13, 8, 12))
     return out

@@ -235,3 +235,25 @@ def conv2d_bwd_weight(x, gy, cout, cin, ks, nterms, inv_scale=None, shuffle=Fals
                                          _ptr(inv_scale), _ptr(ws), ws.numel(), _ptr(dw), _ptr(db), cin,
                                          1 if shuffle else 0, 0, _stream()), "conv2d_bwd_weight")
     return dw, db
+
+
+# --------------------------------------------------------------------------------------------- harness glue (N1)
+def u8_to_frame(img_u8, pads):
+    """HWC BGR uint8 device tensor -> padded fp32 [1,3,Hp,Wp] RGB frame (read_image + ReplicationPad2d)."""
+    _need_cuda(img_u8)
+    assert img_u8.dtype == torch.uint8 and img_u8.dim() == 3 and img_u8.shape[2] == 3
+    img_u8 = img_u8.contiguous()
+    h, w, _ = img_u8.shape
+    l, r, t, b = pads
+    out = torch.empty((1, 3, h + t + b, w + l + r), dtype=torch.float32, device=img_u8.device)
+    L.check(L.lib().binhip_u8_to_frame(_ptr(img_u8), h, w, l, r, t, b, _ptr(out), _stream()), "u8_to_frame")
+    return out
+
+
+def frame_to_u8(frame, top, left, h, w):
+    """fp32 [1,3,Hp,Wp] (or [3,Hp,Wp]) RGB -> cropped HWC BGR uint8 (tensor2img + crop)."""
+    _need_cuda(frame)
+    f = frame.reshape(3, frame.shape[-2], frame.shape[-1]).contiguous().float()
+    out = torch.empty((h, w, 3), dtype=torch.uint8, device=f.device)
+    L.check(L.lib().binhip_frame_to_u8(_ptr(f), f.shape[1], f.shape[2], top, left, h, w, _ptr(out), _stream()), "frame_to_u8")
+    return out

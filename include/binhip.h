@@ -116,6 +116,15 @@ int binhip_planes_to_nchw(const void* x_hi, const void* x_lo, int N, int C, int 
 int binhip_pack_inputs(const float* const* images, int n_images, int N, int H, int W,
                        void* y_hi, void* y_lo, void* stream);
 
+/* ---- harness glue: test.py's per-frame host work on the device --------------------
+ * u8_to_frame: HWC BGR uint8 -> fp32 CHW RGB /255 (read_image, test.py:44-56) + ReplicationPad2d
+ * (test.py:348-371) -> [3, H+pt+pb, W+pl+pr].   frame_to_u8: tensor2img (utils/util.py:113-137: clamp,
+ * x255, round half to even, RGB->BGR) + the crop of test.py:394-402 -> HWC BGR uint8 [H, W, 3].      */
+int binhip_u8_to_frame(const unsigned char* bgr_hwc, int H, int W, int pad_left, int pad_right,
+                       int pad_top, int pad_bottom, float* out_chw, void* stream);
+int binhip_frame_to_u8(const float* chw, int Hp, int Wp, int top, int left, int H, int W,
+                       unsigned char* bgr_hwc, void* stream);
+
 /* ---- ConvLSTM cell (RDN.py:50-95): gates = conv3x3(cat(x,h)) 6->12, i,j,f,o = chunk(4);
  * c' = c*sigmoid(f+forget_bias) + sigmoid(i)*tanh(j); h' = tanh(c')*sigmoid(o).  fp32 NCHW.
  * c_prev/h_prev may both be NULL (zero state, RDN.py:57-68).                                      */

@@ -146,3 +146,46 @@ def test_multistream_schedule_is_bit_identical(prec):
             torch.cuda.synchronize()
             for x, y, z in zip(a, b, b2):
                 assert torch.equal(x, y) and torch.equal(x, z)
+
+
+def test_harness_glue_kernels_match_reference_helpers():
+    """N1: u8->frame (read_image + ReplicationPad2d) and frame->u8 (tensor2img + crop) on the device are bit-exact
+    against the reference helpers' restatement (oracle), including round-half-even and out-of-range values."""
+    from bin_amd import ops
+    from bin_amd.utils import util
+    from oracle import rdn_oracle as O
+    g = torch.Generator().manual_seed(4)
+    img = torch.randint(0, 256, (37, 53, 3), generator=g, dtype=torch.uint8)
+    pads = (3, 5, 2, 7)
+    got = ops.u8_to_frame(img.cuda(), pads).cpu()
+    ref = torch.from_numpy(img.numpy().astype("float32") / 255.0)[:, :, [2, 1, 0]].permute(2, 0, 1).unsqueeze(0)
+    ref = O.replicate_pad(ref, pads)
+    assert torch.equal(got, ref)
+    x = torch.rand(1, 3, 40, 60, generator=g) * 1.5 - 0.25
+    x[0, :, 0, :8] = torch.tensor([0.5 / 255, 1.5 / 255, 2.5 / 255, 254.5 / 255, 0.0, 1.0, -1.0, 2.0])
+    top, left, h, w = 4, 6, 30, 50
+    got8 = ops.frame_to_u8(x.cuda(), top, left, h, w).cpu().numpy()
+    ref8 = O.tensor2img(x[0])[top:top + h, left:left + w, :]
+    assert (got8 == ref8).all()
+    assert (ops.frame_to_u8(x.cuda(), 0, 0, 40, 60).cpu().numpy() == util.tensor2img(x[0])).all()
+
+
+def test_interpolate_clip_u8_sharded():
+    """test.py-style loop on a synthetic u8 clip: window sharding over 2 'ranks' covers every window once and
+    equals the unsharded run; u8 path == fp32 path."""
+    from bin_amd.harness import interpolate_clip
+    g = torch.Generator().manual_seed(9)
+    clip = torch.randint(0, 256, (5, 40, 72, 3), generator=g, dtype=torch.uint8)
+    net = _net("f16")
+    full = interpolate_clip(net, clip)
+    a = interpolate_clip(net, clip, rank=0, world=2)
+    b = interpolate_clip(net, clip, rank=1, world=2)
+    assert sorted(full) == [0, 1, 2, 3] and sorted(list(a) + list(b)) == [0, 1, 2, 3]
+    for k, v in {**a, **b}.items():
+        for x, y in zip(v, full[k]):
+            assert (x == y).all() and x.shape == (40, 72, 3) and x.dtype.name == "uint8"
+    clip_f = (clip.float() / 255.0)[:, :, :, [2, 1, 0]].permute(0, 3, 1, 2).contiguous()
+    ff = interpolate_clip(net, clip_f)
+    for k in full:
+        for x, y in zip(ff[k], full[k]):
+            assert (x == y).all()
