@@ -228,14 +228,20 @@ class RDN_residual_interp_5_input_ConvLSTM_L(nn.Module):
                 m.precision = precision
         return self
 
-    def forward(self, B1, B3, B5, B7, B9, B11):
+    def forward(self, B1, B3, B5, B7, B9, B11, stage1_cache=None):
+        """`stage1_cache` (bin_amd extension, inference only): a dict owned by a streaming caller.  Consecutive
+        windows of a clip share 4 of their 5 stage-1 frame pairs, so model1(Bi, Bj) results are
+        memoised on the identity of the two (cached, hence long-lived) frame tensors: 17 -> 13 RDN calls per
+        window, outputs unchanged bit for bit."""
         for t in (B1, B3, B5, B7, B9, B11):
             if not t.is_cuda:
                 raise RuntimeError("bin_amd: bin_stage4 runs on a HIP device only (no CPU fallback; "
                                    "see oracle/ for the test-only CPU restatement)")
         if self.n_streams > 1 and self.reuse_schedule and self.modelType == "lstm" and not (
                 torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
-            return self._forward_streams((B1, B3, B5, B7, B9, B11))
+            return self._forward_streams((B1, B3, B5, B7, B9, B11), stage1_cache)
+        if stage1_cache is not None:
+            raise RuntimeError("bin_amd: stage1_cache needs the inference schedule (n_streams > 1, no grad)")
         cells = (self.clstm_4_prime, self.clstm_6_prime, self.clstm_8_prime, self.clstm_5_prime_prime,
                  self.clstm_7_prime_prime, self.clstm_6_prime_prime_prime)
         picks = (1, 2, 3, 5, 6, 8)
@@ -262,7 +268,7 @@ class RDN_residual_interp_5_input_ConvLSTM_L(nn.Module):
                 res[0][7], res[0][8], res[0][9], res[1][3], res[1][6], res[1][8], res[1][9])
 
 
-def _forward_streams(self, B):
+def _forward_streams(self, B, stage1_cache=None):
     """Inference schedule that runs the INDEPENDENT RDN calls of each pyramid stage on separate HIP streams
     (stage 1: 4 calls, stage 2: 3, stage 3: 2; window 2's only new stage-1 call rides along with window 1's stage 4).
     Every kernel of one call still runs in order on its stream; calls on different streams overlap, so one call's
@@ -315,13 +321,29 @@ def _forward_streams(self, B):
         return launch(si, lambda: c(x, None)[0], [x])
 
     B1, B3, B5, B7, B9, B11 = B
+
+    def stage1(si, Ba, Bb):
+        if stage1_cache is None:
+            return rdn(si, 1, Ba, Bb)
+        key = (id(Ba), id(Bb))
+        hit = stage1_cache.get(key)
+        if hit is not None and hit[1] is Ba and hit[2] is Bb:
+            return hit[0]
+        out = rdn(si, 1, Ba, Bb)
+        stage1_cache[key] = (out, Ba, Bb)
+        return out
+
+    if stage1_cache is not None:         # keep only pairs that can still recur (those of this window)
+        live = {(id(a), id(b)) for a, b in ((B1, B3), (B3, B5), (B5, B7), (B7, B9), (B9, B11))}
+        for k in [k for k in stage1_cache if k not in live]:
+            del stage1_cache[k]
     # ---- window 1
-    I2 = rdn(0, 1, B1, B3); I4 = rdn(1, 1, B3, B5); I6 = rdn(2, 1, B5, B7); I8 = rdn(3, 1, B7, B9)
+    I2 = stage1(0, B1, B3); I4 = stage1(1, B3, B5); I6 = stage1(2, B5, B7); I8 = stage1(3, B7, B9)
     I3 = rdn(0, 2, I2, I2, I4); I5 = rdn(1, 2, I4, I4, I6); I7 = rdn(2, 2, I6, I6, I8)
     h4 = cell(3, cells[0], I4); h6 = cell(3, cells[1], I6); h8 = cell(3, cells[2], I8)
     I4pp = rdn(0, 3, I3, B3, I3, I5, B5); I6pp = rdn(1, 3, I5, B5, I5, I7, B7)
     h5 = cell(2, cells[3], I5); h7 = cell(2, cells[4], I7)
-    I8b = rdn(2, 1, B9, B11)                                            # window 2's only new stage-1 call
+    I8b = stage1(2, B9, B11)                                            # window 2's only new stage-1 call
     I5ppp = rdn(0, 4, I4, I4, I4pp, I6pp, I6)
     h6pp = cell(1, cells[5], I6pp)
     # ---- window 2 (stage-1 outputs I4, I6, I8 of window 1 are its I2', I4', I6')

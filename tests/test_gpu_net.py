@@ -184,6 +184,10 @@ def test_interpolate_clip_u8_sharded():
     for k, v in {**a, **b}.items():
         for x, y in zip(v, full[k]):
             assert (x == y).all() and x.shape == (40, 72, 3) and x.dtype.name == "uint8"
+    nocache = interpolate_clip(net, clip, reuse_stage1=False)           # N3: the stage-1 cache changes no bit
+    for k in full:
+        for x, y in zip(nocache[k], full[k]):
+            assert (x == y).all()
     clip_f = (clip.float() / 255.0)[:, :, :, [2, 1, 0]].permute(0, 3, 1, 2).contiguous()
     ff = interpolate_clip(net, clip_f)
     for k in full:
