@@ -193,6 +193,8 @@ def main():
     ap.add_argument("--precision", default=os.environ.get("BIN_AMD_BENCH_PRECISION", "f16"),
                     choices=["f16", "f16x3"])
     ap.add_argument("--streams", type=int, default=None, help="concurrent RDN calls (HIP streams) in the forward")
+    ap.add_argument("--batched", action="store_true",
+                    help="batch the shared-weight RDN calls of each pyramid stage (N>1 launches) instead of multi-stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--calib", action="store_true",
                     help="also run one 256 MiB device copy (known HBM bytes) to calibrate rocprofv3 FETCH/WRITE_SIZE")
@@ -227,6 +229,8 @@ def main():
     net.reuse_schedule = not args.reference_schedule
     if args.streams is not None:
         net.n_streams = args.streams
+    if args.batched:
+        net.batched = True
 
     pads = util.pad_sizes(H, W)
     frames = [util.replicate_pad(f, pads).to(dev) for f in synthetic_frames(1234 + rank, 1, H, W, 6)]
@@ -328,7 +332,7 @@ def main():
                                    "(6-frame window padded to 768x1344 by the test.py rule), window-sharded",
                        "schedule": "17 RDN calls + 6 ConvLSTM cells (exact reuse)" if net.reuse_schedule
                                    else "20 RDN calls + 12 ConvLSTM cells (reference literal)",
-                       "precision": args.precision, "streams": net.n_streams, "parity": "max-abs <= 1e-3 vs fp32 reference (tests/)"},
+                       "precision": args.precision, "streams": net.n_streams, "batched_stages": bool(net.batched and net.n_streams > 1), "parity": "max-abs <= 1e-3 vs fp32 reference (tests/)"},
             "roofline": roof,
             "streaming": None if stream_fps is None else {
                 "value": round(stream_fps, 3), "unit": "interpolated frames/s",

@@ -132,15 +132,16 @@ def test_fused_rdb_tail_equals_unfused(prec, canon_gpu):
 
 @pytest.mark.parametrize("prec", ["f16x3", "f16"])
 def test_multistream_schedule_is_bit_identical(prec):
-    """Running independent RDN calls on separate HIP streams changes no output bit."""
+    """Running independent RDN calls on separate HIP streams, or batching the shared-weight calls of a stage into
+    one N>1 launch sequence, changes no output bit."""
     from bin_amd.weights import synthetic_frames
     frames = [f.cuda() for f in synthetic_frames(17, 1, 64, 96, 6)]
     net = _net(prec)
     with torch.no_grad():
         net.n_streams = 1
         a = net(*frames)
-        for ns in (2, 3, 4):
-            net.n_streams = ns
+        for ns, batched in ((2, False), (3, False), (4, False), (3, True)):
+            net.n_streams, net.batched = ns, batched
             b = net(*frames)
             b2 = net(*frames)
             torch.cuda.synchronize()
