@@ -16,6 +16,8 @@
 // Precision: NT=1 -> one fp16 product; NT=3 -> hi/lo split, Ah*Bh + Al*Bh + Ah*Bl (fp32 class).
 #include "binhip_internal.h"
 #include <vector>
+#include <cstdio>
+#include <cstdlib>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -44,6 +46,7 @@ struct ConvKArgs {
     int tiles_x, tiles_y;
     int relu, has_res, nimg, cout;
     int xcd_remap;
+    int wt;                   // write-through (sc1) output stores
     int och_limit;            // output chunks that exist at the destination (rows beyond are padding: not stored)
     int dbg;                  // ablation switches (timing experiments only): 1 skip weight DMA, 2 skip patch DMA, 4 skip MFMA
     int res_chunks;           // residual r applies to output chunks < res_chunks
@@ -76,6 +79,20 @@ struct ConvCfg {
 };
 
 __device__ __forceinline__ half8 lds_ld8(const char* p) { return *reinterpret_cast<const half8*>(p); }
+
+// 16-byte plane store.  wt != 0: write-through (sc1) so the XCD's L2 holds no dirty output lines at the end of the
+// kernel: the kernel-boundary release then has nothing to write back (MI355X: 8 XCDs with private, mutually
+// non-coherent L2s => every boundary flushes dirty lines; 16.5 MB of output costs ~2.8 us there).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16(_Float16* base, long long off_elems, uint4 v, int wt) {
+    if (wt) {
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0xFFFFFFFFu, 0x00020000);
+        u32x4 d = {v.x, v.y, v.z, v.w};
+        __builtin_amdgcn_raw_buffer_store_b128(d, rs, (int)(off_elems * 2), 0, 16);
+    } else {
+        *reinterpret_cast<uint4*>(base + off_elems) = v;
+    }
+}
 
 // Issue the LDS-DMA of K-stage `st` (KC chunks x NPL planes: input patch + weight slab) into buffer `buf`.
 // Every wave issues exactly NPJ + NWJ instructions per (plane, chunk) so that s_waitcnt vmcnt(N) can count
@@ -407,9 +424,9 @@ conv_mfma_kernel(const ConvKArgs a) {
                         }
                     }
                     if (ok && ((z * C::COUTB + (wm * MT + mt) * 32 + 16 * gp) >> 4) < a.och_limit) {
-                        *reinterpret_cast<uint4*>(a.y_hi + o_slot) = make_uint4(hv[0].u[0], hv[0].u[1], hv[1].u[0], hv[1].u[1]);
+                        store16(a.y_hi, o_slot, make_uint4(hv[0].u[0], hv[0].u[1], hv[1].u[0], hv[1].u[1]), a.wt);
                         if constexpr (NT == 3)
-                            *reinterpret_cast<uint4*>(a.y_lo + o_slot) = make_uint4(lv[0].u[0], lv[0].u[1], lv[1].u[0], lv[1].u[1]);
+                            store16(a.y_lo, o_slot, make_uint4(lv[0].u[0], lv[0].u[1], lv[1].u[0], lv[1].u[1]), a.wt);
                     }
                 }
             }
@@ -427,6 +444,14 @@ static int launch_cfg(const ConvKArgs& ka, int cout_pad, hipStream_t s) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
+        if (getenv("BINHIP_DEBUG")) {
+            int nb = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                &nb, reinterpret_cast<const void*>(&conv_mfma_kernel<KS, MT, WM, R, WN, KC, NT, NBUF, EPI>), 64 * C::NW,
+                C::LDS_BYTES);
+            fprintf(stderr, "[binhip] conv<%d,%d,%d,%d,%d,%d,%d,%d,%d> threads %d LDS %d B -> %d workgroups/CU (API)\n", KS, MT,
+                    WM, R, WN, KC, NT, NBUF, EPI, 64 * C::NW, C::LDS_BYTES, nb);
+        }
     }
     ConvKArgs a = ka;
     a.tiles_x = (a.W + 31) / 32;
@@ -490,6 +515,7 @@ int bh_launch_conv(const BhConvCall& c, hipStream_t s) {
     a.tiles_x = a.tiles_y = 0;
     a.xcd_remap = 0;
     a.dbg = 0;
+    a.wt = 0;
     const int P = BINHIP_EPI_PLANES, S = BINHIP_EPI_SHUFFLE, F = BINHIP_EPI_FINAL;
     if (d.epilogue == P) {
         if (!c.y_hi || (d.nterms == 3 && !c.y_lo)) return BINHIP_E_ARG;
@@ -521,6 +547,7 @@ int bh_launch_conv(const BhConvCall& c, hipStream_t s) {
 static int g_variant[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
 static int g_xcd_remap = 1;
 static int g_dbg = 0;
+static int g_wt = 1;
 enum { CLS_K3C32 = 0, CLS_K1C96 = 1, CLS_K3C96 = 2, CLS_SHUFFLE = 3, CLS_FINAL = 4, CLS_K5 = 5 };
 
 static int bh_dispatch_conv(const ConvKArgs& a0, int k, int cp, int nt, int e, hipStream_t s) {
@@ -530,6 +557,12 @@ static int bh_dispatch_conv(const ConvKArgs& a0, int k, int cp, int nt, int e, h
     ConvKArgs a = a0;
     a.xcd_remap = g_xcd_remap;
     a.dbg = g_dbg;
+    {   // 32-bit buffer offsets: write-through path only while the whole output tensor stays below 4 GiB
+        const long long out_chunks = (e == BINHIP_EPI_SHUFFLE) ? (a.cout / 4 + 15) / 16 : (cp + 15) / 16;
+        const long long px = (long long)a.N * a.H * a.W * ((e == BINHIP_EPI_SHUFFLE) ? 4 : 1);
+        const long long span = (a.y_cpg > 0 ? ((out_chunks + a.y_cpg - 1) / a.y_cpg) * a.y_group_stride * 2 : out_chunks * px * 32);
+        a.wt = (g_wt && span < (1ll << 32) - 64) ? 1 : 0;
+    }
     //                                   KS MT WM R WN KC NT NBUF EPI
     if (nt == 1) {
         if (e == F && k == 3 && cp == 32)  return launch_cfg<3, 1, 1, 4, 4, 1, 1, 2, F>(a, cp, s);
@@ -720,6 +753,7 @@ int binhip_conv2d_bwd_data(const BinConvDesc* d, const void* gy_hi, const void* 
 int binhip_set_variant(int layer_class, int variant) {
     if (layer_class == -1) { g_xcd_remap = variant; return 0; }
     if (layer_class == -2) { g_dbg = variant; return 0; }
+    if (layer_class == -3) { g_wt = variant; return 0; }
     if (layer_class < 0 || layer_class >= 8) return BINHIP_E_ARG;
     g_variant[layer_class] = variant;
     return 0;

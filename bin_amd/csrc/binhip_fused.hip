@@ -23,7 +23,7 @@ struct TailKArgs {
     const float *bc, *bl;              // biases (32 / 96 floats)
     _Float16 *y_hi, *y_lo;             // output planes (6 chunks)
     _Float16 *o3_hi, *o3_lo;           // optional: where to keep o3 (2 chunks) for the backward pass
-    int N, H, W, tiles_x, tiles_y, xcd_remap;
+    int N, H, W, tiles_x, tiles_y, xcd_remap, wt;
 };
 
 template <int NT, int NBUF>
@@ -44,6 +44,18 @@ struct TailCfg {
 };
 
 __device__ __forceinline__ half8 ld8(const char* p) { return *reinterpret_cast<const half8*>(p); }
+
+// write-through (sc1) 16-byte plane store: leaves no dirty lines for the kernel-boundary L2 write-back (see binhip_conv.hip)
+typedef unsigned u32x4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16_wt(_Float16* base, long long off_elems, uint4 v, int wt) {
+    if (wt) {
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0xFFFFFFFFu, 0x00020000);
+        u32x4f d = {v.x, v.y, v.z, v.w};
+        __builtin_amdgcn_raw_buffer_store_b128(d, rs, (int)(off_elems * 2), 0, 16);
+    } else {
+        *reinterpret_cast<uint4*>(base + off_elems) = v;
+    }
+}
 
 template <int N>
 __device__ __forceinline__ void wait_vm() {
@@ -336,9 +348,9 @@ rdb_tail_kernel(const TailKArgs a) {
                     }
                 }
                 if (ok) {
-                    *reinterpret_cast<uint4*>(a.y_hi + o_slot) = make_uint4(hv[0].u[0], hv[0].u[1], hv[1].u[0], hv[1].u[1]);
+                    store16_wt(a.y_hi, o_slot, make_uint4(hv[0].u[0], hv[0].u[1], hv[1].u[0], hv[1].u[1]), a.wt);
                     if constexpr (NT == 3)
-                        *reinterpret_cast<uint4*>(a.y_lo + o_slot) = make_uint4(lv[0].u[0], lv[0].u[1], lv[1].u[0], lv[1].u[1]);
+                        store16_wt(a.y_lo, o_slot, make_uint4(lv[0].u[0], lv[0].u[1], lv[1].u[0], lv[1].u[1]), a.wt);
                 }
             }
         }
@@ -385,6 +397,7 @@ int binhip_rdb_tail_fwd(int N, int H, int W, int nterms, const void* blk_hi, con
     a.o3_hi = store_o3 ? (_Float16*)blk_hi + 12 * plane : nullptr;
     a.o3_lo = (store_o3 && nterms == 3) ? (_Float16*)blk_lo + 12 * plane : nullptr;
     a.N = N; a.H = H; a.W = W; a.tiles_x = a.tiles_y = 0; a.xcd_remap = 1;
+    a.wt = (6 * plane * 2 < (1ll << 32) - 64) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     if (nterms == 1) {
         switch (g_tail_depth) {

@@ -143,6 +143,15 @@ def main():
                     print(f"ablate RDB conv {cin}->32 variant {v:2d} {nm:28s}: {time_fn(f):7.1f} us")
         lib.binhip_set_variant(-2, 0)
         lib.binhip_set_variant(0, -1)
+    if os.environ.get("WT"):
+        for cin in (96, 192):
+            cw = wts(32, cin, 3)
+            out = ops.CP.empty(2, n, h, w, nt, dev)
+            f = (lambda cw=cw, cin=cin, out=out: ops.conv2d(x224, cw, relu=True, out=out, cin_chunks=cin // 16))
+            for wt in (0, 1, 0, 1):
+                lib.binhip_set_variant(-3, wt)
+                print(f"RDB conv {cin}->32 write-through={wt}: {time_fn(f):7.1f} us")
+        lib.binhip_set_variant(-3, 1)
     want = {int(c) for c in args.classes.split(",")}
     print(f"nterms={nt} N={n} {h}x{w}")
     for xcd in (1,):
