@@ -160,6 +160,14 @@ rdb_tail_kernel(const TailKArgs a) {
 
     const int a_lane_off = n * 32 + ((kg ^ ((n >> 3) & 1)) << 4);
     const int b_lane_p = wave * C::R * C::PW + n;
+    // identity A fragments: row m selects input channel k of the chunk when m == 16*half + k.  The RDB residual
+    // (`+ x`, RDN.py:165) is then one extra MFMA per row in the K-steps of chunks 0..5 — x is already in registers as
+    // the centre-tap fragment — instead of a second pass over x from HBM in the epilogue (49.5 MB per launch).
+    half8 ident[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ident[hf][e] = (n == hf * 16 + kg * 8 + e) ? (_Float16)1.0f : (_Float16)0.0f;
     int cur = 0, nxt = NBUF - 1;
     for (int st = 0; st < C::NCHUNK; ++st) {
         int yf = C::NCHUNK - 1 - st;
@@ -200,6 +208,19 @@ rdb_tail_kernel(const TailKArgs a) {
                 }
             }
             if (dx == 1) {   // the 1x1 LFF sees the centre tap's fragment
+                if (st < 6) {        // residual: output channels 16*st .. 16*st+15 += x (exact: 1.0 * x, fp32 accumulate)
+#pragma unroll
+                    for (int r = 0; r < C::R; ++r) {
+#pragma unroll
+                        for (int mt = 0; mt < 3; ++mt) {
+                            if (mt == (st >> 1)) {
+                                accl[mt][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ident[st & 1], Bh[r + 1], accl[mt][r], 0, 0, 0);
+                                if constexpr (NT == 3)
+                                    accl[mt][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ident[st & 1], Bl[r + 1], accl[mt][r], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
 #pragma unroll
                 for (int mt = 0; mt < 3; ++mt) {
                     const int off = (mt * 32) * 32 + a_lane_off;
@@ -319,18 +340,7 @@ rdb_tail_kernel(const TailKArgs a) {
                     const float4 bv = *reinterpret_cast<const float4*>(a.bl + co);
                     float v[4] = {accl[mt][r][4 * g + 0] + bv.x, accl[mt][r][4 * g + 1] + bv.y,
                                   accl[mt][r][4 * g + 2] + bv.z, accl[mt][r][4 * g + 3] + bv.w};
-                    // addresses are clamped into the image so the residual loads need no branch (stores are predicated)
                     const long long o = (long long)(co >> 4) * plane_elems + ((((long long)img * H + gyc) * W + gxc) << 4) + (co & 15);
-                    {
-                        const half4 rh = *reinterpret_cast<const half4*>(a.x_hi + o);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] += (float)rh[j];
-                        if constexpr (NT == 3) {
-                            const half4 rl = *reinterpret_cast<const half4*>(a.x_lo + o);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] += (float)rl[j];
-                        }
-                    }
                     if (ge == kg) o_slot = o - 4 * kg;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {

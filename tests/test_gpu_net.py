@@ -115,8 +115,9 @@ def test_cpu_tensor_raises():
 
 @pytest.mark.parametrize("prec", ["f16x3", "f16"])
 def test_fused_rdb_tail_equals_unfused(prec, canon_gpu):
-    """binhip_rdb_tail_fwd (conv #3 + LFF + residual in one kernel) is bit-identical to the two-kernel path
-    (same accumulation order), with and without keeping o3 for the backward pass."""
+    """binhip_rdb_tail_fwd (conv #3 + LFF + residual in one kernel) vs the two-kernel path: identical up to fp32
+    summation order (the fused kernel adds the residual x inside the K-loop as an identity MFMA, the unfused one in the
+    epilogue), and bit-identical with / without keeping o3 for the backward pass."""
     from bin_amd import _lib as L, rdn_plan
     from bin_amd.models.archs.RDN import PRECISIONS
     from bin_amd.rdn_plan import RdnWeights, rdn_forward
@@ -127,7 +128,9 @@ def test_fused_rdb_tail_equals_unfused(prec, canon_gpu):
         a = rdn_forward(wts, ins, flags=0)
         b = rdn_forward(wts, ins, flags=L.PLAN_NO_FUSE)
         c = rdn_forward(wts, ins, flags=L.PLAN_KEEP_ACTS)
-        assert torch.equal(a, b) and torch.equal(a, c)
+        assert torch.equal(a, c)
+        tol = 2e-6 if prec == "f16x3" else 1.5e-3          # f16: 1-ulp fp16 storage differences propagate
+        assert float((a - b).abs().max()) <= tol * float(b.abs().max())
 
 
 @pytest.mark.parametrize("prec", ["f16x3", "f16"])
