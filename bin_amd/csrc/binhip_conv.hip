@@ -201,7 +201,7 @@ __device__ __forceinline__ void compute_stage(const char* smem, int st, int buf,
             } else {
                 load_frags<C, KS, MT, R, NT>(bbase, s / KS, s % KS, wm, a_lane_off, b_lane_p, kg, Bh[0], Bl[0], Ah[0], Al[0]);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PIPE) __builtin_amdgcn_sched_barrier(0);   // (single-set kernels: leave the interleaving to hipcc)
 #pragma unroll
             for (int dy = 0; dy < KS; ++dy)
 #pragma unroll
@@ -214,7 +214,7 @@ __device__ __forceinline__ void compute_stage(const char* smem, int st, int buf,
                         }
                         acc[mt][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[s & (NSET - 1)][dy][mt], Bh[s & (NSET - 1)][r + dy], acc[mt][r], 0, 0, 0);
                     }
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PIPE) __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -561,7 +561,8 @@ static int bh_dispatch_conv(const ConvKArgs& a0, int k, int cp, int nt, int e, h
         const long long out_chunks = (e == BINHIP_EPI_SHUFFLE) ? (a.cout / 4 + 15) / 16 : (cp + 15) / 16;
         const long long px = (long long)a.N * a.H * a.W * ((e == BINHIP_EPI_SHUFFLE) ? 4 : 1);
         const long long span = (a.y_cpg > 0 ? ((out_chunks + a.y_cpg - 1) / a.y_cpg) * a.y_group_stride * 2 : out_chunks * px * 32);
-        a.wt = (g_wt && span < (1ll << 32) - 64) ? 1 : 0;
+        // PLANES only: the PixelShuffle store (16 B per lane at a 64-B stride) relies on L2 to merge partial lines
+        a.wt = (g_wt && e == BINHIP_EPI_PLANES && span < (1ll << 32) - 64) ? 1 : 0;
     }
     //                                   KS MT WM R WN KC NT NBUF EPI
     if (nt == 1) {

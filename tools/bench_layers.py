@@ -68,12 +68,12 @@ def main():
                   (lambda: ops.conv2d(x1152, cwg, out=outg)), 2 * 1152 * 96 * px, (1152 + 96) * bpe * px, outg))
     cw3 = wts(96, 96, 3)
     out3 = ops.CP.empty(6, n, h, w, nt, dev)
-    cases.append((2, "3x3 96->96 +res", [0, 1] if nt == 1 else [0],
+    cases.append((2, "3x3 96->96 +res", [-1, 1] if nt == 1 else [0],
                   (lambda: ops.conv2d(res96, cw3, residual=x224, out=out3)), 2 * 9 * 96 * 96 * px,
                   (96 + 96 + 96) * bpe * px, out3))
     cwu = wts(256, 96, 3, shuffle=True)
     outu = ops.CP.empty(4, n, 2 * h, 2 * w, nt, dev)
-    cases.append((3, "UPNet.0 3x3 96->256 +shuffle", [0, 1] if nt == 1 else [0],
+    cases.append((3, "UPNet.0 3x3 96->256 +shuffle", [0, -1] if nt == 1 else [0],
                   (lambda: ops.conv2d(res96, cwu, out=outu, epilogue=L.EPI_SHUFFLE)), 2 * 9 * 96 * 256 * px,
                   (96 + 256) * bpe * px, outu))
     xu = mk(64, 2 * h, 2 * w)
