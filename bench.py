@@ -136,8 +136,7 @@ def train_bench(args, rank, world, dev):
     import torch.distributed as dist
     from bin_amd.models import create_model
     from bin_amd.weights import reference_state_dict
-    prec = "f16x3" if args.precision == "f16" and "BIN_AMD_BENCH_PRECISION" not in os.environ and "--precision" not in sys.argv \
-        else args.precision
+    prec = args.train_precision
     tmp = tempfile.mkdtemp()
     opt = {"model": "bin", "gpu_ids": [0], "is_train": True, "dist": world > 1,
            "network_G": {"which_model_G": "bin_stage4", "nframes": 6, "version": 2, "precision": prec},
@@ -202,6 +201,8 @@ def main():
                     help="train: BASELINE config 4 — one optimize_parameters() (fwd + Charbonnier + bwd + grad "
                          "all-reduce + Adam) on 256x256 crops, --batch samples per GPU (secondary metric, own JSON line)")
     ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--train-precision", default="f16x3", choices=["f16", "f16x3"],
+                    help="precision of --mode train (default f16x3: fp32-class gradients)")
     ap.add_argument("--reference-schedule", action="store_true",
                     help="run the reference's literal 20 RDN calls + 12 cells instead of the exact 17 + 6")
     args = ap.parse_args()

@@ -50,6 +50,21 @@ __global__ void planes_to_nchw_kernel(const _Float16* __restrict__ x_hi, const _
     y[t] = v;
 }
 
+// ---- exact fp32 space-to-depth (the standalone pixel_reshuffle of the reference's API, RDN.py:107-132) --------------
+__global__ void pixel_unshuffle_f32_kernel(const float* __restrict__ x, int N, int C, int H, int W, int r,
+                                           float* __restrict__ y) {
+    const int h = H / r, w = W / r;
+    const long long total = (long long)N * C * H * W;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int ox = (int)(t % w);
+    const int oy = (int)((t / w) % h);
+    const int oc = (int)((t / ((long long)w * h)) % (C * r * r));
+    const int n = (int)(t / ((long long)w * h * C * r * r));
+    const int c = oc / (r * r), i = (oc / r) % r, j = oc % r;
+    y[t] = x[(((long long)n * C + c) * H + (oy * r + i)) * W + (ox * r + j)];
+}
+
 // ---- K1: pixel_reshuffle(cat(images), 2) -> chunk planes at half resolution ---------------------
 struct PackArgs {
     const float* img[5];
@@ -462,6 +477,16 @@ int binhip_planes_to_nchw(const void* x_hi, const void* x_lo, int N, int C, int 
     const long long total = (long long)N * C * H * W;
     hipLaunchKernelGGL(planes_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const _Float16*)x_hi, (const _Float16*)x_lo, N, C, H, W, y);
+    BH_CHECK_LAUNCH();
+    return 0;
+}
+
+int binhip_pixel_unshuffle_f32(const float* x, int N, int C, int H, int W, int r, float* y, void* stream) {
+    if (!x || !y) return BINHIP_E_ARG;
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || r < 1 || H % r || W % r) return BINHIP_E_SHAPE;
+    const long long total = (long long)N * C * H * W;
+    hipLaunchKernelGGL(pixel_unshuffle_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       N, C, H, W, r, y);
     BH_CHECK_LAUNCH();
     return 0;
 }

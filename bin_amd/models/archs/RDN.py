@@ -53,15 +53,9 @@ class ConvLSTMCell(nn.Module):
 
 
 def pixel_reshuffle(input, upscale_factor):
-    """reference RDN.py:107-132 (space-to-depth); returns fp32 NCHW like the reference."""
-    if upscale_factor != 2 or input.shape[1] % 3:
-        raise NotImplementedError("bin_amd pixel_reshuffle: r=2 on 3k-channel frames only")
-    frames = [input[:, i:i + 3] for i in range(0, input.shape[1], 3)]
-    out = []
-    for i in range(0, len(frames), 5):
-        grp = frames[i:i + 5]
-        out.append(ops.planes_to_nchw(ops.pack_inputs(grp, 3), 12 * len(grp)))
-    return torch.cat(out, 1) if len(out) > 1 else out[0]
+    """reference RDN.py:107-132 (space-to-depth, exact permutation), fp32 NCHW in and out.  Inside the network this
+    op is fused into the input packer (binhip_pack_inputs); the standalone function exists for API parity."""
+    return ops.pixel_unshuffle(input, upscale_factor)
 
 
 class RDB_Conv(nn.Module):
@@ -364,7 +358,7 @@ def _forward_streams(self, B, stage1_cache=None):
     return outs
 
 
-RDN_residual_interp_5_input_ConvLSTM_L._forward_streams = _forward_streams
+RDN_residual_interp_5_input_ConvLSTM_L._forward_streams = _forward_streams      # (defined below the class for readability)
 
 
 def _forward_batched(self, B, stage1_cache=None):

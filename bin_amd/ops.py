@@ -257,3 +257,15 @@ def frame_to_u8(frame, top, left, h, w):
     out = torch.empty((h, w, 3), dtype=torch.uint8, device=f.device)
     L.check(L.lib().binhip_frame_to_u8(_ptr(f), f.shape[1], f.shape[2], top, left, h, w, _ptr(out), _stream()), "frame_to_u8")
     return out
+
+
+def pixel_unshuffle(x, r=2):
+    """Exact space-to-depth: out[b, c*r*r + i*r + j, y, x] = in[b, c, y*r+i, x*r+j] (reference RDN.py:107-132)."""
+    _need_cuda(x)
+    x = x.contiguous().float()
+    n, c, h, w = x.shape
+    if h % r or w % r or r < 1:
+        raise RuntimeError(f"bin_amd: pixel_unshuffle needs H, W divisible by r (got {h}x{w}, r={r})")
+    y = torch.empty((n, c * r * r, h // r, w // r), dtype=torch.float32, device=x.device)
+    L.check(L.lib().binhip_pixel_unshuffle_f32(_ptr(x), n, c, h, w, r, _ptr(y), _stream()), "pixel_unshuffle")
+    return y

@@ -111,6 +111,8 @@ int binhip_nchw_to_planes(const float* x, int N, int C, int H, int W, void* y_hi
 /* chunk planes -> fp32 NCHW (hi + lo when lo != NULL).                                           */
 int binhip_planes_to_nchw(const void* x_hi, const void* x_lo, int N, int C, int H, int W, float* y,
                           void* stream);
+/* exact fp32 space-to-depth, the reference's standalone pixel_reshuffle (RDN.py:107-132)                */
+int binhip_pixel_unshuffle_f32(const float* x, int N, int C, int H, int W, int r, float* y, void* stream);
 /* K1: pixel_reshuffle(cat(images), 2) (RDN.py:107-132, 211/269/323) fused into the CP writer:
  * `n_images` fp32 [N,3,H,W] -> CP [N, H/2, W/2, pad16(12*n_images)].                            */
 int binhip_pack_inputs(const float* const* images, int n_images, int N, int H, int W,

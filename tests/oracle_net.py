@@ -13,7 +13,7 @@ class OracleNet(torch.nn.Module):
         super().__init__()
         self.inner = bin_stage4_lstm()          # parameter container with the reference's key names
 
-    # expose the inner module's state_dict namespace unchanged
+    # expose the inner module's state_dict / parameter namespace unchanged
     def state_dict(self, *a, **k):
         return self.inner.state_dict(*a, **k)
 
@@ -27,15 +27,7 @@ class OracleNet(torch.nn.Module):
         return self.inner.parameters(recurse)
 
     def forward(self, *frames):
-        sd = dict(self.inner.named_parameters())          # de-duplicated (540) but only first aliases
-        full = {}
-        for k, v in sd.items():
-            full[k] = v
-        W = O.canon_from_state_dict(_expand_aliases(full))
+        # named_parameters() lists each shared module once, under its FIRST alias (model1_1, model2_1, model3_1,
+        # model4_1) — exactly the names canon_from_state_dict maps to the canonical weight sets
+        W = O.canon_from_state_dict(dict(self.inner.named_parameters()))
         return O.bin_stage4_forward(list(frames), W)
-
-
-def _expand_aliases(named):
-    """named_parameters() lists shared modules once (model1_1, model2_1, model3_1, model4_1) — exactly
-    the first alias of each set, which is what canon_from_state_dict keys on."""
-    return named

@@ -197,3 +197,21 @@ def test_interpolate_clip_u8_sharded():
     for k in full:
         for x, y in zip(ff[k], full[k]):
             assert (x == y).all()
+
+
+def test_hipgraph_replay_matches_eager():
+    """The whole forward captured into a hipGraph (bin_amd.harness.GraphedNet) replays bit-identically."""
+    from bin_amd.harness import GraphedNet
+    from bin_amd.weights import synthetic_frames
+    net = _net("f16")
+    f1 = [f.cuda() for f in synthetic_frames(31, 1, 64, 64, 6)]
+    f2 = [f.cuda() for f in synthetic_frames(32, 1, 64, 64, 6)]
+    with torch.no_grad():
+        e1 = [o.clone() for o in net(*f1)]
+        e2 = [o.clone() for o in net(*f2)]
+    g = GraphedNet(net, f1)
+    for frames, ref in ((f2, e2), (f1, e1), (f2, e2)):
+        out = g(*frames)
+        torch.cuda.synchronize()
+        for x, y in zip(out, ref):
+            assert torch.equal(x, y)

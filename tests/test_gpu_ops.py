@@ -35,6 +35,15 @@ def test_layout_roundtrip(nterms):
     assert float((x - y).abs().max()) <= tol * float(x.abs().max())
 
 
+def test_pixel_reshuffle_function_exact():
+    """The module-level pixel_reshuffle (API parity with reference RDN.py:107-132) is an exact permutation."""
+    from bin_amd.models.archs.RDN import pixel_reshuffle
+    g = load_golden("g1_pixel_reshuffle")
+    assert torch.equal(pixel_reshuffle(torch.from_numpy(g["x"]).cuda(), 2).cpu(), torch.from_numpy(g["y"]))
+    x = torch.randn(2, 5, 12, 18)
+    assert torch.equal(pixel_reshuffle(x.cuda(), 3).cpu(), torch.nn.functional.pixel_unshuffle(x, 3))
+
+
 @pytest.mark.parametrize("nterms", [3, 1])
 def test_pixel_reshuffle_pack(nterms):
     """K1 against the reference's own pixel_reshuffle output (g1_pixel_reshuffle) — 6 = 2 frames x 3."""
