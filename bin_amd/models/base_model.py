@@ -1,26 +1,54 @@
-"""BaseModel (reference models/base_model.py:8-125): device pick, LR warm-up, checkpoint IO.
-Checkpoints are the reference's format: `{iter}_G.pth` = CPU state_dict of the unwrapped generator
-(1332 aliased keys), `{iter}.state` = {epoch, iter, schedulers[], optimizers[]}."""
+"""Host-side base class of the model wrapper: same public surface as the reference's `BaseModel`
+(models/base_model.py:8-125 — device pick, LR warm-up, network / training-state checkpoints), written
+for the one-process-per-GPU design.
+
+Checkpoint formats are the reference's, so files interchange both ways:
+  `{iter}_G.pth`   CPU state_dict of the unwrapped generator (1332 aliased keys for bin_stage4)
+  `{iter}.state`   {"epoch", "iter", "schedulers": [...], "optimizers": [...]}
+"""
 import os
 from collections import OrderedDict
 
 import torch
 import torch.nn as nn
 
+_PREFIXES = ("module.", "InterpNet.")
+
 
 def unwrap(network):
-    """Strip a DataParallel / DDP / SingleProcessParallel wrapper."""
-    return network.module if hasattr(network, "module") and isinstance(network.module, nn.Module) else network
+    """The bare generator behind a DataParallel / DDP / SingleProcessParallel style wrapper."""
+    inner = getattr(network, "module", None)
+    return inner if isinstance(inner, nn.Module) else network
+
+
+def clean_state_dict_keys(loaded, strict):
+    """Key clean-up of the reference's load_network (base_model.py:93-102): a leading 'module.' or
+    'InterpNet.' is stripped.  The reference also keeps a 'module.'-prefixed key under its original name
+    (its `else` belongs to the second `if`); that duplicate makes a strict load of a DataParallel-saved
+    file impossible, so under strict=True it is dropped when the stripped twin exists."""
+    out = OrderedDict()
+    for key, value in loaded.items():
+        stripped = next((key[len(p):] for p in _PREFIXES if key.startswith(p)), None)
+        if stripped is not None:
+            out[stripped] = value
+        if not key.startswith("InterpNet."):
+            out[key] = value
+    if strict:
+        for key in [k for k in out if k.startswith("module.") and k[len("module."):] in out]:
+            del out[key]
+    return out
 
 
 class BaseModel:
     def __init__(self, opt):
         self.opt = opt
-        self.device = torch.device("cuda" if opt["gpu_ids"] is not None else "cpu")
         self.is_train = opt["is_train"]
-        self.schedulers = []
+        # reference rule (base_model.py:11): any gpu_ids => 'cuda' (the process's current HIP device), else cpu
+        self.device = torch.device("cpu" if opt["gpu_ids"] is None else "cuda")
         self.optimizers = []
+        self.schedulers = []
 
+    # ---- interface stubs the concrete wrapper overrides (kept for API parity) ----------------------
     def feed_data(self, data):
         pass
 
@@ -42,71 +70,54 @@ class BaseModel:
     def load(self):
         pass
 
+    # ---- learning rate -----------------------------------------------------------------------------
     def _set_lr(self, lr_groups_l):
-        """set learning rate for warm-up; lr_groups_l: one list of group lrs per optimizer"""
-        for optimizer, lr_groups in zip(self.optimizers, lr_groups_l):
-            for param_group, lr in zip(optimizer.param_groups, lr_groups):
-                param_group["lr"] = lr
+        """lr_groups_l[i][j]: learning rate of param group j of optimizer i."""
+        for opt_, group_lrs in zip(self.optimizers, lr_groups_l):
+            for group, lr in zip(opt_.param_groups, group_lrs):
+                group["lr"] = lr
 
     def _get_init_lr(self):
-        return [[v["initial_lr"] for v in o.param_groups] for o in self.optimizers]
+        """The schedulers record each group's starting rate as 'initial_lr'."""
+        return [[g["initial_lr"] for g in opt_.param_groups] for opt_ in self.optimizers]
 
     def update_learning_rate(self, cur_iter, warmup_iter=-1):
-        for scheduler in self.schedulers:
-            scheduler.step()
+        """Step every scheduler, then override with the linear warm-up ramp while cur_iter < warmup_iter
+        (reference base_model.py:51-63)."""
+        for sched in self.schedulers:
+            sched.step()
         if cur_iter < warmup_iter:
-            init = self._get_init_lr()
-            self._set_lr([[v / warmup_iter * cur_iter for v in grp] for grp in init])
+            # same arithmetic order as the reference: initial_lr / warmup_iter * cur_iter
+            self._set_lr([[lr0 / warmup_iter * cur_iter for lr0 in grp] for grp in self._get_init_lr()])
 
     def get_current_learning_rate(self):
         return [g["lr"] for g in self.optimizers[0].param_groups]
 
+    # ---- description / checkpoints -------------------------------------------------------------------
     def get_network_description(self, network):
-        network = unwrap(network)
-        return str(network), sum(p.numel() for p in network.parameters())
+        net = unwrap(network)
+        return str(net), sum(p.numel() for p in net.parameters())
 
     def save_network(self, network, network_label, iter_label):
-        save_path = os.path.join(self.opt["path"]["models"], "{}_{}.pth".format(iter_label, network_label))
-        state_dict = unwrap(network).state_dict()
-        for key, param in state_dict.items():
-            state_dict[key] = param.cpu()
-        torch.save(state_dict, save_path)
+        target = os.path.join(self.opt["path"]["models"], f"{iter_label}_{network_label}.pth")
+        torch.save(OrderedDict((k, v.cpu()) for k, v in unwrap(network).state_dict().items()), target)
 
     def load_network(self, load_path, network, strict=True):
-        """Strips 'module.' / 'InterpNet.' prefixes exactly like the reference (base_model.py:89-103,
-        including its quirk that a 'module.'-prefixed key is also kept under its original name unless it
-        starts with 'InterpNet.')."""
-        network = unwrap(network)
-        load_net = torch.load(load_path, map_location="cpu")
-        clean = OrderedDict()
-        for k, v in load_net.items():
-            if k.startswith("module."):
-                clean[k[7:]] = v
-            if k.startswith("InterpNet."):
-                clean[k[10:]] = v
-            else:
-                clean[k] = v
-        if strict:
-            # the quirk above would make strict loading of a DataParallel-saved file fail on the
-            # duplicated 'module.*' keys; drop them when their stripped twin exists
-            for k in [k for k in clean if k.startswith("module.") and k[7:] in clean]:
-                del clean[k]
-        network.load_state_dict(clean, strict=strict)
+        loaded = torch.load(load_path, map_location="cpu")
+        unwrap(network).load_state_dict(clean_state_dict_keys(loaded, strict), strict=strict)
 
     def save_training_state(self, epoch, iter_step):
-        state = {"epoch": epoch, "iter": iter_step, "schedulers": [], "optimizers": []}
-        for s in self.schedulers:
-            state["schedulers"].append(s.state_dict())
-        for o in self.optimizers:
-            state["optimizers"].append(o.state_dict())
-        torch.save(state, os.path.join(self.opt["path"]["training_state"], "{}.state".format(iter_step)))
+        """`{iter}.state` with everything needed to resume (reference base_model.py:105-114)."""
+        state = {"epoch": epoch, "iter": iter_step,
+                 "schedulers": [s.state_dict() for s in self.schedulers],
+                 "optimizers": [o.state_dict() for o in self.optimizers]}
+        torch.save(state, os.path.join(self.opt["path"]["training_state"], f"{iter_step}.state"))
 
     def resume_training(self, resume_state):
-        resume_optimizers = resume_state["optimizers"]
-        resume_schedulers = resume_state["schedulers"]
-        assert len(resume_optimizers) == len(self.optimizers), "Wrong lengths of optimizers"
-        assert len(resume_schedulers) == len(self.schedulers), "Wrong lengths of schedulers"
-        for i, o in enumerate(resume_optimizers):
-            self.optimizers[i].load_state_dict(o)
-        for i, s in enumerate(resume_schedulers):
-            self.schedulers[i].load_state_dict(s)
+        saved_opt, saved_sched = resume_state["optimizers"], resume_state["schedulers"]
+        assert len(saved_opt) == len(self.optimizers), "Wrong lengths of optimizers"
+        assert len(saved_sched) == len(self.schedulers), "Wrong lengths of schedulers"
+        for target, state in zip(self.optimizers, saved_opt):
+            target.load_state_dict(state)
+        for target, state in zip(self.schedulers, saved_sched):
+            target.load_state_dict(state)
