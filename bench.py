@@ -137,6 +137,9 @@ def train_bench(args, rank, world, dev):
     from bin_amd.models import create_model
     from bin_amd.weights import reference_state_dict
     prec = args.train_precision
+    if os.environ.get("BIN_AMD_WGRAD_DBG"):          # kernel A/B switch for tools/ experiments (binhip_wgrad_set_debug)
+        from bin_amd import _lib
+        _lib.lib().binhip_wgrad_set_debug(int(os.environ["BIN_AMD_WGRAD_DBG"]))
     tmp = tempfile.mkdtemp()
     opt = {"model": "bin", "gpu_ids": [0], "is_train": True, "dist": world > 1,
            "network_G": {"which_model_G": "bin_stage4", "nframes": 6, "version": 2, "precision": prec},

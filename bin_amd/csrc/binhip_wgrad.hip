@@ -258,6 +258,99 @@ wgrad_mfma_kernel(const WgradKArgs a) {
 
 
 // ---------------------------------------------------------------------------------------------------------------
+// Lean variant of the kernel above: ONE LDS buffer (no intra-workgroup double buffering), fragments fetched per tap,
+// bias as per-lane VALU sums, <= 256 registers -> two workgroups share a CU and overlap each other's DMA waits.
+template <int KS, int TR, int NT>
+__global__ void __launch_bounds__(256, 2)
+wgrad_mfma_sb_kernel(const WgradKArgs a) {
+    using C = WgCfg<KS, TR, NT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pb = blockIdx.x, cp = blockIdx.y;
+    const int cot = blockIdx.z % a.ncot;
+    const int dyg = blockIdx.z / a.ncot;
+    const int dy0 = dyg * TR;
+    const long long plane_elems = (long long)a.N * a.H * a.W * 16;
+    const unsigned plane_bytes = (unsigned)(plane_elems * 2);
+    const bool do_bias = (cp == 0) && (dyg == 0);
+
+    floatx16 acc[C::NTAP];
+    float bsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < C::NTAP; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    for (int tile = pb; tile < a.ntiles; tile += a.PB) {
+        if (!(a.dbg & 1)) wg_issue<KS, TR, NT>(a, smem, 0, tile, cp, cot, dy0, wave, lane, plane_elems, plane_bytes);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (!(a.dbg & 2)) {
+            const char* xb = smem;
+            const char* gb = xb + 2 * C::XBYTES;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int row = wave * 2 + (s4 >> 1), x0 = (s4 & 1) * 16;
+                const half8 Bh = tr_frag(gb, C::GBYTES, row * 32 + x0, lane);
+                half8 Bl;
+                if constexpr (NT == 3) Bl = tr_frag(gb + C::PLANE_BYTES, C::GBYTES, row * 32 + x0, lane);
+                if (do_bias) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        bsum += (float)Bh[e];
+                        if constexpr (NT == 3) bsum += (float)Bl[e];
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < C::NTAP; ++t) {
+                    const int p0 = (row + t / KS) * C::PW + x0 + t % KS;
+                    const half8 Ah = tr_frag(xb, C::XBYTES, p0, lane);
+                    if constexpr (NT == 3) {
+                        const half8 Al = tr_frag(xb + C::PLANE_BYTES, C::XBYTES, p0, lane);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, acc[t], 0, 0, 0);
+                    }
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (a.dbg & 4) { if (acc[0][0] == 12345.f) a.partial[0] = bsum; return; }
+    float* red = reinterpret_cast<float*>(smem);
+    const int n = lane & 31, hi = lane >> 5;
+    const long long blk = ((long long)blockIdx.z * a.ncp + cp) * a.PB + pb;
+#pragma unroll
+    for (int t = 0; t < C::NTAP; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = (e & 3) + 8 * (e >> 2) + 4 * hi;
+            red[wave * 1024 + m * 32 + n] = acc[t][e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            a.partial[(blk * C::NTAP + t) * 1024 + idx] = (red[idx] + red[1024 + idx]) + (red[2048 + idx] + red[3072 + idx]);
+        }
+    }
+    if (do_bias) {
+        __syncthreads();
+        red[tid] = bsum;                              // [wave][kg][co]
+        __syncthreads();
+        if (tid < 32) {
+            float tsum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) tsum += red[k * 32 + tid];
+            a.partial_b[((long long)cot * a.PB + pb) * 32 + tid] = tsum;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // 1x1 convolutions (LFF 224->96, GFF.0 1152->96): with a single tap the whole [NCPB x 32 ci] x [96 co] gradient tile
 // fits in registers (NCPB*3 accumulators), so one workgroup keeps ALL three output tiles and NCPB = 4 input-channel
 // pairs: X and gY are each streamed through LDS exactly once (the generic kernel re-reads X per output tile and gY
@@ -566,6 +659,23 @@ int launch_wg(const WgradKArgs& a, const WgGeom& g, hipStream_t s) {
     return 0;
 }
 
+template <int KS, int TR, int NT>
+int launch_wg_sb(const WgradKArgs& a, const WgGeom& g, hipStream_t s) {
+    using C = WgCfg<KS, TR, NT>;
+    constexpr int LDS = C::BUF_BYTES > 16384 ? C::BUF_BYTES : 16384;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_sb_kernel<KS, TR, NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid((unsigned)g.PB, (unsigned)g.ncp, (unsigned)(g.ncot * g.ndyg));
+    wgrad_mfma_sb_kernel<KS, TR, NT><<<grid, dim3(256), LDS, s>>>(a);
+    BH_CHECK_LAUNCH();
+    return 0;
+}
+
 int g_wg_dbg = 0;
 int g_cus = 0;
 int cus() {
@@ -612,7 +722,7 @@ int binhip_conv2d_bwd_weight(const BinConvDesc* d, const void* x_hi, const void*
     a.cin_chunks = d->cin_chunks; a.cout_chunks = (d->cout + 15) / 16;
     a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.ntiles = g.ntiles;
     a.PB = g.PB; a.ncp = g.ncp; a.ncot = g.ncot;
-    a.dbg = g_wg_dbg;
+    a.dbg = g_wg_dbg & 15;
     hipStream_t s = (hipStream_t)stream;
     int rc = BINHIP_E_SHAPE;
     if (use_w1(d->ksize, d->cout)) {
@@ -629,6 +739,8 @@ int binhip_conv2d_bwd_weight(const BinConvDesc* d, const void* x_hi, const void*
         }
         BH_CHECK_LAUNCH();
         rc = 0;
+    } else if (d->ksize == 3 && !(g_wg_dbg & 16)) {   // default: lean 2-workgroup/CU kernel; flag 16 = the double-buffered one
+        rc = (d->nterms == 1) ? launch_wg_sb<3, 3, 1>(a, g, s) : launch_wg_sb<3, 3, 3>(a, g, s);
     } else if (d->nterms == 1) {
         if (d->ksize == 3) rc = launch_wg<3, 3, 1>(a, g, s);
         else if (d->ksize == 1) rc = launch_wg<1, 1, 1>(a, g, s);

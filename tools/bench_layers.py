@@ -125,7 +125,7 @@ def main():
             xx = ops.nchw_to_planes(torch.rand(nn_, cin, hh_, ww_, generator=gg).to(dev), nt)
             gy = ops.nchw_to_planes(torch.rand(nn_, cout, hh_, ww_, generator=gg).to(dev) - 0.5, nt)
             f = (lambda xx=xx, gy=gy, ks=ks, cin=cin, cout=cout: ops.conv2d_bwd_weight(xx, gy, cout, cin, ks, nt))
-            for dbg, nm in ((0, "full"), (1, "no DMA"), (2, "no MFMA"), (4, "no reduce/store"), (7, "nothing")):
+            for dbg, nm in ((0, "full"), (16, "full, 1 wg/CU double-buffered"), (1, "no DMA"), (2, "no MFMA"), (4, "no reduce/store"), (7, "nothing")):
                 lib.binhip_wgrad_set_debug(dbg)
                 us = time_fn(f, iters=10, warm=2)
                 print(f"wgrad k{ks} {cin}->{cout} nt={nt} {nm:16s}: {us:8.1f} us   {2*ks*ks*cin*cout*nn_*hh_*ww_*(3 if nt==3 else 1)/us/1e6:7.0f} TF-eq/s")
