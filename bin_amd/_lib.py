@@ -64,6 +64,8 @@ _SIGNATURES = {
     "binhip_dgrad_rows_pad": (C.c_int, [C.c_int, C.c_int]),
     "binhip_weights_relayout_dgrad": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                 C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "binhip_weights_relayout_rdb_gather": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                     C.c_void_p]),
     "binhip_conv2d_bwd_data": (C.c_int, [C.POINTER(BinConvDesc)] + [C.c_void_p] * 7 + [C.c_int, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p,
                                          C.c_void_p, C.c_void_p]),

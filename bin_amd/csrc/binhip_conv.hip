@@ -708,6 +708,45 @@ __global__ void relayout_dgrad_kernel(const float* __restrict__ w, int cout, int
     if (w_lo) *reinterpret_cast<half8*>(w_lo + t * 8) = lv;
 }
 
+// Backward-data of a residual dense block in GATHER form.  Group g of the block's concat buffer (g = 0: the 96 input
+// channels, g = 1..3: the 32 outputs of conv g-1) receives dgrad contributions from every later conv c >= cmin
+// (cmin = g for g >= 1, 0 for g = 0).  Stacking those convs' masked output gradients G_c (32 channels each, contiguous
+// in the gradient buffer) along K turns the sum into ONE forward-shaped conv per group:
+//   Wg[r][32 (c - cmin) + co][dy][dx] = W_c[co][base_g + r][2-dy][2-dx],   base_0 = 0, base_g = 96 + 32 (g - 1).
+struct GatherSrc { const float* w[4]; };
+__global__ void relayout_rdb_gather_kernel(GatherSrc src, int group, int rows, int nchunks, int cb,
+                                           _Float16* __restrict__ w_hi, _Float16* __restrict__ w_lo,
+                                           float* __restrict__ bias_out) {
+    const long long total = (long long)rows * nchunks * 9 * 2;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < rows) bias_out[t] = 0.f;
+    if (t >= total) return;
+    const int s = (int)(t & 1);
+    long long u = t >> 1;
+    const int row = (int)(u % cb); u /= cb;
+    const int tap = (int)(u % 9); u /= 9;
+    const int c = (int)(u % nchunks); u /= nchunks;
+    const int r = (int)u * cb + row;
+    const int cg = s ^ ((row >> 3) & 1);
+    const int dy = 2 - tap / 3, dx = 2 - tap % 3;
+    const int cmin = group;                            // group 0 and group 1.. both start at conv index == group
+    const int ci = (group == 0) ? r : 96 + 32 * (group - 1) + r;
+    const int j0 = c * 16 + cg * 8;                    // 8 consecutive K entries never straddle a conv (32 each)
+    const int conv = cmin + j0 / 32;
+    const int cin_c = 96 + 32 * conv;
+    const float* w = src.w[conv];
+    half8 hv, lv;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int co = (j0 & 31) + e;
+        const float v = w[(((long long)co * cin_c + ci) * 3 + dy) * 3 + dx];
+        hv[e] = (_Float16)v;
+        lv[e] = (_Float16)(v - (float)hv[e]);
+    }
+    *reinterpret_cast<half8*>(w_hi + t * 8) = hv;
+    if (w_lo) *reinterpret_cast<half8*>(w_lo + t * 8) = lv;
+}
+
 extern "C" {
 
 int binhip_dgrad_rows_pad(int ksize, int cin) {
@@ -729,6 +768,25 @@ int binhip_weights_relayout_dgrad(const float* w_oihw, int cout, int cin, int ks
     const long long nb = (total + 255) / 256;
     hipLaunchKernelGGL(relayout_dgrad_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, w_oihw, cout, cin,
                        ksize, rows_pad, cin_chunks, cout_block, shuffle_perm, (_Float16*)w_hi, (_Float16*)w_lo, bias_out);
+    BH_CHECK_LAUNCH();
+    return 0;
+}
+
+int binhip_weights_relayout_rdb_gather(const float* const* w_oihw4, int group, int cout_block, void* w_hi, void* w_lo,
+                                       float* bias_out, void* stream) {
+    if (!w_oihw4 || !w_hi || !bias_out || group < 0 || group > 3) return BINHIP_E_ARG;
+    const int rows = group == 0 ? 96 : 32;
+    const int nchunks = 2 * (4 - group);
+    if (cout_block <= 0 || rows % cout_block || cout_block % 32) return BINHIP_E_SHAPE;
+    GatherSrc src;
+    for (int i = 0; i < 4; ++i) {
+        src.w[i] = w_oihw4[i];
+        if (i >= group && !src.w[i]) return BINHIP_E_ARG;
+    }
+    const long long total = (long long)rows * nchunks * 9 * 2;
+    hipLaunchKernelGGL(relayout_rdb_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, src, group, rows, nchunks, cout_block, (_Float16*)w_hi, (_Float16*)w_lo,
+                       bias_out);
     BH_CHECK_LAUNCH();
     return 0;
 }

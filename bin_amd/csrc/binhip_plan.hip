@@ -284,16 +284,19 @@ int binhip_rdn_backward(const BinRdnBwdPlan* p, const void* saved, size_t saved_
         // LFF 1x1 224 -> 96 (+x): gcat = W'^T gy (+ gy on the first 6 chunks); ReLU mask of conv 3's output
         if ((rc = wgrad(L + 4, 1, h, ww, 14, 224, 96, blk, w.s_blk, 0, 0, gy, b.s_gy, 0))) return rc;
         if ((rc = dgrad(L + 4, 1, h, ww, 6, 224, gy, b.s_gy, b.gcat, b.s_gcat, gy, b.s_gy, 6, false, blk, 12, 0, 0))) return rc;
+        // The four 3x3 convs in gather form (binhip_weights_relayout_rdb_gather): every group of gcat is produced
+        // ONCE as L_g + conv(stacked G_c of the later convs) instead of being read-modified-written by each of them.
         for (int c = 3; c >= 0; --c) {
-            const int64_t gyc = b.gcat + (int64_t)(6 + 2 * c) * P;
+            const int64_t gyc = b.gcat + (int64_t)(6 + 2 * c) * P;       // G_c .. G_3, contiguous chunks
             if ((rc = wgrad(L + c, 3, h, ww, 6 + 2 * c, 96 + 32 * c, 32, blk, w.s_blk, 0, 0, gyc, b.s_gcat, 0))) return rc;
             if (c > 0) {
-                // accumulate into gcat[0 : 6+2c] in place; conv c-1's output slots (chunks 4+2c, 5+2c) get their mask
-                if ((rc = dgrad(L + c, 3, h, ww, 2, 96 + 32 * c, gyc, b.s_gcat, b.gcat, b.s_gcat, -1, 0, 0, true, blk,
-                                4 + 2 * c, 0, 0))) return rc;
+                // group c = conv c-1's output slot (chunks 4+2c, 5+2c): G_{c-1} = relu'( L_c + sum_{c' >= c} dgrad_c' )
+                const int64_t slot = b.gcat + (int64_t)(4 + 2 * c) * P;
+                if ((rc = dgrad(L + c, 3, h, ww, 2 * (4 - c), 32, gyc, b.s_gcat, slot, b.s_gcat, slot, b.s_gcat, 0, false,
+                                blk + (int64_t)(4 + 2 * c) * P, 0, 0, 0))) return rc;
             } else {
-                // conv 0: result + gcat[0:6] -> grad of the block input = GY[d] (already holds GFF.0's share when d >= 1)
-                if ((rc = dgrad(L, 3, h, ww, 2, 96, gyc, b.s_gcat, b.gy + (int64_t)d * 6 * P, b.s_gy, b.gcat, b.s_gcat, 0,
+                // group 0: L_0 + all four convs -> grad of the block input = GY[d] (already holds GFF.0's share when d >= 1)
+                if ((rc = dgrad(L, 3, h, ww, 8, 96, gyc, b.s_gcat, b.gy + (int64_t)d * 6 * P, b.s_gy, b.gcat, b.s_gcat, 0,
                                 d >= 1, -1, 0, 0, 0))) return rc;
             }
         }

@@ -52,26 +52,46 @@ class RdnWeights:
 
 
 class RdnDgradWeights:
-    """W'[ci][co][dy][dx] = W[co][ci][k-1-dy][k-1-dx] of the 66 layers in kernel layout (binhip_weights_relayout_dgrad)."""
+    """Backward-data weights of the 66 layers in kernel layout.
+
+    Plain layers: W'[ci][co][dy][dx] = W[co][ci][k-1-dy][k-1-dx] (binhip_weights_relayout_dgrad).
+    The four 3x3 convs of each residual dense block are stored in GATHER form (binhip_weights_relayout_rdb_gather):
+    slot `RDBs.d.convs.g` holds the weights that produce concat-group g of the block from the stacked output
+    gradients of convs g..3 - what binhip_rdn_backward expects (include/binhip.h, BinRdnBwdPlan)."""
 
     def __init__(self, params, n_inputs, nterms, prefix=""):
         lib = L.lib()
         self.w_hi, self.w_lo = [], []
         dev = None
-        for nm in layer_names():
-            w = params[f"{prefix}{nm}.weight"].detach().contiguous().float()
-            dev = w.device
-            cout, cin, ks, _ = w.shape
-            rows_pad = lib.binhip_dgrad_rows_pad(ks, cin)
-            cin_chunks = (cout + 15) // 16
-            cb = lib.binhip_conv_cout_block(ks, rows_pad, nterms)
-            nbytes = lib.binhip_weights_bytes(rows_pad, cin_chunks, ks)
+        names = layer_names()
+        fp32 = {nm: params[f"{prefix}{nm}.weight"].detach().contiguous().float() for nm in names}
+
+        def alloc(rows, chunks, ks):
+            nbytes = lib.binhip_weights_bytes(rows, chunks, ks)
             hi = torch.empty(nbytes // 2, dtype=torch.float16, device=dev)
             lo = torch.empty(nbytes // 2, dtype=torch.float16, device=dev) if nterms == 3 else None
-            zb = torch.empty(rows_pad, dtype=torch.float32, device=dev)
-            L.check(lib.binhip_weights_relayout_dgrad(_ptr(w), cout, cin, ks, rows_pad, cin_chunks, cb,
-                                                      1 if nm == "UPNet.0" else 0, _ptr(hi), _ptr(lo), _ptr(zb),
-                                                      _stream()), "weights_relayout_dgrad")
+            return hi, lo, torch.empty(rows, dtype=torch.float32, device=dev)
+
+        for nm in names:
+            w = fp32[nm]
+            dev = w.device
+            cout, cin, ks, _ = w.shape
+            if ".convs." in nm:
+                d, g = int(nm.split(".")[1]), int(nm.split(".")[3])
+                rows, chunks = (96, 8) if g == 0 else (32, 2 * (4 - g))
+                hi, lo, zb = alloc(rows, chunks, 3)
+                src = (C.c_void_p * 4)(*[fp32[f"RDBs.{d}.convs.{c}.conv.0"].data_ptr() for c in range(4)])
+                cb = lib.binhip_conv_cout_block(3, rows, nterms)
+                L.check(lib.binhip_weights_relayout_rdb_gather(src, g, cb, _ptr(hi), _ptr(lo), _ptr(zb), _stream()),
+                        "weights_relayout_rdb_gather")
+            else:
+                rows_pad = lib.binhip_dgrad_rows_pad(ks, cin)
+                cin_chunks = (cout + 15) // 16
+                cb = lib.binhip_conv_cout_block(ks, rows_pad, nterms)
+                hi, lo, zb = alloc(rows_pad, cin_chunks, ks)
+                L.check(lib.binhip_weights_relayout_dgrad(_ptr(w), cout, cin, ks, rows_pad, cin_chunks, cb,
+                                                          1 if nm == "UPNet.0" else 0, _ptr(hi), _ptr(lo), _ptr(zb),
+                                                          _stream()), "weights_relayout_dgrad")
             self.w_hi.append(hi)
             self.w_lo.append(lo)
         self.zero_bias = torch.zeros(1152, dtype=torch.float32, device=dev)

@@ -96,6 +96,15 @@ int binhip_dgrad_rows_pad(int ksize, int cin);   /* rows_pad the library expects
 int binhip_weights_relayout_dgrad(const float* w_oihw, int cout, int cin, int ksize, int rows_pad,
                                   int cin_chunks, int cout_block, int shuffle_perm, void* w_hi, void* w_lo,
                                   float* bias_out, void* stream);
+/* Residual dense block (RDN.py:132-165) backward-data in GATHER form.  Concat group g of a block (g = 0: its 96 input
+ * channels; g = 1..3: the 32 outputs of conv g-1) gets dgrad contributions from convs g..3 (0..3 for g = 0).  With
+ * those convs' masked output gradients stacked along K (they are contiguous in the gradient concat buffer) the sum
+ * is ONE forward-shaped conv:  Wg[r][32 (c - g) + co][dy][dx] = W_c[co][base_g + r][2-dy][2-dx]  (base_0 = 0,
+ * base_g = 96 + 32 (g - 1)); rows = 96 (g = 0) or 32, input chunks = 2 (4 - g).  Every group is then written once
+ * instead of being read-modified-written by each later conv.  w_oihw4 = HOST array of the block's four OIHW fp32
+ * device pointers (entries < group may be NULL).                                                                  */
+int binhip_weights_relayout_rdb_gather(const float* const* w_oihw4, int group, int cout_block, void* w_hi, void* w_lo,
+                                       float* bias_out, void* stream);
 int binhip_conv2d_bwd_data(const BinConvDesc* d, const void* gy_hi, const void* gy_lo,
                            const void* wt_hi, const void* wt_lo, const float* zero_bias,
                            const void* res_hi, const void* res_lo, int res_chunks,
@@ -215,7 +224,8 @@ int binhip_convlstm_bwd(const float* x, const float* c_prev, const float* h_prev
  * dw[i]/db[i]: OIHW fp32 gradients of layer i (overwritten).  gin[i]: fp32 [N,3,H,W] or NULL.           */
 typedef struct BinRdnBwdPlan {
     int32_t N, H, W, n_inputs, nterms, reserved;
-    const void* wt_hi[BINHIP_RDN_LAYERS];   /* binhip_weights_relayout_dgrad outputs                  */
+    const void* wt_hi[BINHIP_RDN_LAYERS];   /* binhip_weights_relayout_dgrad outputs; for the slots   */
+                                            /* RDBs.d.convs.g: binhip_weights_relayout_rdb_gather(g)   */
     const void* wt_lo[BINHIP_RDN_LAYERS];
     const float* zero_bias;                 /* >= 1152 zero floats                                    */
     float* dw[BINHIP_RDN_LAYERS];
