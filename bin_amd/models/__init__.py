@@ -1,6 +1,6 @@
 """Model factory with the reference's entry point (models/__init__.py:4-20): `create_model(opt)` picks the wrapper
-class from `opt['model']`.  On the bin_stage4 hot path only 'bin' exists; the reference's other names ('sr', 'srgan',
-'video_base') point at modules that are absent or un-importable there."""
+class from `opt['model']`: 'bin' (the hot path's wrapper) and 'video_base' (the single-tensor API over the same net,
+Video_base_model.py).  The reference's other names ('sr', 'srgan') point at modules that are absent there."""
 import logging
 
 _log = logging.getLogger("base")
@@ -8,7 +8,8 @@ _log = logging.getLogger("base")
 
 def _wrappers():
     from .bin_model import bin_model
-    return {"bin": bin_model}
+    from .Video_base_model import VideoBaseModel
+    return {"bin": bin_model, "video_base": VideoBaseModel}
 
 
 def create_model(opt):

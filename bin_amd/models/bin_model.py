@@ -315,10 +315,9 @@ class bin_model(BaseModel):
             b.reset()
 
     def compute_current_psnr_ssim(self, save=False, name=None, save_path=None):
-        """PSNR / SSIM of the 14 outputs vs GT through tensor2img (bin_model.py:564-589).  PNG saving needs
-        cv2, which is outside the hot path; `save=True` raises."""
-        if save:
-            raise NotImplementedError("bin_amd: PNG writing (cv2) is out of scope of the hot path")
+        """PSNR / SSIM of the 14 outputs vs GT through tensor2img (bin_model.py:564-589); save=True also writes
+        `rlt_<name>_<i>.png` / `gt_<name>_<i>.png` under save_path."""
+        import os.path as osp
         num = self.get_info()
         visuals = self.get_current_visuals()
         psnr, ssim = [], []
@@ -327,6 +326,9 @@ class bin_model(BaseModel):
             gt_img = util.tensor2img(visuals["GT"][i])
             psnr.append(util.calculate_psnr(rlt_img, gt_img))
             ssim.append(util.calculate_ssim(rlt_img, gt_img))
+            if save:
+                util.save_img(rlt_img, osp.join(save_path, "rlt_{}_{}.png".format(name, i)))
+                util.save_img(gt_img, osp.join(save_path, "gt_{}_{}.png".format(name, i)))
         return psnr, ssim
 
     # ------------------------------------------------------------------ IO

@@ -1,0 +1,250 @@
+"""Evaluate / run bin_stage4 over folders of blurry frames: the reference's test.py (with --gt_path: PSNR/SSIM of the
+interpolated and deblurred frames against the sharp ground truth) and demo.py (without) in one entry point.
+
+    python -m bin_amd.test --netName bin_stage4 --input_path DATA/test_blur --gt_path DATA/test \\
+        --output_path OUT --opt bin_amd/options/train/train_adobe_stage4.yml [--time_step 0.5]
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m bin_amd.test ... --launcher pytorch
+
+What the reference does per input frame `index` of a clip (test.py:236-402) and this keeps:
+  * the six blurry frames index + [-2..3], clamped to the clip (test.py:257-261, 333);
+  * replicate padding to the next multiple of 128, or 32 px per side when already one (test.py:348-366);
+  * outputs Ft_p[13] -> <num+8>.png (the interpolated frame), Ft_p[8] -> <num+4>.png and, except for the last
+    window, Ft_p[12] -> <num+12>.png (the deblurred frames), `num` being the frame's own file number
+    (test.py:286-293, 380-402); files that already exist are not recomputed;
+  * tensor -> image: clamp [0,1], x255, round, RGB->BGR uint8 (util.py:113-137), done on the device.
+What is different: PNG decode/encode and the metrics run on a thread pool beside the
+GPU work instead of in line; decoded frames and their padded device copies are cached across the 5-of-6 overlap of
+consecutive windows; stage-1 RDN results are reused across consecutive windows (exact); and with --launcher
+pytorch the flattened (clip, frame) window list is sharded contiguously over the ranks, per-rank metric sums being
+combined with one all-reduce at the end."""
+import argparse
+import logging
+import os
+import threading
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import torch
+
+from . import harness, ops
+from .data import util as data_util
+from .models import create_model
+from .options import options as option
+from .utils import util
+from .utils.util import AverageMeter
+
+OUT_KEYS = (13, 8, 12)         # interpolated, first deblurred, second deblurred (test.py:380-382)
+METRICS = ("interp_psnr", "interp_ssim", "interp_err", "deblur_psnr", "deblur_ssim", "blurry_psnr", "blurry_ssim")
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    p.add_argument("--netName", type=str, default="bin_stage4")
+    p.add_argument("--input_path", type=str, required=True)
+    p.add_argument("--gt_path", type=str, default=None, help="sharp frames; omit for demo mode (no metrics)")
+    p.add_argument("--output_path", type=str, required=True)
+    p.add_argument("--gpu_id", type=str, default=None)
+    p.add_argument("--time_step", type=float, default=0.5)
+    p.add_argument("--opt", type=str, required=True, help="Path to option YAML file.")
+    p.add_argument("--launcher", choices=["none", "pytorch"], default="none")
+    p.add_argument("--precision", choices=["f16", "f16x3"], default=None)
+    p.add_argument("--io_threads", type=int, default=8)
+    p.add_argument("--no_reuse", action="store_true", help="recompute the stage-1 calls shared by consecutive windows")
+    p.add_argument("--ssim", action="store_true", help="also compute SSIM (host, ~0.2 s per 720p frame)")
+    return p.parse_args(argv)
+
+
+def list_windows(input_path):
+    """[(clip, frame names, index)] for every window of every clip, in the reference's order."""
+    wins = []
+    for clip in sorted(os.listdir(input_path)):
+        frames = sorted(f for f in os.listdir(os.path.join(input_path, clip)) if data_util.is_image_file(f))
+        wins += [(clip, frames, i) for i in range(len(frames) - 1)]
+    return wins
+
+
+def output_names(frames, index):
+    """(interp, first deblur, second deblur or None) file names of window `index` (test.py:286-293, 311-312, 394)."""
+    num = int(frames[index][:-4])
+    name = lambda n: str(n).zfill(5) + ".png"
+    return name(num + 8), name(num + 4), (name(num + 12) if index < len(frames) - 2 else None)
+
+
+class _Sums:
+    """Thread-safe per-clip / total metric accumulators."""
+
+    def __init__(self):
+        self.lock = threading.Lock()
+        self.total = {k: [0.0, 0] for k in METRICS}
+        self.clips = {}
+
+    def add(self, clip, key, value):
+        with self.lock:
+            for d in (self.total, self.clips.setdefault(clip, {k: [0.0, 0] for k in METRICS})):
+                d[key][0] += float(value)
+                d[key][1] += 1
+
+
+def _score(sums, clip, kind, img_bgr, gt_path, want_ssim):
+    if gt_path is None or not os.path.exists(gt_path):
+        return
+    gt = data_util.imread_u8(gt_path)[:, :, :3]
+    sums.add(clip, kind + "_psnr", util.calculate_psnr(img_bgr, gt))
+    if kind == "interp":
+        sums.add(clip, "interp_err", np.mean(np.abs(img_bgr.astype(np.float64) - gt.astype(np.float64))))
+    if want_ssim:
+        sums.add(clip, kind + "_ssim", util.calculate_ssim(img_bgr, gt))
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    opt = option.parse(args.opt, is_train=False)
+    if args.launcher == "pytorch":
+        import torch.distributed as dist
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        if not dist.is_initialized():
+            dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+        rank, world = dist.get_rank(), dist.get_world_size()
+        opt["gpu_ids"] = [local]
+    else:
+        rank, world = 0, 1
+        if args.gpu_id is not None:
+            torch.cuda.set_device(int(args.gpu_id))
+            opt["gpu_ids"] = [int(args.gpu_id)]
+    opt["dist"] = False                      # inference needs no gradient sync; ranks only share the window list
+    if args.precision:
+        opt["network_G"]["precision"] = args.precision
+    opt = option.dict_to_nonedict(opt)
+
+    n_out = round(1 / args.time_step)
+    assert n_out == 2, "bin_stage4 interpolates the middle frame (time_step 0.5), as the reference asserts"
+    result_root = os.path.join(args.output_path, f"{n_out * 30}fps_test_results", opt["name"])
+    os.makedirs(result_root, exist_ok=True)
+    if rank == 0:
+        util.setup_logger("base", result_root, "test", screen=True, tofile=True)
+    log = logging.getLogger("base")
+
+    model = create_model(opt)
+    netG = model.netG
+    netG.eval()
+    dev = next(netG.parameters()).device
+    inner = netG.module if hasattr(netG, "module") else netG
+    reuse = (not args.no_reuse) and getattr(inner, "n_streams", 1) > 1
+    log.info("In Data: %s | model: %s | parameters: %d | ranks: %d | stage-1 reuse: %s", args.input_path,
+             opt["path"]["pretrain_model_G"], sum(p.numel() for p in netG.parameters() if p.requires_grad), world, reuse)
+
+    windows = list_windows(args.input_path)
+    begin, end = harness.shard_windows(len(windows), rank, world)
+    sums = _Sums()
+    pool = ThreadPoolExecutor(max_workers=max(2, args.io_threads))
+    copy_stream = torch.cuda.Stream(device=dev)
+    decoded, frames_dev, stage1_cache, pending = {}, {}, {}, []
+    geom = None                                        # (h, w, pads) of the current clip
+    claimed = set()
+    cur_clip, timer = None, AverageMeter()
+
+    def want(clip, frames, fid):                       # async decode, at most once per frame
+        key = (clip, fid)
+        if key not in decoded:
+            decoded[key] = pool.submit(data_util.imread_u8, os.path.join(args.input_path, clip, frames[fid]))
+        return decoded[key]
+
+    def finish(job):
+        clip, names, owned, host, done, blurry_path = job
+        done.synchronize()
+        clip_dir = os.path.join(result_root, clip)
+        for img, name, mine, kind in zip(host.numpy(), names, owned, ("interp", "deblur", "deblur")):
+            if name is None:
+                continue
+            if mine:
+                util.save_img(img, os.path.join(clip_dir, name))
+            if mine or kind == "interp":           # the reference scores a deblurred frame when it writes it
+                _score(sums, clip, kind, img, args.gt_path and os.path.join(args.gt_path, clip, name), args.ssim)
+        if args.gt_path:
+            _score(sums, clip, "blurry", data_util.imread_u8(blurry_path)[:, :, :3],
+                   os.path.join(args.gt_path, clip, names[0]), args.ssim)
+
+    t_all = time.time()
+    with torch.no_grad():
+        for wi in range(begin, end):
+            clip, frames, index = windows[wi]
+            if clip != cur_clip:
+                cur_clip = clip
+                decoded.clear(); frames_dev.clear(); stage1_cache.clear()
+                os.makedirs(os.path.join(result_root, clip), exist_ok=True)
+            names = output_names(frames, index)
+            clip_dir = os.path.join(result_root, clip)
+            # who writes what is settled here, in window order, as in the serial reference loop: <num+12> belongs to
+            # the first window that reaches it (its Ft_p[12]), the next window's Ft_p[8] of the same name is dropped
+            owned = [n is not None and (clip, n) not in claimed and not os.path.exists(os.path.join(clip_dir, n))
+                     for n in names]
+            claimed.update((clip, n) for n, mine in zip(names, owned) if mine)
+            if not any(owned) and not args.gt_path:
+                continue
+            ids = harness.window_frame_ids(index, len(frames))
+            for ahead in range(1, 4):                    # keep the decoders a few windows ahead of the GPU
+                if wi + ahead < end and windows[wi + ahead][0] == clip:
+                    for fid in harness.window_frame_ids(index + ahead, len(frames)):
+                        want(clip, frames, fid)
+            t0 = time.time()
+            batch = []
+            for fid in ids:
+                if fid not in frames_dev:
+                    img = want(clip, frames, fid).result()
+                    if img.shape[2] != 3:
+                        raise RuntimeError(f"{clip}/{frames[fid]}: expected a 3-channel image")
+                    geom = (img.shape[0], img.shape[1], util.pad_sizes(img.shape[0], img.shape[1]))
+                    frames_dev[fid] = ops.u8_to_frame(torch.from_numpy(img).to(dev, non_blocking=True), geom[2])
+                batch.append(frames_dev[fid])
+            for fid in [f for f in frames_dev if f < min(ids)]:
+                del frames_dev[fid]
+                decoded.pop((clip, fid), None)
+            (h, w), (l, r, t, b) = geom[:2], geom[2]
+            Ft_p = netG(*batch, stage1_cache=stage1_cache) if reuse else netG(*batch)
+            outs = torch.stack([ops.frame_to_u8(Ft_p[k], t, l, h, w) for k in OUT_KEYS])
+            ready = torch.cuda.Event()
+            ready.record()
+            host = torch.empty(outs.shape, dtype=torch.uint8, pin_memory=True)
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(ready)
+                host.copy_(outs, non_blocking=True)
+                outs.record_stream(copy_stream)
+                done = torch.cuda.Event()
+                done.record()
+            pending.append(pool.submit(finish, (clip, names, owned, host, done,
+                                                os.path.join(args.input_path, clip, frames[ids[3]]))))
+            while len(pending) > 8:                       # bound host memory; surfaces worker exceptions
+                pending.pop(0).result()
+            timer.update(time.time() - t0)
+        for job in pending:
+            job.result()
+    torch.cuda.synchronize()
+    wall = time.time() - t_all
+    pool.shutdown()
+
+    # ---- combine the ranks' sums (one small all-reduce) and report like test.py:466-502
+    vec = torch.tensor([v for k in METRICS for v in sums.total[k]] + [end - begin, wall], dtype=torch.float64)
+    if world > 1:
+        import torch.distributed as dist
+        vec = vec.to(dev)
+        wall_t = vec[-1:].clone()
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
+        vec[-1] = wall_t[0]
+        vec = vec.cpu()
+    if rank == 0:
+        tot = {k: (vec[2 * i].item() / max(vec[2 * i + 1].item(), 1)) for i, k in enumerate(METRICS)}
+        n_win, wall = int(vec[-2].item()), vec[-1].item()
+        if world == 1:
+            for clip, d in sums.clips.items():
+                log.info("clip %s: " % clip + " ".join(f"{k} {d[k][0] / max(d[k][1], 1):.4f}" for k in METRICS if d[k][1]))
+        log.info("Avg. testset " + " ".join(f"{k} {tot[k]:.4f}" for k in METRICS))
+        log.info("windows: %d  wall: %.2f s  -> %.2f interpolated frames/s (IO included); net+glue per window %.4f s",
+                 n_win, wall, n_win / max(wall, 1e-9), timer.avg)
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -1,6 +1,8 @@
 """Host helpers of the evaluation harness (counterparts of reference utils/util.py:113-137, 201-231,
 utils/AverageMeter.py and the padding rule of test.py:348-366).  Pure numpy/torch host code."""
+import logging
 import math
+import os
 
 import numpy as np
 import torch
@@ -103,3 +105,112 @@ def pad_sizes(h, w):
 def replicate_pad(x, pads):
     """torch.nn.ReplicationPad2d([l, r, t, b]) (test.py:368-371)."""
     return torch.nn.functional.pad(x, list(pads), mode="replicate")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# run bookkeeping used by the train / test scripts (reference utils/util.py:43-111, 140-142)
+def get_timestamp():
+    from datetime import datetime
+    return datetime.now().strftime("%y%m%d-%H%M%S")
+
+
+def mkdir(path):
+    os.makedirs(path, exist_ok=True)
+
+
+def mkdirs(paths):
+    for p in ([paths] if isinstance(paths, str) else paths):
+        mkdir(p)
+
+
+def mkdir_and_rename(path):
+    """A fresh experiment directory; an existing one is kept under `<path>_archived_<timestamp>`."""
+    if os.path.exists(path):
+        archived = f"{path}_archived_{get_timestamp()}"
+        logging.getLogger("base").info("Path already exists. Rename it to [%s]", archived)
+        os.rename(path, archived)
+    os.makedirs(path)
+
+
+def set_random_seed(seed):
+    import random
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+def setup_logger(logger_name, root, phase, level=logging.INFO, screen=False, tofile=False):
+    """Named logger with the reference's line format; `<root>/<phase>_<timestamp>.log` when tofile."""
+    lg = logging.getLogger(logger_name)
+    fmt = logging.Formatter("%(asctime)s.%(msecs)03d - %(levelname)s: %(message)s", datefmt="%y-%m-%d %H:%M:%S")
+    lg.setLevel(level)
+    if tofile:
+        fh = logging.FileHandler(os.path.join(root, f"{phase}_{get_timestamp()}.log"), mode="w")
+        fh.setFormatter(fmt)
+        lg.addHandler(fh)
+    if screen:
+        sh = logging.StreamHandler()
+        sh.setFormatter(fmt)
+        lg.addHandler(sh)
+    return lg
+
+
+def crop_border(img_list, border):
+    """Drop `border` pixels from each side of every HWC image."""
+    if border == 0:
+        return img_list
+    return [v[border:-border, border:-border] for v in img_list]
+
+
+def save_img(img, img_path, mode="RGB"):
+    """Write an HWC uint8 image in cv2's channel order (BGR), as cv2.imwrite would (PNG/JPEG by extension)."""
+    from PIL import Image
+    img = np.asarray(img)
+    if img.ndim == 3 and img.shape[2] == 3:
+        img = img[:, :, ::-1]
+    elif img.ndim == 3 and img.shape[2] == 1:
+        img = img[:, :, 0]
+    Image.fromarray(np.ascontiguousarray(img)).save(img_path, compress_level=1)
+
+
+class ProgressBar:
+    """Two-line console progress bar (reference utils/util.py:255-302): bar + counts, then a message."""
+
+    def __init__(self, task_num=0, bar_width=50, start=True):
+        import shutil
+        cols = shutil.get_terminal_size().columns
+        self.task_num = task_num
+        self.bar_width = max(10, min(bar_width, min(int(cols * 0.6), cols - 50)))
+        self.completed = 0
+        if start:
+            self.start()
+
+    def start(self):
+        import sys
+        import time
+        if self.task_num > 0:
+            sys.stdout.write("[{}] 0/{}, elapsed: 0s, ETA:\nStart...\n".format(" " * self.bar_width, self.task_num))
+        else:
+            sys.stdout.write("completed: 0, elapsed: 0s")
+        sys.stdout.flush()
+        self.start_time = time.time()
+
+    def update(self, msg="In progress..."):
+        import sys
+        import time
+        self.completed += 1
+        elapsed = max(time.time() - self.start_time, 1e-9)
+        rate = self.completed / elapsed
+        if self.task_num > 0:
+            frac = self.completed / float(self.task_num)
+            eta = int(elapsed * (1 - frac) / frac + 0.5)
+            done = int(self.bar_width * frac)
+            sys.stdout.write("\033[2F\033[J[{}] {}/{}, {:.1f} task/s, elapsed: {}s, ETA: {:5}s\n{}\n".format(
+                ">" * done + "-" * (self.bar_width - done), self.completed, self.task_num, rate, int(elapsed + 0.5),
+                eta, msg))
+        else:
+            sys.stdout.write("completed: {}, elapsed: {}s, {:.1f} tasks/s".format(self.completed, int(elapsed + 0.5),
+                                                                                 rate))
+        sys.stdout.flush()

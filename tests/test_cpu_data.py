@@ -1,0 +1,316 @@
+"""CPU host-logic tests of the rows SURVEY.md §8f marks "next": data pipeline + sampler (N2), option parsing /
+training loop / checkpoints (N4) and the single-tensor wrapper (row a17), against tests/golden/g7_host.json
+(generated from the reference by tests/golden/make_golden_host.py)."""
+import json
+import os
+import random
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO
+from host_fixtures import OPTION_YML, make_adobe_tree
+
+G7 = json.load(open(os.path.join(REPO, "tests", "golden", "g7_host.json")))
+
+
+# ------------------------------------------------------------------ sampler
+def test_dist_iter_sampler_matches_reference():
+    from bin_amd.data.data_sampler import DistIterSampler
+    for c in G7["sampler"]:
+        n, world, rank, ratio, epoch = c["case"]
+        s = DistIterSampler(list(range(n)), world, rank, ratio)
+        s.set_epoch(epoch)
+        assert len(s) == c["len"]
+        assert list(iter(s)) == c["indices"]
+    with pytest.raises(RuntimeError):
+        DistIterSampler([0, 1])                        # no process group, no explicit rank/world
+
+
+def test_sampler_ranks_partition_the_epoch():
+    from bin_amd.data.data_sampler import DistIterSampler
+    parts = []
+    for r in range(4):
+        s = DistIterSampler(list(range(10)), 4, r, ratio=6)
+        s.set_epoch(2)
+        parts.append(list(iter(s)))
+    flat = sorted(v for p in parts for v in p)
+    assert len(flat) == 60 and all(flat.count(v) == 6 for v in range(10))
+
+
+# ------------------------------------------------------------------ dataset
+@pytest.fixture(scope="module")
+def adobe(tmp_path_factory):
+    return make_adobe_tree(str(tmp_path_factory.mktemp("adobe")))
+
+
+def test_window_list_matches_reference(adobe):
+    from bin_amd.data.BIN_dataset import make_window_list
+    kept, rest = make_window_list(adobe, mode="train", shuffle=False)
+    assert rest == []
+    rel = lambda p: os.path.relpath(p, adobe)
+    mine = sorted(([[rel(p) for p in w[0]], [rel(p) for p in w[1]], [rel(p) for p in w[2]], w[3]] for w in kept),
+                  key=lambda w: w[3])
+    assert mine == G7["windows"]
+    # clipA: 9 blurry frames -> 4 windows, the one touching the unlisted last frame is dropped; clipB: 7 -> 2
+    assert [w[3] for w in mine] == ["clipA_00016", "clipA_00024", "clipA_00032", "clipB_00000", "clipB_00008"]
+    random.seed(3)
+    a, b = make_window_list(adobe, mode="train", split=60)
+    assert len(a) == 3 and len(b) == 2 and sorted(w[3] for w in a + b) == [w[3] for w in mine]
+
+
+def test_loader_draws_match_reference(adobe):
+    from bin_amd.data.BIN_dataset import make_window_list, load_window, BINDataset
+    kept, _ = make_window_list(adobe, mode="train", shuffle=False)
+    win = sorted(kept, key=lambda w: w[3])[1]
+    for ref in G7["loader"]:
+        random.seed(ref["seed"])
+        LQs, GTenh, GTinp, key = load_window(win, input_frame_size=(3, 64, 96))
+        arrs = [np.stack(x, 0) for x in (LQs, GTenh, GTinp)]
+        assert key == ref["key"]
+        assert [list(a.shape) for a in arrs] == ref["shapes"]
+        for a, s, f, l in zip(arrs, ref["sums"], ref["first"], ref["last"]):
+            assert a.dtype == np.float32
+            assert float(a.astype(np.float64).sum()) == s                  # same crop, flip and order, bit for bit
+            assert a[0, 0, 0, :].astype(float).tolist() == f and a[-1, -1, -1, :].astype(float).tolist() == l
+    # the facade keeps the reference's name and argument order
+    random.seed(1)
+    again = BINDataset.Adobe_BIN_loader(win, (3, 64, 96))
+    random.seed(1)
+    assert np.array_equal(np.stack(again[0]), np.stack(load_window(win, (3, 64, 96))[0]))
+
+
+def test_dataset_items_and_loader(adobe):
+    from bin_amd.data import create_dataset, create_dataloader
+    random.seed(0)
+    ds = create_dataset({"mode": "BIN", "name": "train", "dataroot_GT": adobe, "dataroot_LQ": adobe,
+                         "LQ_size": [3, 32, 48], "data_type": "img", "phase": "train"})
+    assert len(ds) == 5
+    item = ds[0]
+    assert item["LQs"].shape == (6, 3, 32, 48) and item["GTenh"].shape == (6, 3, 32, 48)
+    assert item["GTinp"].shape == (5, 3, 32, 48) and item["LQs"].dtype == torch.float32
+    assert 0.0 <= float(item["LQs"].min()) and float(item["LQs"].max()) <= 1.0
+    loader = create_dataloader(ds, {"phase": "train", "batch_size": 2, "n_workers": 0}, {"dist": False, "gpu_ids": [0]})
+    batches = list(loader)
+    assert len(batches) == 2 and batches[0]["LQs"].shape == (2, 6, 3, 32, 48)       # drop_last
+    val = create_dataloader(ds, {"phase": "val"}, {"dist": False}, vscode_debug=True)
+    assert len(list(val)) == 5
+    with pytest.raises(NotImplementedError):
+        create_dataset({"mode": "REDS", "name": "x"})
+
+
+def test_image_io_helpers(tmp_path):
+    from bin_amd.data import util as du
+    from bin_amd.utils import util
+    g = np.random.Generator(np.random.PCG64(0))
+    bgr = g.integers(0, 256, (9, 7, 3), dtype=np.uint8)
+    p = str(tmp_path / "a.png")
+    util.save_img(bgr, p)
+    assert np.array_equal(du.imread_u8(p), bgr)                              # BGR in, BGR out, like cv2
+    f = du.read_img(p)
+    assert f.dtype == np.float32 and np.allclose(f, bgr / 255.0)
+    grey = g.integers(0, 256, (5, 4, 1), dtype=np.uint8)
+    util.save_img(grey, str(tmp_path / "g.png"))
+    assert du.read_img(str(tmp_path / "g.png")).shape == (5, 4, 1)
+    seq = du.read_img_seq([p, p])
+    assert seq.shape == (2, 3, 9, 7) and torch.allclose(seq[0], torch.from_numpy(bgr[:, :, ::-1].copy()).permute(2, 0, 1) / 255.0)
+    assert du.is_image_file("x.PNG") and not du.is_image_file("x.txt")
+    paths, sizes = du.get_image_paths("img", str(tmp_path))
+    assert [os.path.basename(q) for q in paths] == ["a.png", "g.png"] and sizes is None
+    random.seed(4)
+    draws = [random.random() < 0.5 for _ in range(3)]
+    random.seed(4)
+    out = du.augment([bgr], hflip=True, rot=True)[0]
+    want = bgr[:, ::-1] if draws[0] else bgr
+    want = want[::-1] if draws[1] else want
+    want = want.transpose(1, 0, 2) if draws[2] else want
+    assert np.array_equal(out, want)
+
+
+# ------------------------------------------------------------------ options
+def _norm(o):
+    return json.loads(json.dumps(o))
+
+
+def test_options_parse_matches_reference(tmp_path, monkeypatch):
+    from bin_amd.options import options as option
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setenv("CUDA_VISIBLE_DEVICES", "")
+    yml = tmp_path / "o.yml"
+    yml.write_text(OPTION_YML)
+    assert _norm(option.parse(str(yml), is_train=True)) == G7["options_train"]
+    assert os.environ["CUDA_VISIBLE_DEVICES"] == "0"
+    t = option.parse(str(yml), is_train=False)
+    assert _norm(t) == G7["options_test"]
+    assert option.dict2str(_norm(t)) == G7["dict2str"]
+    nd = option.dict_to_nonedict(t)
+    assert nd["train"]["T_period"] is None and nd["nope"] is None and nd["train"]["lr_steps"] == [4, 8]
+    # one process per GPU: the launcher owns device visibility
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    monkeypatch.setenv("CUDA_VISIBLE_DEVICES", "3")
+    option.parse(str(yml), is_train=True)
+    assert os.environ["CUDA_VISIBLE_DEVICES"] == "3"
+
+
+def test_check_resume():
+    from bin_amd.options import options as option
+    opt = {"model": "bin", "path": {"resume_state": "/x/5.state", "models": "/m", "pretrain_model_G": "/w.pth"}}
+    option.check_resume(opt, 5)
+    assert opt["path"]["pretrain_model_G"] == os.path.join("/m", "5_G.pth")
+    opt = {"model": "bin", "path": {"resume_state": None, "models": "/m", "pretrain_model_G": "/w.pth"}}
+    option.check_resume(opt, 5)
+    assert opt["path"]["pretrain_model_G"] == "/w.pth"
+
+
+# ------------------------------------------------------------------ wrappers on a tiny stand-in generator
+class TinyNet(torch.nn.Module):
+    """6 frames -> 14 frames, pointwise (1x1 conv of the frame mix): fast on CPU, exact under tiling."""
+
+    def __init__(self):
+        super().__init__()
+        self.mix = torch.nn.Conv2d(18, 42, 1)
+        self.prev_state = self.hidden_state = None
+
+    def forward(self, *frames):
+        y = self.mix(torch.cat(frames, 1))
+        return tuple(y[:, 3 * i:3 * i + 3] for i in range(14))
+
+
+class _Cb(torch.nn.Module):
+    def forward(self, x, y):
+        return torch.sqrt((x - y) ** 2 + 1e-6).mean()
+
+
+def _vopt(tmp):
+    return {"model": "video_base", "gpu_ids": None, "is_train": True, "dist": False,
+            "network_G": {"which_model_G": "bin_stage4", "nframes": 6, "version": 2},
+            "path": {"pretrain_model_G": None, "strict_load": True, "models": str(tmp), "training_state": str(tmp)},
+            "train": {"pixel_criterion": "cb", "pixel_weight": 1.0, "lr_G": 1e-3, "beta1": 0.9, "beta2": 0.99,
+                      "lr_scheme": "MultiStepLR", "lr_steps": [100], "lr_gamma": 0.5}}
+
+
+def test_video_base_model_surface(tmp_path):
+    from bin_amd.models.Video_base_model import VideoBaseModel
+    torch.manual_seed(0)
+    m = VideoBaseModel(_vopt(tmp_path), netG=TinyNet(), cri_pix=_Cb())
+    data = {"LQs": torch.rand(2, 6, 3, 40, 56), "GT": torch.rand(2, 14, 3, 40, 56)}
+    m.feed_data(data)
+    before = float(m.get_loss()) if hasattr(m, "fake_H") else None
+    losses = []
+    for step in range(1, 6):
+        m.optimize_parameters(step)
+        losses.append(m.get_current_log()["l_pix"])
+    assert before is None and losses[-1] < losses[0]
+    m.test()
+    full = m.fake_H.clone()
+    assert full.shape == (2, 14, 3, 40, 56)
+    m.test_stitch(tile_hw=(16, 32), halo=8)                  # ragged: 40 = 2.5 tiles, 56 = 1.75 tiles
+    assert m.fake_H.shape == full.shape and torch.allclose(m.fake_H, full, atol=1e-6)
+    vis = m.get_current_visuals(save=True, name="v", save_path=str(tmp_path))
+    assert vis["LQ"].shape == (6, 3, 40, 56) and vis["rlt"].shape == (14, 3, 40, 56) and vis["GT"].shape == (14, 3, 40, 56)
+    assert (tmp_path / "v.png").exists()
+    m.save(7)
+    m2 = VideoBaseModel({**_vopt(tmp_path), "path": {**_vopt(tmp_path)["path"],
+                                                       "pretrain_model_G": str(tmp_path / "7_G.pth")}},
+                        netG=TinyNet(), cri_pix=_Cb())
+    for a, b in zip(m.netG.parameters(), m2.netG.parameters()):
+        assert torch.equal(a, b)
+    from bin_amd.models import _wrappers
+    assert _wrappers()["video_base"] is VideoBaseModel
+
+
+# ------------------------------------------------------------------ the training loop (bin_amd.train) on CPU
+def _train_yml(tmp, adobe, resume=None, niter=6):
+    y = OPTION_YML.replace("~/data/adobe", adobe).replace("/tmp/bin_amd_runs", str(tmp))
+    y = y.replace("pretrain_model_G: ~/w/adobe_bin.pth", "pretrain_model_G: ~")
+    y = y.replace("mode: BIN_mc", "mode: BIN").replace("/data/val.lmdb", adobe).replace("/data/val", adobe)
+    y = y.replace("name: test", "name: train")             # validate on the same tiny tree
+    y = y.replace("save_checkpoint_freq: !!float 5000", "save_checkpoint_freq: 3")
+    y = y.replace("print_freq: 100", "print_freq: 2").replace("val_freq: !!float 5e3", "val_freq: 4")
+    y = y.replace("niter: 6", f"niter: {niter}\n  val_max_batches: 1\n  val_save_images: 1")
+    if resume:
+        y = y.replace("resume_state: ~", f"resume_state: {resume}")
+    p = os.path.join(str(tmp), "train.yml" if not resume else "resume.yml")
+    open(p, "w").write(y)
+    return p
+
+
+def _tiny_factory(opt):
+    from bin_amd.models.bin_model import bin_model
+    torch.manual_seed(11)
+    opt["gpu_ids"] = None                                   # BaseModel: no gpu ids -> cpu (reference base_model.py:11)
+    return bin_model(opt, netG=TinyNet(), cri_pix=_Cb())
+
+
+def test_train_loop_checkpoints_and_resume(tmp_path, adobe, monkeypatch):
+    from bin_amd import train
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setenv("CUDA_VISIBLE_DEVICES", "")
+    assert train.main(["-opt", _train_yml(tmp_path, adobe)], model_factory=_tiny_factory) == 0
+    exp = tmp_path / "experiments" / "debug_host"          # 'debug' in the name: freqs forced to 1 by parse()
+    models = sorted(os.listdir(exp / "models"))
+    assert "latest_G.pth" in models and "6_G.pth" in models and "3_G.pth" in models
+    assert (exp / "training_state" / "3.state").exists()
+    logs = [f for f in os.listdir(exp) if f.endswith(".log")]
+    text = open(exp / logs[0]).read()
+    assert "<epoch:" in text and "<val iter:" in text and "End of training." in text
+    assert any(f.startswith("rlt_") for f in os.listdir(exp / "val_images" / "1"))
+    # resume from iteration 3: continues at 4, ends at 6, the LR follows MultiStepLR([4, 8]) from the restored state
+    state = torch.load(exp / "training_state" / "3.state", weights_only=False)
+    assert state["iter"] == 3
+    for h in list(__import__("logging").getLogger("base").handlers):
+        __import__("logging").getLogger("base").removeHandler(h)
+    assert train.main(["-opt", _train_yml(tmp_path, adobe, resume=str(exp / "training_state" / "3.state"))],
+                      model_factory=_tiny_factory) == 0
+    logs2 = sorted(f for f in os.listdir(exp) if f.endswith(".log"))
+    text2 = "".join(open(exp / f).read() for f in logs2)
+    assert "Resuming training from epoch" in text2 and "iter:       4" in text2.replace("iter:       4,", "iter:       4")
+    final = torch.load(exp / "models" / "6_G.pth", weights_only=False)
+    assert set(final) == set(TinyNet().state_dict())
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dist_worker(rank, world, port, yml, q):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    import test_cpu_data as T
+    from bin_amd import train
+    captured = {}
+
+    def factory(opt):
+        captured["m"] = T._tiny_factory(opt)
+        return captured["m"]
+
+    rc = train.main(["-opt", yml, "--launcher", "pytorch", "--max_iter", "3"], model_factory=factory)
+    q.put((rank, rc, [p.detach().double().sum().item() for p in captured["m"].netG.parameters()]))
+    torch.distributed.destroy_process_group()
+
+
+def test_train_loop_world2_gloo(tmp_path, adobe):
+    import torch.multiprocessing as mp
+    yml = _train_yml(tmp_path, adobe)
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dist_worker, args=(r, 2, port, yml, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][1] == 0 and got[1][1] == 0
+    assert got[0][2] == got[1][2]                            # ranks hold identical parameters after 3 DP steps
