@@ -108,11 +108,12 @@ def lib():
     """Load libbinhip.so (once).  Raises RuntimeError with the build hint when it is absent."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("BIN_AMD_LIB", LIB_PATH)      # developer knob: tools/ experiments load side builds
+        if not os.path.exists(path):
             raise RuntimeError(
                 f"bin_amd: HIP library {LIB_PATH} not built. Run `python -c 'import __graft_entry__ as g; "
                 f"g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback by design.")
-        h = C.CDLL(LIB_PATH)
+        h = C.CDLL(path)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(h, name)
             fn.restype = res

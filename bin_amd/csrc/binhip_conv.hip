@@ -48,7 +48,7 @@ struct ConvKArgs {
     int xcd_remap;
     int wt;                   // write-through (sc1) output stores
     int och_limit;            // output chunks that exist at the destination (rows beyond are padding: not stored)
-    int dbg;                  // ablation switches (timing experiments only): 1 skip weight DMA, 2 skip patch DMA, 4 skip MFMA
+    int dbg;                  // ablation switches (timing experiments only): 1 skip weight DMA, 2 skip patch DMA, 4 skip MFMA, 8 skip epilogue, 16 empty
     int res_chunks;           // residual r applies to output chunks < res_chunks
     int mask_from;            // mask applies to output chunks >= mask_from (when m_hi != null)
     int y_cpg;                // output chunk grouping (<=0: one group)
@@ -73,12 +73,34 @@ struct ConvCfg {
     static constexpr int NPJ = (PP + NW - 1) / NW;
     static constexpr int NWJ = (WP + NW - 1) / NW;
     static constexpr int PS = NPL * KC * (NPJ + NWJ);    // DMA instructions per wave per full stage
-    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+    static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 waves per workgroup");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     static_assert(NBUF <= 2 || (NBUF - 2) * PS <= 63, "vmcnt immediate range");
 };
 
-__device__ __forceinline__ half8 lds_ld8(const char* p) { return *reinterpret_cast<const half8*>(p); }
+// BINHIP_ABLATE (tools/ablate_kloop.py builds side libraries with it; 0 in the product): timing-only variants of the
+// K-loop — 1 no MFMA (fragment loads kept alive), 2 no fragment loads (MFMA on undefined registers), 3 no per-stage
+// barrier, 4 no DMA instructions.  Results are garbage by construction.
+#ifndef BINHIP_ABLATE
+#define BINHIP_ABLATE 0
+#endif
+__device__ __forceinline__ half8 lds_ld8(const char* p) {
+#if BINHIP_ABLATE == 2
+    half8 v;
+    asm volatile("" : "=v"(v));
+    return v;
+#else
+    return *reinterpret_cast<const half8*>(p);
+#endif
+}
+__device__ __forceinline__ floatx16 mfma16(half8 a, half8 b, floatx16 c) {
+#if BINHIP_ABLATE == 1
+    asm volatile("" ::"v"(a), "v"(b));
+    return c;
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
+}
 
 // 16-byte plane store.  wt != 0: write-through (sc1) so the XCD's L2 holds no dirty output lines at the end of the
 // kernel: the kernel-boundary release then has nothing to write back (MI355X: 8 XCDs with private, mutually
@@ -99,8 +121,7 @@ __device__ __forceinline__ void store16(_Float16* base, long long off_elems, uin
 // whole stages; surplus lanes read out of range (zero fill, no memory traffic) into a dummy 1-KiB LDS area.
 template <class C, int KS, int KC>
 __device__ __forceinline__ void issue_stage(const ConvKArgs& a, char* smem, int st, int buf, int wave, int lane, int z,
-                                            const unsigned (&voff)[C::NPJ], long long plane_elems,
-                                            unsigned plane_bytes) {
+                                            const unsigned* voff, long long plane_elems, unsigned plane_bytes) {
     char* bbase = smem + buf * C::BUF_BYTES;
     char* dummy = smem + (C::LDS_BYTES - 1024);
     const int nchunks = a.nchunks;
@@ -155,8 +176,7 @@ __device__ __forceinline__ void load_frags(const char* bbase, int kc, int dx, in
     const char* wb = pb + C::PP * 1024 + wm * (MT * 32 * 32);
 #pragma unroll
     for (int rr = 0; rr < R + KS - 1; ++rr) {
-        const int p = b_lane_p + rr * C::PW + dx;
-        const int off = p * 32 + ((kg ^ ((p >> 3) & 1)) << 4);
+        const int off = (kg * (C::PH * C::PW) + b_lane_p) * 16 + (rr * C::PW + dx) * 16;
         Bh[rr] = lds_ld8(pb + off);
         if constexpr (NT == 3) Bl[rr] = lds_ld8(pb + C::PLANE_BYTES + off);
     }
@@ -209,10 +229,10 @@ __device__ __forceinline__ void compute_stage(const char* smem, int st, int buf,
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         if constexpr (NT == 3) {
-                            acc[mt][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[s & (NSET - 1)][dy][mt], Bh[s & (NSET - 1)][r + dy], acc[mt][r], 0, 0, 0);
-                            acc[mt][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[s & (NSET - 1)][dy][mt], Bl[s & (NSET - 1)][r + dy], acc[mt][r], 0, 0, 0);
+                            acc[mt][r] = mfma16(Al[s & (NSET - 1)][dy][mt], Bh[s & (NSET - 1)][r + dy], acc[mt][r]);
+                            acc[mt][r] = mfma16(Ah[s & (NSET - 1)][dy][mt], Bl[s & (NSET - 1)][r + dy], acc[mt][r]);
                         }
-                        acc[mt][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[s & (NSET - 1)][dy][mt], Bh[s & (NSET - 1)][r + dy], acc[mt][r], 0, 0, 0);
+                        acc[mt][r] = mfma16(Ah[s & (NSET - 1)][dy][mt], Bh[s & (NSET - 1)][r + dy], acc[mt][r]);
                     }
             if constexpr (PIPE) __builtin_amdgcn_sched_barrier(0);
         }
@@ -233,6 +253,7 @@ conv_mfma_kernel(const ConvKArgs a) {
     const int n = lane & 31;     // pixel column (B/N index) and cout row (A/M index) of this lane
     const int kg = lane >> 5;    // which 8-channel half of the 16-channel chunk
 
+    if (a.dbg & 16) return;      // timing experiments: empty kernel (launch + boundary only)
     int bid = blockIdx.x;
     if (a.xcd_remap) {
         // consecutive workgroup ids land on different XCDs (private L2s): give each XCD a contiguous band of tiles
@@ -256,13 +277,15 @@ conv_mfma_kernel(const ConvKArgs a) {
     for (int j = 0; j < C::NPJ; ++j) {
         const int i = wave + C::NW * j;
         const int q = i * 64 + lane;          // 16-byte slot index in the LDS patch image
-        const int p = q >> 1;                 // patch pixel
-        const int s = q & 1;                  // slot within the pixel
+        // image = [channel half cg][patch pixel p][16 B]: a 16-lane ds_read_b128 group reads 16 consecutive pixels of
+        // one half = 256 contiguous bytes (every bank once), and a fragment address is ONE per-lane base + an
+        // immediate (row, dx) offset
+        const int cg = q >= C::PH * C::PW ? 1 : 0;
+        const int p = q - cg * (C::PH * C::PW);
         const int py = p / C::PW;
         const int px = p - py * C::PW;
         const int gy = ty0 + py - C::PAD;
         const int gx = tx0 + px - C::PAD;
-        const int cg = s ^ ((p >> 3) & 1);    // swizzle: slot s of pixel p holds channel group cg
         const bool ok = (p < C::PH * C::PW) && (gy >= 0) && (gy < H) && (gx >= 0) && (gx < W);
         voff[j] = ok ? (unsigned)((((long long)img * H + gy) * W + gx) * 32 + cg * 16) : 0x80000000u;
     }
@@ -285,7 +308,7 @@ conv_mfma_kernel(const ConvKArgs a) {
         const int nfull = nchunks / KC;       // stages that issue the full C::PS instructions per wave
 #pragma unroll
         for (int s0 = 0; s0 < NBUF - 1; ++s0)
-            if (s0 < nst) issue_stage<C, KS, KC>(a, smem, s0, s0, wave, lane, z, voff, plane_elems, plane_bytes);
+            if (s0 < nst && BINHIP_ABLATE != 4) issue_stage<C, KS, KC>(a, smem, s0, s0, wave, lane, z, voff, plane_elems, plane_bytes);
         int cur = 0, nxt = NBUF - 1;
         for (int st = 0; st < nst; ++st) {
             // younger full-size stages still allowed in flight while stage st must have landed
@@ -294,10 +317,14 @@ conv_mfma_kernel(const ConvKArgs a) {
             if (NBUF >= 4 && yf >= 2) wait_vmcnt<(NBUF >= 4 ? 2 : 0) * C::PS>();
             else if (NBUF >= 3 && yf >= 1) wait_vmcnt<(NBUF >= 3 ? 1 : 0) * C::PS>();
             else wait_vmcnt<0>();
+#if BINHIP_ABLATE != 3
             __builtin_amdgcn_s_barrier();
+#endif
             __builtin_amdgcn_sched_barrier(0);
+#if BINHIP_ABLATE != 4
             if (st + NBUF - 1 < nst)
                 issue_stage<C, KS, KC>(a, smem, st + NBUF - 1, nxt, wave, lane, z, voff, plane_elems, plane_bytes);
+#endif
             compute_stage<C, KS, MT, R, KC, NT>(smem, st, cur, nchunks, wm, a_lane_off, b_lane_p, kg, acc);
             cur = (cur + 1 == NBUF) ? 0 : cur + 1;
             nxt = (nxt + 1 == NBUF) ? 0 : nxt + 1;
@@ -317,6 +344,7 @@ conv_mfma_kernel(const ConvKArgs a) {
     // channels of one pixel per g, and lanes n / n+32 hold the two halves of each 8-channel slot.  One
     // v_permlane32_swap per dword turns a (g even, g odd) pair into full 16-byte slots — lanes 0-31 get slot 0, lanes
     // 32-63 slot 1 of the same pixel — so every store instruction writes 32 pixels x 32 B = 1 KiB contiguous.
+    if (a.dbg & 8) { if (acc[0][0][0] == 12345.f) a.y_hi[0] = (_Float16)1.f; return; }   // timing: no epilogue
     const int gx = tx0 + n;
     if constexpr (EPI == BINHIP_EPI_FINAL) {
 #pragma unroll
@@ -586,6 +614,7 @@ static int bh_dispatch_conv(const ConvKArgs& a0, int k, int cp, int nt, int e, h
                 case 9: return launch_cfg<3, 1, 1, 2, 8, 1, 1, 3, P>(a, cp, s);
                 case 10: return launch_cfg<3, 1, 1, 3, 4, 1, 1, 3, P>(a, cp, s);   // 12x32 tile, depth 3, 73 KB -> 2 wg/CU
                 case 11: return launch_cfg<3, 1, 1, 2, 4, 1, 1, 4, P>(a, cp, s);   // 8x32 tile, depth 4, 81 KB
+                case 12: return launch_cfg<3, 1, 1, 2, 16, 1, 1, 2, P>(a, cp, s);  // 16 waves, 32x32 tile, 1 wg/CU: weights once per CU
                 case 0: return launch_cfg<3, 1, 1, 4, 4, 1, 1, 2, P>(a, cp, s);
                 default: return launch_cfg<3, 1, 1, 2, 8, 1, 1, 2, P>(a, cp, s);     // 8 waves x 2 rows, 16x32 tile
             }

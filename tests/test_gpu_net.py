@@ -84,6 +84,40 @@ def test_padded_window_vs_oracle_and_psnr(prec, canon_cpu):
         assert abs(util.calculate_psnr(img_h, target) - util.calculate_psnr(img_o, target)) <= 0.01
 
 
+_ORACLE_AT = {}
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "f16"])
+@pytest.mark.parametrize("hw", [(256, 256), (256, 448)], ids=["config0_demo_256", "config4_vimeo_256x448"])
+def test_baseline_config_sizes_vs_oracle(hw, prec, canon_cpu):
+    """BASELINE.json configs 0 (demo.py 256x256 window -> padded 320x320) and 4 (Vimeo septuplet frame size 448x256 ->
+    padded 320x512) at their FULL sizes against the oracle (one CPU forward per size, shared by both precisions):
+    all 14 outputs within the 1e-3 bar, the three outputs test.py writes within 0.01 dB PSNR after tensor2img."""
+    from bin_amd.utils import util
+    from bin_amd.weights import synthetic_frames
+    from oracle import rdn_oracle as O
+    h, w = hw
+    frames = synthetic_frames(1234, 1, h, w, 6)
+    pads = util.pad_sizes(h, w)
+    padded = [util.replicate_pad(f, pads) for f in frames]
+    assert padded[0].shape[-2:] == {(256, 256): (320, 320), (256, 448): (320, 512)}[hw]
+    if hw not in _ORACLE_AT:
+        torch.set_num_threads(max(1, min(16, (torch.get_num_threads() or 1))))
+        with torch.no_grad():
+            _ORACLE_AT[hw] = O.bin_stage4_forward(padded, canon_cpu)
+    ref = _ORACLE_AT[hw]
+    with torch.no_grad():
+        out = _net(prec)(*[p.cuda() for p in padded])
+    l, r, t, b = pads
+    target = util.tensor2img(frames[3][0])
+    for idx in range(14):
+        assert float((out[idx].cpu() - ref[idx]).abs().max()) <= TOL[prec], idx
+    for idx in (13, 8, 12):
+        img_h = util.tensor2img(out[idx][0])[t:t + h, l:l + w]
+        img_o = util.tensor2img(ref[idx][0])[t:t + h, l:l + w]
+        assert abs(util.calculate_psnr(img_h, target) - util.calculate_psnr(img_o, target)) <= 0.01
+
+
 def test_full_720p_properties():
     """BASELINE config 2 at full size (6 x [1,3,720,1280] -> padded 768x1344): size-independent
     properties instead of a CPU oracle run (65 s): (i) finite, (ii) a 128x256 interior crop processed

@@ -53,7 +53,7 @@ def main():
     for cin in (96, 192):
         cw = wts(32, cin, 3)
         out = ops.CP.empty(2, n, h, w, nt, dev)
-        cases.append((0, f"RDB conv3x3 {cin}->32 +ReLU", [0, -1, 8, 10, 11, 6] if nt == 1 else [0, 1, 2, 3],
+        cases.append((0, f"RDB conv3x3 {cin}->32 +ReLU", [0, -1, 12, 3] if nt == 1 else [0, -1, 12],
                       (lambda cw=cw, cin=cin, out=out: ops.conv2d(x224, cw, relu=True, out=out, cin_chunks=cin // 16)),
                       2 * 9 * cin * 32 * px, (cin + 32) * bpe * px, out))
     cw = wts(96, 224, 1)
@@ -135,12 +135,23 @@ def main():
             cw = wts(32, cin, 3)
             out = ops.CP.empty(2, n, h, w, nt, dev)
             f = (lambda cw=cw, cin=cin, out=out: ops.conv2d(x224, cw, relu=True, out=out, cin_chunks=cin // 16))
-            for v in (-1, 0, 3):
+            for v in (-1,):
                 lib.binhip_set_variant(0, v)
                 for dbg, nm in ((0, "full"), (1, "no weight DMA"), (2, "no patch DMA"), (3, "no DMA at all"), (4, "no MFMA"),
-                                (7, "nothing (launch+epilogue)")):
+                                (7, "nothing (launch+epilogue)"), (8, "no epilogue"), (12, "DMA+barriers only"),
+                                (15, "empty stages, no epilogue"), (16, "empty kernel")):
                     lib.binhip_set_variant(-2, dbg)
-                    print(f"ablate RDB conv {cin}->32 variant {v:2d} {nm:28s}: {time_fn(f):7.1f} us")
+                    wall = time_fn(f)
+                    # per-launch hipEvent pairs on the launch stream (independent of the Python launch rate)
+                    import ctypes as C
+                    L.check(lib.binhip_profile_begin(3, 32, 0, 64), "profile_begin")
+                    for _ in range(64):
+                        f()
+                    torch.cuda.synchronize()
+                    ms, cnt = C.c_double(0), C.c_int(0)
+                    L.check(lib.binhip_profile_end(C.byref(ms), C.byref(cnt)), "profile_end")
+                    print(f"ablate RDB conv {cin}->32 variant {v:2d} {nm:28s}: wall {wall:7.1f} us/launch, "
+                          f"event pair {ms.value / max(cnt.value, 1) * 1e3:7.1f} us")
         lib.binhip_set_variant(-2, 0)
         lib.binhip_set_variant(0, -1)
     if os.environ.get("WT"):
