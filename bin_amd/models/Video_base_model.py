@@ -114,6 +114,8 @@ class VideoBaseModel(BaseModel):
         if ft and step < ft:
             self.set_params_lr_zero()
         self.optimizer_G.zero_grad()
+        if self.grad_sync is not None:
+            self.grad_sync.attach()
         self.fake_H = self._net(self.var_L)
         loss, parts = self._pix_loss()
         l_pix = self.l_pix_w * loss

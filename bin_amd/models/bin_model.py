@@ -47,34 +47,53 @@ class SingleProcessParallel(nn.Module):
 
 
 class FlatGradAllReduce:
-    """Average gradients over the default process group with one flat buffer (C1 in SURVEY.md §2c)."""
+    """Data-parallel gradient averaging with ONE collective per step (C1 in SURVEY.md §2c): every parameter's .grad is
+    a view into one flat fp32 buffer (11.44 M floats = 45.77 MB for bin_stage4), so autograd accumulates straight into
+    it and the all-reduce (RCCL over xGMI under "nccl", gloo in the CPU tests) runs on the buffer in place — no
+    per-parameter gather/scatter copies (540 tensors each way)."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
+        self.flat = None
+
+    def attach(self):
+        """Zero the flat buffer and (re)point every .grad at its slice; call after optimizer.zero_grad()."""
+        dev = self.params[0].device
+        if self.flat is None or self.flat.device != dev:
+            self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        else:
+            self.flat.zero_()
+        o = 0
+        for p in self.params:
+            p.grad = self.flat[o:o + p.numel()].view_as(p)
+            o += p.numel()
 
     def __call__(self):
         import torch.distributed as dist
         world = dist.get_world_size()
         if world == 1:
             return
+        if self.flat is None or any(p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * o
+                                    for p, o in zip(self.params, self._offsets())):
+            self._gather()                       # somebody replaced a .grad (or attach() was skipped): copy in
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        self.flat.div_(world)
+
+    def _offsets(self):
+        o = 0
+        for p in self.params:
+            yield o
+            o += p.numel()
+
+    def _gather(self):
         dev = self.params[0].device
         flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
-        o = 0
-        for p in self.params:
+        for p, o in zip(self.params, self._offsets()):
             if p.grad is not None:
                 flat[o:o + p.numel()].copy_(p.grad.reshape(-1))
-            o += p.numel()
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat.div_(world)
-        o = 0
-        for p in self.params:
-            g = flat[o:o + p.numel()].view_as(p)
-            if p.grad is None:
-                p.grad = g.clone()
-            else:
-                p.grad.copy_(g)
-            o += p.numel()
+            p.grad = flat[o:o + p.numel()].view_as(p)
+        self.flat = flat
 
 
 class bin_model(BaseModel):
@@ -164,6 +183,8 @@ class bin_model(BaseModel):
         if ft and step < ft:
             self.set_params_lr_zero()
         self.optimizer_G.zero_grad()
+        if self.grad_sync is not None:
+            self.grad_sync.attach()
         self.Ft_p = self.forward()
         self.loss, self.loss_list = self.get_loss(ret=1)
         l_pix = self.l_pix_w * self.loss

@@ -78,3 +78,22 @@ def test_shard_windows_covers_everything():
                 assert b == c
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_flat_grad_views_accumulate_in_place():
+    """FlatGradAllReduce.attach(): every .grad is a slice of one flat buffer and autograd accumulates into it in place
+    (so the DP all-reduce needs no per-parameter copies)."""
+    from bin_amd.models.bin_model import FlatGradAllReduce
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.Conv2d(4, 2, 1))
+    sync = FlatGradAllReduce(net.parameters())
+    sync.attach()
+    ptrs = [p.grad.data_ptr() for p in net.parameters()]
+    x = torch.rand(2, 3, 8, 8)
+    net(x).sum().backward()
+    net(x * 2).sum().backward()                         # second backward accumulates
+    assert [p.grad.data_ptr() for p in net.parameters()] == ptrs
+    ref = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    assert torch.equal(ref, sync.flat) and float(sync.flat.abs().sum()) > 0
+    sync.attach()                                       # next step: zeroed, same storage
+    assert float(sync.flat.abs().sum()) == 0 and [p.grad.data_ptr() for p in net.parameters()] == ptrs
