@@ -20,6 +20,14 @@ from .ops import _ptr, _stream
 from .rdn_plan import layer_names, rdn_forward, workspace
 
 
+# When True (bin_model.optimize_parameters turns it on around backward()), an RDN's weight gradients are written /
+# accumulated by the kernels DIRECTLY into the parameters' .grad buffers (BINHIP_BWD_ACCUMULATE) and autograd gets None
+# for them: the four weight sets are shared by 4/3/2/1 calls, so the default path costs ~1.7 k elementwise adds per
+# step in autograd's AccumulateGrad.  Off by default: torch.autograd.grad() / gradient hooks see the parameter grads
+# only through the regular path.
+DIRECT_PARAM_GRADS = False
+
+
 def train_precision(module):
     from .models.archs.RDN import PRECISIONS
     p = module.precision or os.environ.get("BIN_AMD_TRAIN_PRECISION", "f16x3")
@@ -43,6 +51,7 @@ class _RdnFn(torch.autograd.Function):
         ctx.saved_ws = saved
         ctx.dims = (n, h, w)
         ctx.param_meta = [(tuple(a.shape), a.device) for a in args[n_frames:]]
+        ctx.params = args[n_frames:]
         return out
 
     @staticmethod
@@ -56,7 +65,20 @@ class _RdnFn(torch.autograd.Function):
         plan = L.BinRdnBwdPlan()
         plan.N, plan.H, plan.W, plan.n_inputs, plan.nterms = n, h, w, k, nterms
         dgw.fill_plan(plan)
-        grads = [torch.empty(shape, dtype=torch.float32, device=dev) for shape, _ in ctx.param_meta]
+        params = ctx.params
+        direct = DIRECT_PARAM_GRADS and all(ctx.needs_input_grad[3 + k:])
+        have = False
+        if direct:
+            states = [p.grad is not None for p in params]
+            have = all(states)
+            direct = (have or not any(states)) and all(
+                p.grad is None or (p.grad.dtype == torch.float32 and p.grad.is_contiguous() and p.grad.device == dev)
+                for p in params)
+        if direct and have:
+            grads = [p.grad for p in params]
+            plan.reserved = L.BWD_ACCUMULATE
+        else:
+            grads = [torch.empty(shape, dtype=torch.float32, device=dev) for shape, _ in ctx.param_meta]
         for i in range(L.RDN_LAYERS):
             plan.dw[i] = grads[2 * i].data_ptr()
             plan.db[i] = grads[2 * i + 1].data_ptr()
@@ -74,6 +96,11 @@ class _RdnFn(torch.autograd.Function):
         L.check(lib.binhip_rdn_backward(C.byref(plan), _ptr(ctx.saved_ws), ctx.saved_ws.numel(), _ptr(gout), _ptr(ws),
                                         ws.numel(), _stream()), "rdn_backward")
         ctx.saved_ws = None
+        if direct:
+            if not have:
+                for p, g in zip(params, grads):
+                    p.grad = g
+            return (None, None, None, *gins, *([None] * len(grads)))
         pgrads = [g if ctx.needs_input_grad[3 + k + i] else None for i, g in enumerate(grads)]
         return (None, None, None, *gins, *pgrads)
 

@@ -229,6 +229,7 @@ int binhip_rdn_backward(const BinRdnBwdPlan* p, const void* saved, size_t saved_
     auto GH = [&](int64_t off) { return (void*)(gbase + off); };
     auto GL = [&](int64_t off, int64_t size) { return nt == 3 ? (void*)(gbase + off + size) : (void*)nullptr; };
 
+    const int accumulate = (p->reserved & BINHIP_BWD_ACCUMULATE) ? 1 : 0;   // dw/db += instead of =
     int rc;
     if ((rc = binhip_grad_scale(gout, (int64_t)N * 3 * H * W, 16.f, amax_part, sc, stream))) return rc;
     if ((rc = binhip_nchw_to_planes_scaled(gout, N, 3, H, W, sc, GH(b.gout), GL(b.gout, b.s_gout), stream))) return rc;
@@ -240,7 +241,7 @@ int binhip_rdn_backward(const BinRdnBwdPlan* p, const void* saved, size_t saved_
         d.N = N; d.H = Hc; d.W = Wc; d.ksize = ks; d.cin_chunks = cin_chunks; d.cout = cout; d.cout_pad = 0;
         d.nterms = nt; d.epilogue = 0; d.relu = 0; d.x_cpg = cpg; d.x_group_stride = gstride; d.n_images = 0; d.reserved = 0;
         return binhip_conv2d_bwd_weight(&d, SH(x_off), SL(x_off, x_size), GH(g_off), GL(g_off, g_size), inv, wgws,
-                                        b.wg_bytes, p->dw[layer], p->db[layer], cin, shuffle, 0, stream);
+                                        b.wg_bytes, p->dw[layer], p->db[layer], cin, shuffle, accumulate, stream);
     };
     // data gradient through forward layer `layer`: conv with the transposed/flipped weights
     auto dgrad = [&](int layer, int ks, int Hc, int Wc, int gin_chunks, int gout_ch, int64_t g_off, int64_t g_size,

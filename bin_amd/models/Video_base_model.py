@@ -119,7 +119,12 @@ class VideoBaseModel(BaseModel):
         self.fake_H = self._net(self.var_L)
         loss, parts = self._pix_loss()
         l_pix = self.l_pix_w * loss
-        l_pix.backward()
+        from .. import autograd as _ag
+        _ag.DIRECT_PARAM_GRADS = True
+        try:
+            l_pix.backward()
+        finally:
+            _ag.DIRECT_PARAM_GRADS = False
         if self.grad_sync is not None:
             self.grad_sync()
         self.optimizer_G.step()

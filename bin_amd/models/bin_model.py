@@ -188,7 +188,12 @@ class bin_model(BaseModel):
         self.Ft_p = self.forward()
         self.loss, self.loss_list = self.get_loss(ret=1)
         l_pix = self.l_pix_w * self.loss
-        l_pix.backward()
+        from .. import autograd as _ag
+        _ag.DIRECT_PARAM_GRADS = True          # weight gradients land in .grad straight from the kernels
+        try:
+            l_pix.backward()
+        finally:
+            _ag.DIRECT_PARAM_GRADS = False
         if self.grad_sync is not None:
             self.grad_sync()
         self.optimizer_G.step()

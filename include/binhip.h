@@ -221,9 +221,12 @@ int binhip_convlstm_bwd(const float* x, const float* c_prev, const float* h_prev
 
 /* ---- backward of one whole RDN sub-network ----------------------------------------------------------
  * `saved` is the workspace binhip_rdn_forward filled (kept by the caller between forward and backward).
- * dw[i]/db[i]: OIHW fp32 gradients of layer i (overwritten).  gin[i]: fp32 [N,3,H,W] or NULL.           */
+ * dw[i]/db[i]: OIHW fp32 gradients of layer i — overwritten, or accumulated into (`+=`, e.g. straight into the
+ * parameters' .grad buffers when a weight set is shared by several calls) when `reserved` has
+ * BINHIP_BWD_ACCUMULATE.  gin[i]: fp32 [N,3,H,W] or NULL.                                                */
+#define BINHIP_BWD_ACCUMULATE 1
 typedef struct BinRdnBwdPlan {
-    int32_t N, H, W, n_inputs, nterms, reserved;
+    int32_t N, H, W, n_inputs, nterms, reserved;   /* reserved = flags (BINHIP_BWD_*)                     */
     const void* wt_hi[BINHIP_RDN_LAYERS];   /* binhip_weights_relayout_dgrad outputs; for the slots   */
                                             /* RDBs.d.convs.g: binhip_weights_relayout_rdb_gather(g)   */
     const void* wt_lo[BINHIP_RDN_LAYERS];

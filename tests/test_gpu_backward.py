@@ -155,3 +155,36 @@ def test_training_step_matches_reference_golden(tmp_path):
             n = key[5:]
             assert _rel(named[n].grad.cpu(), torch.from_numpy(g[key])) <= 5e-3, n
             assert float((named[n].detach().cpu() - torch.from_numpy(g["after." + n])).abs().max()) <= 2e-5, n
+
+
+def test_direct_param_grads_equal_autograd_accumulation():
+    """bin_amd.autograd.DIRECT_PARAM_GRADS: the kernels write / accumulate weight gradients straight into .grad
+    (BINHIP_BWD_ACCUMULATE) instead of returning them to autograd's AccumulateGrad.  Same values added in the same order
+    => every gradient of the whole net is bit-identical, with and without pre-existing (flat-view) .grad buffers."""
+    from bin_amd import autograd as ag
+    from bin_amd.models.archs.RDN import bin_stage4_lstm
+    from bin_amd.models.bin_model import FlatGradAllReduce
+    from bin_amd.weights import reference_state_dict, synthetic_frames
+    frames = [f.cuda() for f in synthetic_frames(3, 1, 32, 32, 6)]
+
+    def run(direct, flat):
+        net = bin_stage4_lstm()
+        net.load_state_dict(reference_state_dict(0), strict=True)
+        net = net.cuda().train()
+        if flat:
+            FlatGradAllReduce(net.parameters()).attach()
+        out = net(*frames)
+        loss = sum((o * o).mean() for o in out)
+        ag.DIRECT_PARAM_GRADS = direct
+        try:
+            loss.backward()
+        finally:
+            ag.DIRECT_PARAM_GRADS = False
+        return {n: p.grad.clone() for n, p in net.named_parameters()}
+
+    base = run(False, False)
+    for direct, flat in ((True, False), (True, True), (False, True)):
+        got = run(direct, flat)
+        assert set(got) == set(base)
+        for n in base:
+            assert torch.equal(got[n], base[n]), (direct, flat, n)
