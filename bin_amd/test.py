@@ -142,6 +142,7 @@ def main(argv=None):
     copy_stream = torch.cuda.Stream(device=dev)
     decoded, frames_dev, stage1_cache, pending = {}, {}, {}, []
     geom = None                                        # (h, w, pads) of the current clip
+    pinned = []                                        # recycled page-locked staging buffers (allocation is slow)
     claimed = set()
     cur_clip, timer = None, AverageMeter()
 
@@ -206,19 +207,22 @@ def main(argv=None):
             outs = torch.stack([ops.frame_to_u8(Ft_p[k], t, l, h, w) for k in OUT_KEYS])
             ready = torch.cuda.Event()
             ready.record()
-            host = torch.empty(outs.shape, dtype=torch.uint8, pin_memory=True)
+            host = pinned.pop() if pinned and pinned[-1].shape == outs.shape else torch.empty(
+                outs.shape, dtype=torch.uint8, pin_memory=True)
             with torch.cuda.stream(copy_stream):
                 copy_stream.wait_event(ready)
                 host.copy_(outs, non_blocking=True)
                 outs.record_stream(copy_stream)
                 done = torch.cuda.Event()
                 done.record()
-            pending.append(pool.submit(finish, (clip, names, owned, host, done,
-                                                os.path.join(args.input_path, clip, frames[ids[3]]))))
+            pending.append((pool.submit(finish, (clip, names, owned, host, done,
+                                                 os.path.join(args.input_path, clip, frames[ids[3]]))), host))
             while len(pending) > 8:                       # bound host memory; surfaces worker exceptions
-                pending.pop(0).result()
+                job, buf = pending.pop(0)
+                job.result()
+                pinned.append(buf)
             timer.update(time.time() - t0)
-        for job in pending:
+        for job, _ in pending:
             job.result()
     torch.cuda.synchronize()
     wall = time.time() - t_all

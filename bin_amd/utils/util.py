@@ -146,6 +146,9 @@ def setup_logger(logger_name, root, phase, level=logging.INFO, screen=False, tof
     lg = logging.getLogger(logger_name)
     fmt = logging.Formatter("%(asctime)s.%(msecs)03d - %(levelname)s: %(message)s", datefmt="%y-%m-%d %H:%M:%S")
     lg.setLevel(level)
+    for old in list(lg.handlers):            # a set-up call defines the handlers: a second run in one process does
+        lg.removeHandler(old)                # not log twice / into the previous run's file
+        old.close()
     if tofile:
         fh = logging.FileHandler(os.path.join(root, f"{phase}_{get_timestamp()}.log"), mode="w")
         fh.setFormatter(fmt)

@@ -261,8 +261,6 @@ def test_train_loop_checkpoints_and_resume(tmp_path, adobe, monkeypatch):
     # resume from iteration 3: continues at 4, ends at 6, the LR follows MultiStepLR([4, 8]) from the restored state
     state = torch.load(exp / "training_state" / "3.state", weights_only=False)
     assert state["iter"] == 3
-    for h in list(__import__("logging").getLogger("base").handlers):
-        __import__("logging").getLogger("base").removeHandler(h)
     assert train.main(["-opt", _train_yml(tmp_path, adobe, resume=str(exp / "training_state" / "3.state"))],
                       model_factory=_tiny_factory) == 0
     logs2 = sorted(f for f in os.listdir(exp) if f.endswith(".log"))
