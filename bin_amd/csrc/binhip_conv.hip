@@ -594,7 +594,15 @@ static int bh_dispatch_conv(const ConvKArgs& a0, int k, int cp, int nt, int e, h
     }
     //                                   KS MT WM R WN KC NT NBUF EPI
     if (nt == 1) {
-        if (e == F && k == 3 && cp == 32)  return launch_cfg<3, 1, 1, 4, 4, 1, 1, 2, F>(a, cp, s);
+        if (e == F && k == 3 && cp == 32) {
+            switch (g_variant[CLS_FINAL]) {
+                case 1: return launch_cfg<3, 1, 1, 2, 8, 1, 1, 2, F>(a, cp, s);    // 8 waves, 16x32 tile
+                case 2: return launch_cfg<3, 1, 1, 4, 8, 1, 1, 2, F>(a, cp, s);    // 8 waves, 32x32 tile
+                case 3: return launch_cfg<3, 1, 1, 2, 4, 1, 1, 2, F>(a, cp, s);    // 4 waves, 8x32 tile
+                case 0: return launch_cfg<3, 1, 1, 4, 4, 1, 1, 2, F>(a, cp, s);
+                default: return launch_cfg<3, 1, 1, 2, 8, 1, 1, 2, F>(a, cp, s);   // 8 waves, 16x32 tile: 45 vs 55 us
+            }
+        }
         if (e == S && k == 3 && cp == 256) {
             switch (g_variant[CLS_SHUFFLE]) {
                 case 0: return launch_cfg<3, 2, 2, 4, 2, 1, 1, 2, S>(a, cp, s);
@@ -623,6 +631,9 @@ static int bh_dispatch_conv(const ConvKArgs& a0, int k, int cp, int nt, int e, h
         if (e == P && k == 3 && cb == 96) {
             switch (g_variant[CLS_K3C96]) {
                 case 1: return launch_cfg<3, 3, 1, 2, 4, 1, 1, 3, P>(a, cp, s);
+                case 2: return launch_cfg<3, 3, 1, 2, 8, 1, 1, 2, P>(a, cp, s);    // 8 waves, 16x32 tile
+                case 3: return launch_cfg<3, 3, 1, 1, 8, 1, 1, 2, P>(a, cp, s);    // 8 waves x 1 row, 8x32 tile
+                case 4: return launch_cfg<3, 3, 1, 1, 4, 1, 1, 2, P>(a, cp, s);    // 4 waves x 1 row, 4x32 tile
                 default: return launch_cfg<3, 3, 1, 2, 4, 1, 1, 2, P>(a, cp, s);
             }
         }
@@ -634,13 +645,31 @@ static int bh_dispatch_conv(const ConvKArgs& a0, int k, int cp, int nt, int e, h
                 case 3: return launch_cfg<1, 3, 1, 4, 4, 2, 1, 2, P>(a, cp, s);
                 case 4: return launch_cfg<1, 3, 1, 2, 4, 1, 1, 4, P>(a, cp, s);
                 case 5: return launch_cfg<1, 3, 1, 4, 4, 2, 1, 3, P>(a, cp, s);
+                case 6: return launch_cfg<1, 3, 1, 2, 8, 2, 1, 2, P>(a, cp, s);    // 8 waves, 16x32 tile
+                case 7: return launch_cfg<1, 3, 1, 1, 8, 2, 1, 2, P>(a, cp, s);    // 8 waves x 1 row
                 case 0: return launch_cfg<1, 3, 1, 2, 4, 4, 1, 2, P>(a, cp, s);
-                default: return launch_cfg<1, 3, 1, 2, 4, 2, 1, 2, P>(a, cp, s);     // 44 KB LDS -> 3 blocks/CU
+                default:
+                    // short K (LFF, LFF dgrad): 8 waves x 1 row, 38.6 vs 49.6 us; long K (GFF.0, 72 chunks): the 4-wave tile
+                    if (a.nchunks >= 32) return launch_cfg<1, 3, 1, 2, 4, 2, 1, 2, P>(a, cp, s);
+                    return launch_cfg<1, 3, 1, 1, 8, 2, 1, 2, P>(a, cp, s);
             }
         }
-        if (e == P && k == 5 && cb == 32)  return launch_cfg<5, 1, 1, 4, 4, 1, 1, 2, P>(a, cp, s);
+        if (e == P && k == 5 && cb == 32) {
+            switch (g_variant[CLS_K5]) {
+                case 1: return launch_cfg<5, 1, 1, 2, 8, 1, 1, 2, P>(a, cp, s);    // 8 waves, 16x32 tile
+                case 2: return launch_cfg<5, 1, 1, 4, 8, 1, 1, 2, P>(a, cp, s);    // 8 waves, 32x32 tile
+                case 3: return launch_cfg<5, 1, 1, 2, 4, 1, 1, 2, P>(a, cp, s);    // 4 waves, 8x32 tile
+                case 0: return launch_cfg<5, 1, 1, 4, 4, 1, 1, 2, P>(a, cp, s);
+                default: return launch_cfg<5, 1, 1, 2, 8, 1, 1, 2, P>(a, cp, s);   // 8 waves, 16x32 tile: 69 vs 83 us
+            }
+        }
     } else {
-        if (e == F && k == 3 && cp == 32)  return launch_cfg<3, 1, 1, 4, 4, 1, 3, 2, F>(a, cp, s);
+        if (e == F && k == 3 && cp == 32) {
+            switch (g_variant[CLS_FINAL]) {
+                case 0: return launch_cfg<3, 1, 1, 4, 4, 1, 3, 2, F>(a, cp, s);
+                default: return launch_cfg<3, 1, 1, 2, 8, 1, 3, 2, F>(a, cp, s);   // 130 vs 162 us
+            }
+        }
         if (e == S && k == 3 && cp == 256) return launch_cfg<3, 1, 2, 4, 2, 1, 3, 2, S>(a, cp, s);
         if (e == P && k == 3 && cb == 32) {
             switch (g_variant[CLS_K3C32]) {
@@ -651,16 +680,31 @@ static int bh_dispatch_conv(const ConvKArgs& a0, int k, int cp, int nt, int e, h
             }
         }
         if (e == P && k == 3 && cb == 64)  return launch_cfg<3, 2, 1, 2, 4, 1, 3, 2, P>(a, cp, s);
-        if (e == P && k == 3 && cb == 96)  return launch_cfg<3, 3, 1, 2, 4, 1, 3, 2, P>(a, cp, s);
+        if (e == P && k == 3 && cb == 96) {
+            switch (g_variant[CLS_K3C96]) {
+                case 0: return launch_cfg<3, 3, 1, 2, 4, 1, 3, 2, P>(a, cp, s);
+                default: return launch_cfg<3, 3, 1, 1, 8, 1, 3, 2, P>(a, cp, s);   // 8 waves x 1 row: 168 vs 184 us
+            }
+        }
         if (e == P && k == 1 && cb == 32)  return launch_cfg<1, 1, 1, 4, 4, 2, 3, 2, P>(a, cp, s);
         if (e == P && k == 1 && cb == 96) {
             switch (g_variant[CLS_K1C96]) {
                 case 1: return launch_cfg<1, 3, 1, 2, 4, 1, 3, 3, P>(a, cp, s);
                 case 0: return launch_cfg<1, 3, 1, 2, 4, 2, 3, 2, P>(a, cp, s);
-                default: return launch_cfg<1, 3, 1, 2, 4, 1, 3, 2, P>(a, cp, s);
+                case 2: return launch_cfg<1, 3, 1, 1, 8, 1, 3, 2, P>(a, cp, s);    // 8 waves x 1 row
+                case 3: return launch_cfg<1, 3, 1, 1, 8, 2, 3, 2, P>(a, cp, s);
+                case 4: return launch_cfg<1, 3, 1, 2, 4, 1, 3, 2, P>(a, cp, s);
+                default:
+                    if (a.nchunks >= 32) return launch_cfg<1, 3, 1, 2, 4, 1, 3, 2, P>(a, cp, s);
+                    return launch_cfg<1, 3, 1, 1, 8, 1, 3, 2, P>(a, cp, s);    // LFF 90 vs 108 us
             }
         }
-        if (e == P && k == 5 && cb == 32)  return launch_cfg<5, 1, 1, 4, 4, 1, 3, 1, P>(a, cp, s);
+        if (e == P && k == 5 && cb == 32) {
+            switch (g_variant[CLS_K5]) {
+                case 0: return launch_cfg<5, 1, 1, 4, 4, 1, 3, 1, P>(a, cp, s);
+                default: return launch_cfg<5, 1, 1, 2, 8, 1, 3, 1, P>(a, cp, s);
+            }
+        }
     }
     return BINHIP_E_SHAPE;
 }

@@ -58,17 +58,17 @@ def main():
                       2 * 9 * cin * 32 * px, (cin + 32) * bpe * px, out))
     cw = wts(96, 224, 1)
     out96 = ops.CP.empty(6, n, h, w, nt, dev)
-    cases.append((1, "LFF 1x1 224->96 +res", [0, 1, 4] if nt == 1 else [0, 1, 2],
+    cases.append((1, "LFF 1x1 224->96 +res", [1, -1] if nt == 1 else [-1, 2, 3],
                   (lambda cw=cw: ops.conv2d(x224, cw, residual=res96, out=out96)), 2 * 224 * 96 * px,
                   (224 + 96 + 96) * bpe * px, out96))
     x1152 = mk(1152)
     cwg = wts(96, 1152, 1)
     outg = ops.CP.empty(6, n, h, w, nt, dev)
-    cases.append((1, "GFF.0 1x1 1152->96", [0, 1, 4] if nt == 1 else [0, 1, 2],
+    cases.append((1, "GFF.0 1x1 1152->96", [1, -1] if nt == 1 else [-1, 2, 3],
                   (lambda: ops.conv2d(x1152, cwg, out=outg)), 2 * 1152 * 96 * px, (1152 + 96) * bpe * px, outg))
     cw3 = wts(96, 96, 3)
     out3 = ops.CP.empty(6, n, h, w, nt, dev)
-    cases.append((2, "3x3 96->96 +res", [-1, 1] if nt == 1 else [0],
+    cases.append((2, "3x3 96->96 +res", [-1] if nt == 1 else [-1, 2],
                   (lambda: ops.conv2d(res96, cw3, residual=x224, out=out3)), 2 * 9 * 96 * 96 * px,
                   (96 + 96 + 96) * bpe * px, out3))
     cwu = wts(256, 96, 3, shuffle=True)
@@ -79,13 +79,13 @@ def main():
     xu = mk(64, 2 * h, 2 * w)
     cwf = wts(3, 64, 3)
     imgs = [torch.rand(n, 3, 2 * h, 2 * w, generator=g).to(dev) for _ in range(2)]
-    cases.append((4, "UPNet.2 3x3 64->3 +mean (final)", [0],
+    cases.append((4, "UPNet.2 3x3 64->3 +mean (final)", [0, -1] if nt == 1 else [-1, 1],
                   (lambda: ops.conv2d(xu, cwf, epilogue=L.EPI_FINAL, images=imgs)), 2 * 9 * 64 * 3 * 4 * px,
                   (64 * bpe + 3 * 4 * 3) * 4 * px, None))
     x48 = mk(48)
     cw5 = wts(96, 36, 5)
     out5 = ops.CP.empty(6, n, h, w, nt, dev)
-    cases.append((5, "SFENet1 5x5 36->96", [0], (lambda: ops.conv2d(x48, cw5, out=out5, cin_chunks=3)),
+    cases.append((5, "SFENet1 5x5 36->96", [0, -1] if nt == 1 else [-1, 1], (lambda: ops.conv2d(x48, cw5, out=out5, cin_chunks=3)),
                   2 * 25 * 36 * 96 * px, (48 + 96) * bpe * px, out5))
 
     # fused conv#3 + LFF vs the two separate kernels
