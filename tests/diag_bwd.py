@@ -1,3 +1,5 @@
+"""Diagnostic (GPU box, run by hand): per-parameter relative error of one RDN backward vs torch autograd of the oracle.
+Lives under tests/ because it uses oracle/ (test infrastructure)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
