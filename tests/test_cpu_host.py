@@ -40,6 +40,38 @@ def test_library_host_queries():
     assert 0 < b1 < b3 < (8 << 30)
 
 
+def test_abi_error_codes_without_a_gpu():
+    """Argument / shape validation happens before any HIP call, so the error behaviour of the C ABI (0 ok, < 0
+    BINHIP_E_*, never an exception) can be pinned on a GPU-less box: every call below must return, not launch."""
+    from bin_amd import _lib as L
+    lib = L.lib()
+    E_ARG, E_SHAPE, E_WS = -1, -2, -3
+    null = ctypes.c_void_p(0)
+    d = L.BinConvDesc()
+    d.N, d.H, d.W, d.ksize, d.cin_chunks, d.cout, d.cout_pad, d.nterms, d.epilogue = 1, 8, 8, 3, 2, 32, 32, 1, 0
+    # null pointers
+    assert lib.binhip_conv2d_fwd(None, *([null] * 10), None, null) == E_ARG
+    assert lib.binhip_conv2d_fwd(ctypes.byref(d), *([null] * 10), None, null) == E_ARG
+    assert lib.binhip_rdn_forward(None, None, null, null, 0, null) == E_ARG
+    assert lib.binhip_weights_relayout(null, null, 32, 32, 3, 32, 2, 32, 0, null, null, null, null) == E_ARG
+    four = (ctypes.c_void_p * 4)()
+    assert lib.binhip_weights_relayout_rdb_gather(four, 7, 32, null, null, null, null) == E_ARG       # bad group
+    # shapes the kernels do not have
+    one = ctypes.c_void_p(16)                      # any non-null value: validation must fail before it is touched
+    assert lib.binhip_weights_relayout(one, null, 32, 32, 3, 48, 2, 32, 0, one, null, one, null) == E_SHAPE   # cout_pad % 32
+    assert lib.binhip_weights_relayout(one, null, 40, 32, 3, 32, 2, 32, 0, one, null, one, null) == E_SHAPE   # cout > cout_pad
+    assert lib.binhip_weights_relayout_dgrad(one, 32, 96, 3, 96, 2, 40, 0, one, null, one, null) == E_SHAPE   # bad cout_block
+    assert lib.binhip_dgrad_rows_pad(1, 224) == 288 and lib.binhip_dgrad_rows_pad(3, 96) == 96
+    plan = L.BinRdnPlan()
+    plan.N, plan.H, plan.W, plan.n_inputs, plan.nterms = 1, 33, 32, 2, 1
+    arr = (ctypes.c_void_p * 2)(16, 16)
+    assert lib.binhip_rdn_forward(ctypes.byref(plan), arr, one, one, 1 << 20, null) in (E_SHAPE, E_ARG)      # odd height
+    assert lib.binhip_rdn_backward_workspace_bytes(1, 64, 64, 4, 1) == 0
+    assert lib.binhip_wgrad_workspace_bytes(3, 0, 8, 8, 2, 32) == 0
+    assert lib.binhip_profile_begin(3, 32, 0, 0) == E_ARG
+    assert E_WS == -3
+
+
 def test_product_has_no_cpu_path():
     from bin_amd import ops
     from bin_amd.models.archs.RDN import bin_stage4_lstm
