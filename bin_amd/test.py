@@ -50,6 +50,8 @@ def parse_args(argv=None):
     p.add_argument("--launcher", choices=["none", "pytorch"], default="none")
     p.add_argument("--precision", choices=["f16", "f16x3"], default=None)
     p.add_argument("--io_threads", type=int, default=8)
+    p.add_argument("--batch", type=int, default=1, help="windows per forward (small frames: 8 fills the chip; no "
+                   "cross-window stage-1 reuse when > 1)")
     p.add_argument("--no_reuse", action="store_true", help="recompute the stage-1 calls shared by consecutive windows")
     p.add_argument("--ssim", action="store_true", help="also compute SSIM (host, ~0.2 s per 720p frame)")
     return p.parse_args(argv)
@@ -167,11 +169,46 @@ def main(argv=None):
             _score(sums, clip, "blurry", data_util.imread_u8(blurry_path)[:, :, :3],
                    os.path.join(args.gt_path, clip, names[0]), args.ssim)
 
+    group = []                                         # windows of one clip waiting to go through the net together
+
+    def flush():
+        """One forward for the windows in `group` (batched along N when there are several), then hand each window's
+        three u8 images to the writer pool through a copy stream."""
+        if not group:
+            return
+        t0 = time.time()
+        (h, w), (l, r, t, b) = geom[:2], geom[2]
+        if len(group) == 1:
+            inputs = group[0][3]
+            Ft_p = netG(*inputs, stage1_cache=stage1_cache) if reuse else netG(*inputs)
+        else:
+            Ft_p = netG(*[torch.cat([g[3][k] for g in group], 0) for k in range(6)])
+        for j, (clip, names, owned, _, blurry_path) in enumerate(group):
+            outs = torch.stack([ops.frame_to_u8(Ft_p[k][j:j + 1], t, l, h, w) for k in OUT_KEYS])
+            ready = torch.cuda.Event()
+            ready.record()
+            host = pinned.pop() if pinned and pinned[-1].shape == outs.shape else torch.empty(
+                outs.shape, dtype=torch.uint8, pin_memory=True)
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(ready)
+                host.copy_(outs, non_blocking=True)
+                outs.record_stream(copy_stream)
+                done = torch.cuda.Event()
+                done.record()
+            pending.append((pool.submit(finish, (clip, names, owned, host, done, blurry_path)), host))
+        while len(pending) > 8 + len(group):             # bound host memory; surfaces worker exceptions
+            job, buf = pending.pop(0)
+            job.result()
+            pinned.append(buf)
+        timer.update((time.time() - t0) / len(group), len(group))
+        group.clear()
+
     t_all = time.time()
     with torch.no_grad():
         for wi in range(begin, end):
             clip, frames, index = windows[wi]
             if clip != cur_clip:
+                flush()
                 cur_clip = clip
                 decoded.clear(); frames_dev.clear(); stage1_cache.clear()
                 os.makedirs(os.path.join(result_root, clip), exist_ok=True)
@@ -185,12 +222,11 @@ def main(argv=None):
             if not any(owned) and not args.gt_path:
                 continue
             ids = harness.window_frame_ids(index, len(frames))
-            for ahead in range(1, 4):                    # keep the decoders a few windows ahead of the GPU
+            for ahead in range(1, 3 + args.batch):       # keep the decoders a few windows ahead of the GPU
                 if wi + ahead < end and windows[wi + ahead][0] == clip:
                     for fid in harness.window_frame_ids(index + ahead, len(frames)):
                         want(clip, frames, fid)
-            t0 = time.time()
-            batch = []
+            six = []
             for fid in ids:
                 if fid not in frames_dev:
                     img = want(clip, frames, fid).result()
@@ -198,30 +234,14 @@ def main(argv=None):
                         raise RuntimeError(f"{clip}/{frames[fid]}: expected a 3-channel image")
                     geom = (img.shape[0], img.shape[1], util.pad_sizes(img.shape[0], img.shape[1]))
                     frames_dev[fid] = ops.u8_to_frame(torch.from_numpy(img).to(dev, non_blocking=True), geom[2])
-                batch.append(frames_dev[fid])
-            for fid in [f for f in frames_dev if f < min(ids)]:
+                six.append(frames_dev[fid])
+            for fid in [f for f in frames_dev if f < min(ids)]:      # the windows in `group` hold their own references
                 del frames_dev[fid]
                 decoded.pop((clip, fid), None)
-            (h, w), (l, r, t, b) = geom[:2], geom[2]
-            Ft_p = netG(*batch, stage1_cache=stage1_cache) if reuse else netG(*batch)
-            outs = torch.stack([ops.frame_to_u8(Ft_p[k], t, l, h, w) for k in OUT_KEYS])
-            ready = torch.cuda.Event()
-            ready.record()
-            host = pinned.pop() if pinned and pinned[-1].shape == outs.shape else torch.empty(
-                outs.shape, dtype=torch.uint8, pin_memory=True)
-            with torch.cuda.stream(copy_stream):
-                copy_stream.wait_event(ready)
-                host.copy_(outs, non_blocking=True)
-                outs.record_stream(copy_stream)
-                done = torch.cuda.Event()
-                done.record()
-            pending.append((pool.submit(finish, (clip, names, owned, host, done,
-                                                 os.path.join(args.input_path, clip, frames[ids[3]]))), host))
-            while len(pending) > 8:                       # bound host memory; surfaces worker exceptions
-                job, buf = pending.pop(0)
-                job.result()
-                pinned.append(buf)
-            timer.update(time.time() - t0)
+            group.append((clip, names, owned, six, os.path.join(args.input_path, clip, frames[ids[3]])))
+            if len(group) >= args.batch:
+                flush()
+        flush()
         for job, _ in pending:
             job.result()
     torch.cuda.synchronize()

@@ -226,6 +226,12 @@ def test_interpolate_clip_u8_sharded():
     for k in full:
         for x, y in zip(nocache[k], full[k]):
             assert (x == y).all()
+    for bsz in (2, 3, 8):                                                # windows batched along N: no bit changes
+        batched = interpolate_clip(net, clip, batch=bsz)
+        assert sorted(batched) == sorted(full)
+        for k in full:
+            for x, y in zip(batched[k], full[k]):
+                assert (x == y).all()
     clip_f = (clip.float() / 255.0)[:, :, :, [2, 1, 0]].permute(0, 3, 1, 2).contiguous()
     ff = interpolate_clip(net, clip_f)
     for k in full:

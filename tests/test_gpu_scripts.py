@@ -77,6 +77,15 @@ def test_folder_evaluation_matches_harness(tmp_path):
     logs = [f for f in os.listdir(res) if f.endswith(".log")]
     text = open(os.path.join(res, logs[0])).read()
     assert "Avg. testset" in text and "interp_psnr" in text and "interpolated frames/s" in text
+    # windows batched along N (--batch 3, no cross-window stage-1 reuse): the same files, bit for bit
+    out_b = str(tmp_path / "out_b")
+    assert run_test.main(["--input_path", os.path.join(root, "test_blur"), "--output_path", out_b,
+                          "--opt", _yml(tmp_path, weights), "--precision", "f16x3", "--batch", "3"]) == 0
+    res_b = os.path.join(out_b, "60fps_test_results", "adobe_stage4")
+    for clip in ("c0", "c1"):
+        assert sorted(os.listdir(os.path.join(res_b, clip))) == sorted(os.listdir(os.path.join(res, clip)))
+        for f in os.listdir(os.path.join(res, clip)):
+            assert np.array_equal(du.imread_u8(os.path.join(res_b, clip, f)), du.imread_u8(os.path.join(res, clip, f)))
     # second run: everything exists -> nothing is rewritten (mtime unchanged), still scores
     before = {f: os.path.getmtime(os.path.join(res, "c0", f)) for f in os.listdir(os.path.join(res, "c0"))}
     assert run_test.main(["--input_path", os.path.join(root, "test_blur"), "--output_path", out,
