@@ -676,6 +676,8 @@ static int bh_dispatch_conv(const ConvKArgs& a0, int k, int cp, int nt, int e, h
                 case 1: return launch_cfg<3, 1, 1, 2, 4, 1, 3, 3, P>(a, cp, s);
                 case 2: return launch_cfg<3, 1, 1, 2, 4, 1, 3, 2, P>(a, cp, s);
                 case 0: return launch_cfg<3, 1, 1, 4, 4, 1, 3, 2, P>(a, cp, s);
+                case 3: return launch_cfg<3, 1, 1, 1, 8, 1, 3, 2, P>(a, cp, s);    // 8 waves x 1 row, 8x32 tile, 80 KB
+                case 4: return launch_cfg<3, 1, 1, 1, 4, 1, 3, 2, P>(a, cp, s);    // 4 waves x 1 row, 4x32 tile
                 default: return launch_cfg<3, 1, 1, 2, 8, 1, 3, 2, P>(a, cp, s);
             }
         }

@@ -53,7 +53,7 @@ def main():
     for cin in (96, 192):
         cw = wts(32, cin, 3)
         out = ops.CP.empty(2, n, h, w, nt, dev)
-        cases.append((0, f"RDB conv3x3 {cin}->32 +ReLU", [0, -1, 12, 3] if nt == 1 else [0, -1, 12],
+        cases.append((0, f"RDB conv3x3 {cin}->32 +ReLU", [0, -1, 12, 3] if nt == 1 else [-1, 3, 4],
                       (lambda cw=cw, cin=cin, out=out: ops.conv2d(x224, cw, relu=True, out=out, cin_chunks=cin // 16)),
                       2 * 9 * cin * 32 * px, (cin + 32) * bpe * px, out))
     cw = wts(96, 224, 1)
