@@ -76,21 +76,28 @@ def interpolate_clip(netG, clip, rank=0, world=1, reuse_stage1=True, batch=1):
 
 
 class GraphedNet:
-    """hipGraph replay of the whole 6-frame forward for one input shape (launch-bound regime: a 256x256 demo window
-    is ~1150 kernel launches of a few microseconds each, so the host, not the GPU, sets the pace when the launches
-    are issued one by one).  The forward is captured once — every launch of `binhip_rdn_forward`, the ConvLSTM
-    kernels and the multi-stream fork/join become graph nodes/edges; the library allocates nothing and never syncs,
-    which is what makes it capturable — and replayed with `__call__`, which copies the new frames into the static
-    input buffers first.  Outputs are the static output tensors of the capture (overwritten by the next replay).
-    The capture uses the single-stream schedule: capturing the multi-stream fork/join crashes in capture_end on this
-    ROCm 7.2 / torch 2.10 stack, and in the launch-bound regime the serial graph is the fast one anyway."""
+    """hipGraph replay of the 6-frame forward for one input shape (launch-bound regime: a 256x256 demo window is ~1150
+    kernel launches of a few microseconds each, so the host, not the GPU, sets the pace when they are issued one by one).
+    The library allocates nothing and never syncs, which is what makes its launch sequences capturable.
 
-    def __init__(self, netG, example_frames, warmup=2):
+    multi_stream=False: the whole serial forward is ONE graph.
+    multi_stream=True : every RDN call (67 launches) and ConvLSTM cell is its own graph, captured on the stream the
+    3-stream schedule runs it on; a replayed forward is 23 graph launches whose cross-stream dependencies stay eager
+    events.  (One graph over all three streams is not possible on this stack: hipStreamEndCapture crashes once two
+    captured streams depend on each other in both directions — tools/probe_graph.py.)
+    `__call__` copies the new frames into the static input buffers and replays; outputs are the static output tensors
+    of the capture (overwritten by the next replay)."""
+
+    def __init__(self, netG, example_frames, warmup=2, multi_stream=False):
         self.net = netG
+        self.multi_stream = multi_stream
         self.static_in = [f.detach().clone().contiguous().float() for f in example_frames]
-        inner = netG.module if hasattr(netG, "module") else netG
+        self.inner = inner = netG.module if hasattr(netG, "module") else netG
         saved_streams = getattr(inner, "n_streams", 1)
-        inner.n_streams = 1
+        if not multi_stream:
+            inner.n_streams = 1
+        elif saved_streams < 2:
+            raise RuntimeError("GraphedNet(multi_stream=True) needs the multi-stream inference schedule (n_streams > 1)")
         try:
             self._capture(netG, warmup)
         finally:
@@ -105,13 +112,34 @@ class GraphedNet:
                     netG(*self.static_in)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.static_out = netG(*self.static_in)
+            if self.multi_stream:
+                self.inner._graph_mode = "capture"
+                try:
+                    self.static_out = netG(*self.static_in)
+                finally:
+                    self.inner._graph_mode = None
+                self.call_graphs = self.inner._call_graphs
+                self.inner._call_graphs = None
+                torch.cuda.synchronize()
+            else:
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    self.static_out = netG(*self.static_in)
 
     @torch.no_grad()
     def __call__(self, *frames):
         for dst, src in zip(self.static_in, frames):
             dst.copy_(src, non_blocking=True)
-        self.graph.replay()
-        return self.static_out
+        if not self.multi_stream:
+            self.graph.replay()
+            return self.static_out
+        inner = self.inner
+        inner._graph_mode, inner._call_graphs = "replay", self.call_graphs
+        try:
+            return netG_call(self.net, self.static_in)
+        finally:
+            inner._graph_mode, inner._call_graphs = None, None
+
+
+def netG_call(netG, frames):
+    return netG(*frames)

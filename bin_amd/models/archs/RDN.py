@@ -284,20 +284,40 @@ def _forward_streams(self, B, stage1_cache=None):
     kw = {k: v.kernel_weights(nterms[k]) for k, v in mods.items()}       # relayouts (if any) on the main stream
     lib = L.lib()
     n, _, h, w = B[0].shape
-    ready = {}                                                          # id(tensor) -> event
+    ready = {}                                                          # id(tensor) -> (event recorded after its call, stream)
+    mode = getattr(self, "_graph_mode", None)                           # None | "capture" | "replay" (harness.GraphedNet)
+    if mode == "capture":
+        self._call_graphs = []
+    counter = [0]
 
     def launch(si, fn, ins):
+        # a consumer waits on the event recorded right after the producing CALL (exact dependency, eager events)
         s = streams[si % len(streams)]
         for t in ins:
-            ev = ready.get(id(t))
-            if ev is not None:
-                s.wait_event(ev)
-        with torch.cuda.stream(s):
-            out = fn()
+            hit = ready.get(id(t))
+            if hit is not None and hit[1] is not s:
+                s.wait_event(hit[0])
+        if mode == "capture":
+            # one hipGraph per call (the 67 launches of an RDN, or a ConvLSTM cell), captured on the call's own stream.
+            # Capturing the WHOLE multi-stream forward into one graph crashes hipStreamEndCapture on ROCm 7.2 as soon
+            # as two captured streams depend on each other in both directions (tools/probe_graph.py), so the
+            # cross-stream edges stay eager events and only the launch-heavy bodies are graphs.
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                out = fn()
+            self._call_graphs.append((g, out))
+        elif mode == "replay":
+            g, out = self._call_graphs[counter[0]]
+            with torch.cuda.stream(s):
+                g.replay()
+        else:
+            with torch.cuda.stream(s):
+                out = fn()
+        counter[0] += 1
+        e = torch.cuda.Event()
+        e.record(s)
         for o in (out if isinstance(out, (tuple, list)) else (out,)):
-            e = torch.cuda.Event()
-            e.record(s)
-            ready[id(o)] = e
+            ready[id(o)] = (e, s)
         return out
 
     def rdn(si, k, *ins):
@@ -350,10 +370,12 @@ def _forward_streams(self, B, stage1_cache=None):
     for s in streams:
         main.wait_stream(s)
     outs = (I2, I4, I6, I8, I3, I5, I7, I4pp, I6pp, I5ppp, I8b, J7, J6pp, J5ppp)
-    for t in outs + (h4, h6, h8, h5, h7, h6pp, J3, J5, J4pp):
-        for s in streams:
-            t.record_stream(s)
-        t.record_stream(main)
+    if mode is None and not torch.cuda.is_current_stream_capturing():
+        # caching-allocator bookkeeping for tensors that crossed streams (graph outputs live in the graphs' private pools)
+        for t in outs + (h4, h6, h8, h5, h7, h6pp, J3, J5, J4pp):
+            for s in streams:
+                t.record_stream(s)
+            t.record_stream(main)
     self.Ft_p_1 = (I6, I8, I8b, None, J3, J5, J7, J4pp, J6pp, J5ppp)
     return outs
 

@@ -239,8 +239,10 @@ def test_interpolate_clip_u8_sharded():
             assert (x == y).all()
 
 
-def test_hipgraph_replay_matches_eager():
-    """The whole forward captured into a hipGraph (bin_amd.harness.GraphedNet) replays bit-identically."""
+@pytest.mark.parametrize("multi", [False, True], ids=["one_graph_serial", "per_call_graphs_3_streams"])
+def test_hipgraph_replay_matches_eager(multi):
+    """hipGraph replay (bin_amd.harness.GraphedNet) is bit-identical to eager launches: the whole serial forward as one
+    graph, and the 3-stream schedule as 23 per-call graphs joined by eager events."""
     from bin_amd.harness import GraphedNet
     from bin_amd.weights import synthetic_frames
     net = _net("f16")
@@ -249,7 +251,8 @@ def test_hipgraph_replay_matches_eager():
     with torch.no_grad():
         e1 = [o.clone() for o in net(*f1)]
         e2 = [o.clone() for o in net(*f2)]
-    g = GraphedNet(net, f1)
+    g = GraphedNet(net, f1, multi_stream=multi)
+    assert (len(g.call_graphs) == 23) if multi else hasattr(g, "graph")
     for frames, ref in ((f2, e2), (f1, e1), (f2, e2)):
         out = g(*frames)
         torch.cuda.synchronize()

@@ -19,5 +19,14 @@ with torch.no_grad():
     for ns in (1, 3):
         net.n_streams = ns
         print(f"eager  streams={ns}: {timeit(lambda: net(*frames)):.2f} ms per 320x320 window")
-    g = GraphedNet(net, frames)
-    print(f"hipGraph replay    : {timeit(lambda: g(*frames)):.2f} ms per 320x320 window")
+    if len(sys.argv) > 1 and sys.argv[1] == "multi":
+        net.n_streams = 3
+        g = GraphedNet(net, frames, multi_stream=True)
+        ref = net(*frames)
+        out = g(*frames)
+        torch.cuda.synchronize()
+        print("3-stream hipGraph == eager:", all(torch.equal(a, b) for a, b in zip(ref, out)))
+        print(f"hipGraph replay (3-stream capture): {timeit(lambda: g(*frames)):.2f} ms per 320x320 window")
+    else:
+        g = GraphedNet(net, frames)
+        print(f"hipGraph replay    : {timeit(lambda: g(*frames)):.2f} ms per 320x320 window")
