@@ -223,8 +223,13 @@ class RDN_residual_interp_5_input_ConvLSTM_L(nn.Module):
                 m.precision = precision
         return self
 
-    def forward(self, B1, B3, B5, B7, B9, B11, stage1_cache=None):
-        """`stage1_cache` (bin_amd extension, inference only): a dict owned by a streaming caller.  Consecutive
+    def forward(self, B1, B3, B5, B7, B9, B11, stage1_cache=None, input_events=None):
+        """`input_events` (bin_amd extension, inference only): a list of torch.cuda.Event after which the six frames are
+        complete (empty list = they already are, e.g. resident frames).  The side streams of the inference schedule
+        then wait on those events instead of on the caller's stream, so back-to-back forwards pipeline: the next
+        window's stage-1 calls start on idle streams while the previous window's lone stage-4 call is still running.
+        The outputs are joined onto the caller's stream as always.
+        `stage1_cache` (bin_amd extension, inference only): a dict owned by a streaming caller.  Consecutive
         windows of a clip share 4 of their 5 stage-1 frame pairs, so model1(Bi, Bj) results are
         memoised on the identity of the two (cached, hence long-lived) frame tensors: 17 -> 13 RDN calls per
         window, outputs unchanged bit for bit."""
@@ -236,9 +241,9 @@ class RDN_residual_interp_5_input_ConvLSTM_L(nn.Module):
                 torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
             if self.batched:
                 return self._forward_batched((B1, B3, B5, B7, B9, B11), stage1_cache)
-            return self._forward_streams((B1, B3, B5, B7, B9, B11), stage1_cache)
-        if stage1_cache is not None:
-            raise RuntimeError("bin_amd: stage1_cache needs the inference schedule (n_streams > 1, no grad)")
+            return self._forward_streams((B1, B3, B5, B7, B9, B11), stage1_cache, input_events)
+        if stage1_cache is not None or input_events is not None:
+            raise RuntimeError("bin_amd: stage1_cache / input_events need the inference schedule (n_streams > 1, no grad)")
         cells = (self.clstm_4_prime, self.clstm_6_prime, self.clstm_8_prime, self.clstm_5_prime_prime,
                  self.clstm_7_prime_prime, self.clstm_6_prime_prime_prime)
         picks = (1, 2, 3, 5, 6, 8)
@@ -265,7 +270,7 @@ class RDN_residual_interp_5_input_ConvLSTM_L(nn.Module):
                 res[0][7], res[0][8], res[0][9], res[1][3], res[1][6], res[1][8], res[1][9])
 
 
-def _forward_streams(self, B, stage1_cache=None):
+def _forward_streams(self, B, stage1_cache=None, input_events=None):
     """Inference schedule that runs the INDEPENDENT RDN calls of each pyramid stage on separate HIP streams
     (stage 1: 4 calls, stage 2: 3, stage 3: 2; window 2's only new stage-1 call rides along with window 1's stage 4).
     Every kernel of one call still runs in order on its stream; calls on different streams overlap, so one call's
@@ -330,7 +335,11 @@ def _forward_streams(self, B, stage1_cache=None):
         return launch(si, fn, ins)
 
     for s in streams:
-        s.wait_stream(main)
+        if input_events is None:
+            s.wait_stream(main)
+        else:                            # pipelined: only the frames' own events, not everything queued on `main`
+            for ev in input_events:
+                s.wait_event(ev)
     cells = (self.clstm_4_prime, self.clstm_6_prime, self.clstm_8_prime, self.clstm_5_prime_prime,
              self.clstm_7_prime_prime, self.clstm_6_prime_prime_prime)
 
@@ -345,9 +354,11 @@ def _forward_streams(self, B, stage1_cache=None):
         key = (id(Ba), id(Bb))
         hit = stage1_cache.get(key)
         if hit is not None and hit[1] is Ba and hit[2] is Bb:
+            if hit[3] is not None:
+                ready[id(hit[0])] = hit[3]        # computed by an earlier forward: consumers still wait on ITS event
             return hit[0]
         out = rdn(si, 1, Ba, Bb)
-        stage1_cache[key] = (out, Ba, Bb)
+        stage1_cache[key] = (out, Ba, Bb, ready.get(id(out)))
         return out
 
     if stage1_cache is not None:         # keep only pairs that can still recur (those of this window)
