@@ -262,3 +262,14 @@ def test_util_helpers_match_reference():
     assert y.shape == (1, 1, 4, 7) and float(y[0, 0, 0, 0]) == 0.0 and float(y[0, 0, 3, 6]) == 11.0
     s = util.calculate_ssim(g["img1"], g["img1"])
     assert abs(s - 1.0) < 1e-12
+
+
+def test_entry_points_parse_their_arguments():
+    """bench.py / bin_amd.test / bin_amd.train import and build their CLIs on a GPU-less box (guards against syntax and
+    import errors in files the CPU suite does not otherwise execute)."""
+    import subprocess
+    import sys
+    for cmd in (["bench.py", "--help"], ["-m", "bin_amd.test", "--help"], ["-m", "bin_amd.train", "--help"]):
+        r = subprocess.run([sys.executable] + cmd, cwd=REPO, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (cmd, r.stderr[-500:])
+        assert "usage" in r.stdout.lower()
