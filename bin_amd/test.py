@@ -2,7 +2,7 @@
 interpolated and deblurred frames against the sharp ground truth) and demo.py (without) in one entry point.
 
     python -m bin_amd.test --netName bin_stage4 --input_path DATA/test_blur --gt_path DATA/test \\
-        --output_path OUT --opt bin_amd/options/train/train_adobe_stage4.yml [--time_step 0.5]
+        --output_path OUT --opt bin_amd/options/bin_stage4_adobe240.yml [--time_step 0.5]
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m bin_amd.test ... --launcher pytorch
 
 What the reference does per input frame `index` of a clip (test.py:236-402) and this keeps:

@@ -2,7 +2,7 @@
 update_learning_rate / save / save_training_state, data.create_dataset / create_dataloader, DistIterSampler,
 options.parse / check_resume) but no train.py; this is the loop those pieces imply.
 
-    python -m bin_amd.train -opt bin_amd/options/train/train_adobe_stage4.yml
+    python -m bin_amd.train -opt bin_amd/options/bin_stage4_adobe240.yml
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m bin_amd.train -opt X.yml --launcher pytorch
 
 One process per GPU; `datasets.train.batch_size` is the whole-job batch (// world_size per rank, data/__init__.py);
