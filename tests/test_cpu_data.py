@@ -312,3 +312,35 @@ def test_train_loop_world2_gloo(tmp_path, adobe):
         assert p.exitcode == 0
     assert got[0][1] == 0 and got[1][1] == 0
     assert got[0][2] == got[1][2]                            # ranks hold identical parameters after 3 DP steps
+
+
+def test_train_loop_reduce_lr_on_plateau(tmp_path, adobe, monkeypatch):
+    """The reference's own option file uses lr_scheme: ReduceLROnPlateau (factor 0.2, patience 1): the loop must step
+    that scheduler with the validation loss (and never through update_learning_rate, which has no metric)."""
+    from bin_amd import train
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setenv("CUDA_VISIBLE_DEVICES", "")
+    yml = _train_yml(tmp_path, adobe, niter=6)
+    y = open(yml).read().replace("lr_scheme: MultiStepLR", "lr_scheme: ReduceLROnPlateau\n  factor: 0.2\n  patience: 0")
+    open(yml, "w").write(y)
+    captured = {}
+
+    def factory(opt):
+        captured["m"] = _tiny_factory(opt)
+        # a criterion that grows every call: the validation loss never improves -> the plateau scheduler must fire
+        captured["m"].cri_pix = _Growing()
+        return captured["m"]
+
+    assert train.main(["-opt", yml], model_factory=factory) == 0
+    lr = captured["m"].get_current_learning_rate()[0]
+    assert lr < 1e-4 * 0.21                              # reduced at least once from lr_G = 1e-4
+
+
+class _Growing(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.k = 0
+
+    def forward(self, x, y):
+        self.k += 1
+        return torch.sqrt((x - y) ** 2 + 1e-6).mean() * (1.0 + 0.5 * self.k)
