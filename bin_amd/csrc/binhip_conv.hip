@@ -80,7 +80,8 @@ struct ConvCfg {
 
 // BINHIP_ABLATE (tools/ablate_kloop.py builds side libraries with it; 0 in the product): timing-only variants of the
 // K-loop — 1 no MFMA (fragment loads kept alive), 2 no fragment loads (MFMA on undefined registers), 3 no per-stage
-// barrier, 4 no DMA instructions.  Results are garbage by construction.
+// barrier, 4 no DMA instructions, 5 three-convs-in-one-launch without inter-workgroup sync (dbg bit 32).  Results are
+// garbage by construction.
 #ifndef BINHIP_ABLATE
 #define BINHIP_ABLATE 0
 #endif
@@ -241,7 +242,11 @@ __device__ __forceinline__ void compute_stage(const char* smem, int st, int buf,
 
 template <int KS, int MT, int WM, int R, int WN, int KC, int NT, int NBUF, int EPI>
 __global__ void __launch_bounds__(64 * WM * WN)
+#if BINHIP_ABLATE == 5
+conv_mfma_kernel(const ConvKArgs a0) {
+#else
 conv_mfma_kernel(const ConvKArgs a) {
+#endif
     using C = ConvCfg<KS, MT, WM, R, WN, KC, NT, NBUF, EPI>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -253,6 +258,17 @@ conv_mfma_kernel(const ConvKArgs a) {
     const int n = lane & 31;     // pixel column (B/N index) and cout row (A/M index) of this lane
     const int kg = lane >> 5;    // which 8-channel half of the 16-channel chunk
 
+#if BINHIP_ABLATE == 5
+    // timing experiment (tools/ablate_kloop.py): the three Cout=32 convs of a dense block as three PHASES of one launch
+    // with only a workgroup barrier in between — no inter-workgroup halo dependency, so the results are garbage; it
+    // measures what removing two launch boundaries per block could save at most
+    ConvKArgs a = a0;
+    const int nph = (KS == 3 && MT == 1 && EPI == BINHIP_EPI_PLANES && (a0.dbg & 32)) ? 3 : 1;
+    for (int ph = 0; ph < nph; ++ph) {
+    a.nchunks = a0.nchunks + 2 * ph;
+    a.y_hi = a0.y_hi + (long long)2 * ph * a0.N * a0.H * a0.W * 16;
+    if (ph) __syncthreads();
+#endif
     if (a.dbg & 16) return;      // timing experiments: empty kernel (launch + boundary only)
     int bid = blockIdx.x;
     if (a.xcd_remap) {
@@ -460,6 +476,9 @@ conv_mfma_kernel(const ConvKArgs a) {
             }
         }
     }
+#if BINHIP_ABLATE == 5
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------

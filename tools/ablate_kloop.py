@@ -12,7 +12,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 OUT = os.path.join(HERE, "_abl")
-VARIANTS = {0: "full", 1: "no MFMA", 2: "no fragment loads", 3: "no stage barrier", 4: "no DMA instructions"}
+VARIANTS = {0: "full", 1: "no MFMA", 2: "no fragment loads", 3: "no stage barrier", 4: "no DMA instructions",
+            5: "3 convs in 1 launch (no sync)"}
 
 
 def build():
@@ -45,6 +46,25 @@ def run_one(nterms):
     g = torch.Generator().manual_seed(0)
     x = ops.nchw_to_planes(torch.rand(n, 224, h, w, generator=g).to(dev), nterms=nterms)
     tag = os.environ.get("ABL_TAG", "?")
+    if tag.startswith("3 convs"):
+        wt = torch.randn(32, 192, 3, 3, generator=g) * 0.05
+        cw = ops.ConvWeights(wt.to(dev), torch.zeros(32, device=dev), nterms=nterms)
+        out = ops.CP.empty(8, n, h, w, nterms, dev)
+        for dbg, nm, chunks in ((0, "conv0 + conv1 + conv2 as 3 launches", (6, 8, 10)), (32, "the same as 3 phases of 1 launch", (6,))):
+            lib.binhip_set_variant(-2, dbg)
+            f = lambda: [ops.conv2d(x, cw, relu=True, out=out, cin_chunks=c) for c in chunks]
+            for _ in range(5):
+                f()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(50):
+                f()
+            e1.record()
+            torch.cuda.synchronize()
+            print(f"nt={nterms} {tag:30s} {nm:40s} {e0.elapsed_time(e1) / 50 * 1e3:7.1f} us per dense-block front", flush=True)
+        lib.binhip_set_variant(-2, 0)
+        return
     for cin in (96, 192):
         wt = torch.randn(32, cin, 3, 3, generator=g) * 0.05
         cw = ops.ConvWeights(wt.to(dev), torch.zeros(32, device=dev), nterms=nterms)
@@ -74,7 +94,10 @@ def main():
         return build()
     if args.one:
         return run_one(args.nterms)
+    only = os.environ.get("ABL_ONLY")
     for v, name in VARIANTS.items():
+        if only and str(v) not in only.split(","):
+            continue
         env = dict(os.environ, BIN_AMD_LIB=os.path.join(OUT, f"libbinhip_abl{v}.so"), ABL_TAG=name)
         subprocess.call([sys.executable, os.path.abspath(__file__), "--one", "--nterms", str(args.nterms)], env=env)
 
