@@ -525,6 +525,7 @@ int bh_conv_cout_block(int ksize, int cout_pad, int nterms) {
     if (cout_pad <= 0 || cout_pad % 32) return -1;
     if (cout_pad == 256) return nterms == 3 ? 64 : 128;     // UPNet.0 (PixelShuffle epilogue)
     if (ksize == 5) return 32;
+    if (ksize == 1 && cout_pad == 224) return 224;            // LFF backward-data: all 224 rows in one workgroup column
     if (cout_pad % 96 == 0) return 96;
     if (ksize == 3 && cout_pad % 64 == 0) return 64;
     return 32;
@@ -656,6 +657,7 @@ static int bh_dispatch_conv(const ConvKArgs& a0, int k, int cp, int nt, int e, h
                 default: return launch_cfg<3, 3, 1, 2, 4, 1, 1, 2, P>(a, cp, s);
             }
         }
+        if (e == P && k == 1 && cb == 224) return launch_cfg<1, 7, 1, 1, 8, 2, 1, 2, P>(a, cp, s);   // LFF dgrad, 8 waves x 1 row
         if (e == P && k == 1 && cb == 32)  return launch_cfg<1, 1, 1, 4, 4, 4, 1, 2, P>(a, cp, s);
         if (e == P && k == 1 && cb == 96) {
             switch (g_variant[CLS_K1C96]) {
@@ -707,6 +709,7 @@ static int bh_dispatch_conv(const ConvKArgs& a0, int k, int cp, int nt, int e, h
                 default: return launch_cfg<3, 3, 1, 1, 8, 1, 3, 2, P>(a, cp, s);   // 8 waves x 1 row: 168 vs 184 us
             }
         }
+        if (e == P && k == 1 && cb == 224) return launch_cfg<1, 7, 1, 1, 8, 1, 3, 2, P>(a, cp, s);   // LFF dgrad
         if (e == P && k == 1 && cb == 32)  return launch_cfg<1, 1, 1, 4, 4, 2, 3, 2, P>(a, cp, s);
         if (e == P && k == 1 && cb == 96) {
             switch (g_variant[CLS_K1C96]) {
@@ -844,10 +847,8 @@ __global__ void relayout_rdb_gather_kernel(GatherSrc src, int group, int rows, i
 extern "C" {
 
 int binhip_dgrad_rows_pad(int ksize, int cin) {
-    // rows of the backward-data conv = original input channels, padded to the kernel's cout granularity.  The LFF
-    // dgrad (224 rows) is padded to 288 = 3 x 96 so it runs 3 wide workgroup columns instead of 7 narrow ones
-    // (its input, the 96-channel output gradient, is re-read once per column).
-    if (ksize == 1 && cin == 224) return 288;
+    // rows of the backward-data conv = original input channels, padded to the kernel's cout granularity (the LFF
+    // dgrad's 224 rows form ONE 224-row workgroup column, so its input — the 96-channel output gradient — is read once)
     return ((cin + 31) / 32) * 32;
 }
 

@@ -61,7 +61,8 @@ def test_abi_error_codes_without_a_gpu():
     assert lib.binhip_weights_relayout(one, null, 32, 32, 3, 48, 2, 32, 0, one, null, one, null) == E_SHAPE   # cout_pad % 32
     assert lib.binhip_weights_relayout(one, null, 40, 32, 3, 32, 2, 32, 0, one, null, one, null) == E_SHAPE   # cout > cout_pad
     assert lib.binhip_weights_relayout_dgrad(one, 32, 96, 3, 96, 2, 40, 0, one, null, one, null) == E_SHAPE   # bad cout_block
-    assert lib.binhip_dgrad_rows_pad(1, 224) == 288 and lib.binhip_dgrad_rows_pad(3, 96) == 96
+    assert lib.binhip_dgrad_rows_pad(1, 224) == 224 and lib.binhip_dgrad_rows_pad(3, 96) == 96
+    assert lib.binhip_conv_cout_block(1, 224, 3) == 224 and lib.binhip_conv_cout_block(1, 96, 1) == 96
     plan = L.BinRdnPlan()
     plan.N, plan.H, plan.W, plan.n_inputs, plan.nterms = 1, 33, 32, 2, 1
     arr = (ctypes.c_void_p * 2)(16, 16)
