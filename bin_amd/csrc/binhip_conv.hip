@@ -526,6 +526,7 @@ int bh_conv_cout_block(int ksize, int cout_pad, int nterms) {
     if (cout_pad == 256) return nterms == 3 ? 64 : 128;     // UPNet.0 (PixelShuffle epilogue)
     if (ksize == 5) return 32;
     if (ksize == 1 && cout_pad == 224) return 224;            // LFF backward-data: all 224 rows in one workgroup column
+    if (ksize == 1 && cout_pad == 1152) return 192;           // GFF.0 backward-data: 6 columns instead of 12
     if (cout_pad % 96 == 0) return 96;
     if (ksize == 3 && cout_pad % 64 == 0) return 64;
     return 32;
@@ -658,6 +659,7 @@ static int bh_dispatch_conv(const ConvKArgs& a0, int k, int cp, int nt, int e, h
             }
         }
         if (e == P && k == 1 && cb == 224) return launch_cfg<1, 7, 1, 1, 8, 2, 1, 2, P>(a, cp, s);   // LFF dgrad, 8 waves x 1 row
+        if (e == P && k == 1 && cb == 192) return launch_cfg<1, 6, 1, 1, 8, 2, 1, 2, P>(a, cp, s);   // GFF.0 dgrad
         if (e == P && k == 1 && cb == 32)  return launch_cfg<1, 1, 1, 4, 4, 4, 1, 2, P>(a, cp, s);
         if (e == P && k == 1 && cb == 96) {
             switch (g_variant[CLS_K1C96]) {
@@ -710,6 +712,7 @@ static int bh_dispatch_conv(const ConvKArgs& a0, int k, int cp, int nt, int e, h
             }
         }
         if (e == P && k == 1 && cb == 224) return launch_cfg<1, 7, 1, 1, 8, 1, 3, 2, P>(a, cp, s);   // LFF dgrad
+        if (e == P && k == 1 && cb == 192) return launch_cfg<1, 6, 1, 1, 8, 1, 3, 2, P>(a, cp, s);   // GFF.0 dgrad
         if (e == P && k == 1 && cb == 32)  return launch_cfg<1, 1, 1, 4, 4, 2, 3, 2, P>(a, cp, s);
         if (e == P && k == 1 && cb == 96) {
             switch (g_variant[CLS_K1C96]) {
