@@ -83,3 +83,46 @@ def test_harness_helpers():
         if key.startswith("pad."):
             h, w = [int(v) for v in key[4:].split("x")]
             assert O.pad_sizes(h, w) == tuple(int(v) for v in g[key])
+
+
+def test_rdb_backward_data_gather_form_identity(canon_cpu):
+    """The algorithm behind binhip_weights_relayout_rdb_gather / binhip_rdn_backward, pinned on the CPU against torch
+    autograd of the oracle's dense block (RDN.py:132-165): concat group g (g = 0: the 96 block inputs, g = 1..3: conv
+    g-1's outputs) receives L_g (the LFF share, + gy on group 0) plus ONE forward-shaped conv of the stacked masked output
+    gradients of convs g..3 with weights Wg[r][32(c-g)+co][dy][dx] = W_c[co][base_g+r][2-dy][2-dx]."""
+    import torch.nn.functional as F
+    from oracle import rdn_oracle as O
+    W = {k: v.double() for k, v in canon_cpu.items() if k.startswith("model1.RDBs.3.")}
+    pre = "model1.RDBs.3"
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 96, 10, 14, generator=g, dtype=torch.float64, requires_grad=True)
+    gy = torch.randn(1, 96, 10, 14, generator=g, dtype=torch.float64)
+    y = O.rdb(x, W, pre)
+    (gx_ref,) = torch.autograd.grad(y, x, gy)
+    # forward activations of the four convs (for the ReLU masks)
+    acts, cat = [], x.detach()
+    for c in range(4):
+        a = F.relu(F.conv2d(cat, W[f"{pre}.convs.{c}.conv.0.weight"], W[f"{pre}.convs.{c}.conv.0.bias"], padding=1))
+        acts.append(a)
+        cat = torch.cat((cat, a), 1)
+    # L = LFF^T gy on all 224 channels (1x1 dgrad), + gy on the first 96 (the block's `+ x`)
+    L = F.conv2d(gy, W[f"{pre}.LFF.weight"].permute(1, 0, 2, 3))
+    L[:, :96] += gy
+
+    def gather_weight(group):
+        base = 0 if group == 0 else 96 + 32 * (group - 1)
+        rows = 96 if group == 0 else 32
+        parts = []
+        for c in range(group, 4):                                        # convs that read this group
+            wc = W[f"{pre}.convs.{c}.conv.0.weight"]                      # [32, 96+32c, 3, 3]
+            parts.append(wc[:, base:base + rows].flip(2, 3).permute(1, 0, 2, 3))      # [rows, 32, 3, 3]
+        return torch.cat(parts, 1)                                        # [rows, 32*(4-group), 3, 3]
+
+    G = [None] * 4                                                        # masked output gradients of conv 0..3
+    G[3] = L[:, 192:224] * (acts[3] > 0)
+    for group in (3, 2, 1):                                               # group g holds conv g-1's output
+        stacked = torch.cat(G[group:], 1)
+        tot = L[:, 96 + 32 * (group - 1):96 + 32 * group] + F.conv2d(stacked, gather_weight(group), padding=1)
+        G[group - 1] = tot * (acts[group - 1] > 0)
+    gx = L[:, :96] + F.conv2d(torch.cat(G, 1), gather_weight(0), padding=1)
+    assert float((gx - gx_ref).abs().max()) <= 1e-12 * max(1.0, float(gx_ref.abs().max()))
