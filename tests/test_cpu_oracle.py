@@ -126,3 +126,33 @@ def test_rdb_backward_data_gather_form_identity(canon_cpu):
         G[group - 1] = tot * (acts[group - 1] > 0)
     gx = L[:, :96] + F.conv2d(torch.cat(G, 1), gather_weight(0), padding=1)
     assert float((gx - gx_ref).abs().max()) <= 1e-12 * max(1.0, float(gx_ref.abs().max()))
+
+
+def test_f16x3_split_arithmetic_error_model():
+    """The numeric model of the `f16x3` precision mode, emulated in numpy: x = hi + lo with hi = fp16(x),
+    lo = fp16(x - hi); a dot product is Ah.Bh + Al.Bh + Ah.Bl accumulated in fp32 (the Al.Bl term is dropped).  For
+    conv-sized reductions of unit-scale data that is fp32-class (relative error ~1e-6), where a single fp16 product
+    (`f16` mode) is ~3e-4 and bf16 would be ~3e-3 — the reason the kernels use fp16 and not bf16 inputs."""
+    g = np.random.Generator(np.random.PCG64(0))
+    K = 9 * 192                                                         # the longest reduction of an RDB conv
+    a = g.standard_normal((64, K)) / np.sqrt(K)
+    b = g.uniform(0.0, 1.0, (K, 64))
+    exact = a @ b
+
+    def split(x):
+        hi = x.astype(np.float16)
+        lo = (x - hi.astype(np.float64)).astype(np.float16)
+        return hi.astype(np.float32), lo.astype(np.float32)
+
+    ah, al = split(a)
+    bh, bl = split(b)
+    one = ah @ bh
+    three = ah @ bh + al @ bh + ah @ bl
+    scale = np.abs(exact).max()
+    e1 = np.abs(one - exact).max() / scale
+    e3 = np.abs(three - exact).max() / scale
+    bf = lambda x: (x.astype(np.float32).view(np.uint32) & 0xFFFF0000).view(np.float32)      # bf16 by truncation
+    eb = np.abs(bf(a) @ bf(b) - exact).max() / scale
+    assert e3 < 2e-6 and 2e-5 < e1 < 2e-3 and eb > 4 * e1
+    # the split itself is exact to ~22 bits
+    assert np.abs((ah.astype(np.float64) + al) - a).max() <= 2.0 ** -21 * np.abs(a).max()
