@@ -139,12 +139,16 @@ def train_bench(args, rank, world, dev):
     from bin_amd.models import create_model
     from bin_amd.weights import reference_state_dict
     prec = args.train_precision
+    bwd_prec = None
+    if prec == "mixed":                      # fp32-class forward (exact loss / ReLU masks), single-product backward
+        prec, bwd_prec = "f16x3", "f16"
     if os.environ.get("BIN_AMD_WGRAD_DBG"):          # kernel A/B switch for tools/ experiments (binhip_wgrad_set_debug)
         from bin_amd import _lib
         _lib.lib().binhip_wgrad_set_debug(int(os.environ["BIN_AMD_WGRAD_DBG"]))
     tmp = tempfile.mkdtemp()
     opt = {"model": "bin", "gpu_ids": [0], "is_train": True, "dist": world > 1,
-           "network_G": {"which_model_G": "bin_stage4", "nframes": 6, "version": 2, "precision": prec},
+           "network_G": {"which_model_G": "bin_stage4", "nframes": 6, "version": 2, "precision": prec,
+                         "backward_precision": bwd_prec},
            "path": {"pretrain_model_G": None, "strict_load": True, "models": tmp, "training_state": tmp},
            "train": {"pixel_criterion": "cb", "pixel_weight": 1.0, "weight_decay_G": 0, "ft_tsa_only": None,
                      "lr_G": 1e-4, "beta1": 0.9, "beta2": 0.99, "lr_scheme": "MultiStepLR", "lr_steps": [100000],
@@ -180,10 +184,10 @@ def train_bench(args, rank, world, dev):
             "metric": "training samples/sec (256x256 crops, 6-frame windows)", "value": round(world * B * args.steps / dt, 4),
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": prec, "data": "synthetic", "loss": float(m.loss.detach()),
+            "vs_baseline": None, "dtype": args.train_precision, "data": "synthetic", "loss": float(m.loss.detach()),
             "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2),
             "config": {"workload": f"Adobe240 training, 256x256 crops, batch {B} per GPU, Charbonnier x17, Adam, "
-                                   f"DP flat gradient all-reduce (45.77 MB)", "precision": prec}}), flush=True)
+                                   f"DP flat gradient all-reduce (45.77 MB)", "precision": prec, "backward_precision": bwd_prec or prec}}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -206,7 +210,7 @@ def main():
                     help="train: BASELINE config 4 — one optimize_parameters() (fwd + Charbonnier + bwd + grad "
                          "all-reduce + Adam) on 256x256 crops, --batch samples per GPU (secondary metric, own JSON line)")
     ap.add_argument("--batch", type=int, default=8)
-    ap.add_argument("--train-precision", default="f16x3", choices=["f16", "f16x3"],
+    ap.add_argument("--train-precision", default="f16x3", choices=["f16", "f16x3", "mixed"],
                     help="precision of --mode train (default f16x3: fp32-class gradients)")
     ap.add_argument("--pipeline", action="store_true",
                     help="let consecutive steps overlap (side streams wait on the resident frames, not on the previous join)")

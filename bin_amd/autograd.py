@@ -27,6 +27,11 @@ from .rdn_plan import layer_names, rdn_forward, workspace
 # only through the regular path.
 DIRECT_PARAM_GRADS = False
 
+# "f16": with an f16x3 (fp32-class) forward, run the RDN backward single-product on the hi planes of the saved
+# activations (BINHIP_BWD_SAVED_X3) — loss and ReLU masks stay exact, gradients carry ~1e-3 relative rounding noise,
+# the step is ~1.4x faster.  Set from network_G.backward_precision / BIN_AMD_BACKWARD_PRECISION; None = same as forward.
+BACKWARD_PRECISION = os.environ.get("BIN_AMD_BACKWARD_PRECISION") or None
+
 
 def train_precision(module):
     from .models.archs.RDN import PRECISIONS
@@ -61,9 +66,12 @@ class _RdnFn(torch.autograd.Function):
         dev = gout.device
         gout = gout.contiguous().float()
         lib = L.lib()
-        dgw = module.kernel_weights(nterms).dgrad(module)
+        nt_bwd = 1 if (BACKWARD_PRECISION == "f16" and nterms == 3) else nterms
+        dgw = module.kernel_weights(nterms).dgrad(module, nt_bwd)
         plan = L.BinRdnBwdPlan()
-        plan.N, plan.H, plan.W, plan.n_inputs, plan.nterms = n, h, w, k, nterms
+        plan.N, plan.H, plan.W, plan.n_inputs, plan.nterms = n, h, w, k, nt_bwd
+        if nt_bwd != nterms:
+            plan.reserved = L.BWD_SAVED_X3
         dgw.fill_plan(plan)
         params = ctx.params
         direct = DIRECT_PARAM_GRADS and all(ctx.needs_input_grad[3 + k:])
@@ -76,7 +84,7 @@ class _RdnFn(torch.autograd.Function):
                 for p in params)
         if direct and have:
             grads = [p.grad for p in params]
-            plan.reserved = L.BWD_ACCUMULATE
+            plan.reserved |= L.BWD_ACCUMULATE
         else:
             grads = [torch.empty(shape, dtype=torch.float32, device=dev) for shape, _ in ctx.param_meta]
         for i in range(L.RDN_LAYERS):
@@ -91,7 +99,7 @@ class _RdnFn(torch.autograd.Function):
             else:
                 plan.gin[i] = None
                 gins.append(None)
-        nbytes = lib.binhip_rdn_backward_workspace_bytes(n, h, w, k, nterms)
+        nbytes = lib.binhip_rdn_backward_workspace_bytes(n, h, w, k, nt_bwd)
         ws = workspace(nbytes, dev, key="bwd")
         L.check(lib.binhip_rdn_backward(C.byref(plan), _ptr(ctx.saved_ws), ctx.saved_ws.numel(), _ptr(gout), _ptr(ws),
                                         ws.numel(), _stream()), "rdn_backward")

@@ -206,14 +206,19 @@ int binhip_rdn_backward(const BinRdnBwdPlan* p, const void* saved, size_t saved_
     if (N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return BINHIP_E_SHAPE;
     if (nin != 2 && nin != 3 && nin != 5) return BINHIP_E_SHAPE;
     if (nt != 1 && nt != 3) return BINHIP_E_ARG;
-    if (saved_bytes < binhip_rdn_workspace_bytes(N, H, W, nin, nt)) return BINHIP_E_WORKSPACE;
+    // BINHIP_BWD_SAVED_X3: the forward ran in the hi/lo (nterms = 3) layout but this backward computes single-product
+    // (nterms = 1): it reads the HI planes of the saved activations (an fp16 rounding of them; the ReLU masks are the
+    // sign of hi, which is the sign of hi + lo) at the offsets of the 3-term layout
+    const int nt_saved = (p->reserved & BINHIP_BWD_SAVED_X3) ? 3 : nt;
+    if (nt_saved == 3 && nt == 3 && (p->reserved & BINHIP_BWD_SAVED_X3)) return BINHIP_E_ARG;
+    if (saved_bytes < binhip_rdn_workspace_bytes(N, H, W, nin, nt_saved)) return BINHIP_E_WORKSPACE;
     const Bws b = make_bws(N, H, W, nin, nt);
     if (workspace_bytes < b.total_bytes) return BINHIP_E_WORKSPACE;
     for (int i = 0; i < BINHIP_RDN_LAYERS; ++i)
         if (!p->wt_hi[i] || (nt == 3 && !p->wt_lo[i]) || !p->dw[i] || !p->db[i]) return BINHIP_E_ARG;
 
     hipStream_t s = (hipStream_t)stream;
-    const Ws w = make_ws(N, H, W, nin, nt);
+    const Ws w = make_ws(N, H, W, nin, nt_saved);
     const int h = H / 2, ww = W / 2;
     const int64_t P = w.P;
     _Float16* sbase = (_Float16*)(((uintptr_t)saved + 255) & ~(uintptr_t)255);

@@ -43,12 +43,16 @@ class RdnWeights:
             plan.w_lo[i] = cw.w_lo.data_ptr() if cw.w_lo is not None else None
             plan.bias[i] = cw.bias.data_ptr()
 
-    def dgrad(self, module):
-        """Backward-data weights (transposed + flipped), built on first use for the same parameter version."""
+    def dgrad(self, module, nterms=None):
+        """Backward-data weights (transposed + flipped), built on first use for the same parameter version; `nterms`
+        other than the forward's for the single-product backward behind an f16x3 forward."""
+        nterms = self.nterms if nterms is None else nterms
         if self._dgrad is None:
+            self._dgrad = {}
+        if nterms not in self._dgrad:
             with torch.no_grad():
-                self._dgrad = RdnDgradWeights(dict(module.named_parameters()), self.n_inputs, self.nterms)
-        return self._dgrad
+                self._dgrad[nterms] = RdnDgradWeights(dict(module.named_parameters()), self.n_inputs, nterms)
+        return self._dgrad[nterms]
 
 
 class RdnDgradWeights:

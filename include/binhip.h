@@ -225,6 +225,9 @@ int binhip_convlstm_bwd(const float* x, const float* c_prev, const float* h_prev
  * parameters' .grad buffers when a weight set is shared by several calls) when `reserved` has
  * BINHIP_BWD_ACCUMULATE.  gin[i]: fp32 [N,3,H,W] or NULL.                                                */
 #define BINHIP_BWD_ACCUMULATE 1
+#define BINHIP_BWD_SAVED_X3   2   /* `saved` has the nterms = 3 layout while this plan's nterms is 1: a single-product
+                                   * backward behind the fp32-class forward (exact loss and ReLU masks, ~1e-3 relative
+                                   * gradient error); wt_* are then the nterms = 1 backward-data weights              */
 typedef struct BinRdnBwdPlan {
     int32_t N, H, W, n_inputs, nterms, reserved;   /* reserved = flags (BINHIP_BWD_*)                     */
     const void* wt_hi[BINHIP_RDN_LAYERS];   /* binhip_weights_relayout_dgrad outputs; for the slots   */
