@@ -7,12 +7,13 @@
 // (RDN.py:206) and the input-mean skip (RDN.py:221/279/333).
 //
 // Formulation: D[cout][pixel] += W[cout][tap][cin16] * X[cin16][pixel+tap] with
-// v_mfma_f32_32x32x16_f16 (A = weights, B = activations, fp32 accumulate).  A workgroup (4 wave64)
-// owns a TH x 32 pixel tile and COUTB output channels; per K-stage it DMA-copies
+// v_mfma_f32_32x32x16_f16 (A = weights, B = activations, fp32 accumulate).  A workgroup (4, 8 or 16
+// wave64) owns a TH x 32 pixel tile and COUTB output channels; per K-stage it DMA-copies
 // (buffer_load ... lds, 16 B/lane, zero-fill outside the image = the conv's zero padding) the
 // (TH+k-1) x (32+k-1) x 16-channel input patch and the k*k x COUTB x 16 weight slab into LDS,
-// double-buffered, then every wave runs k*k*MT*R MFMAs straight out of LDS (ds_read_b128, 16-byte
-// slots XOR-swizzled so each 16-lane read group hits 16 distinct bank slots).
+// double-buffered, then every wave runs k*k*MT*R MFMAs straight out of LDS with ds_read_b128: the
+// patch image is [channel half][pixel][16 B] (a 16-lane read group = 256 contiguous bytes, one per-lane
+// base + immediates), the weight slab keeps 16-byte slots XOR-swizzled by (row>>3)&1 from the relayout.
 // Precision: NT=1 -> one fp16 product; NT=3 -> hi/lo split, Ah*Bh + Al*Bh + Ah*Bl (fp32 class).
 #include "binhip_internal.h"
 #include <vector>
