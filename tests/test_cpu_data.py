@@ -344,3 +344,29 @@ class _Growing(torch.nn.Module):
     def forward(self, x, y):
         self.k += 1
         return torch.sqrt((x - y) ** 2 + 1e-6).mean() * (1.0 + 0.5 * self.k)
+
+
+def test_folder_runner_window_and_file_naming(tmp_path):
+    """bin_amd.test host logic (reference test.py:236-312): clips in sorted order, one window per frame but the last;
+    window `index` of a clip whose frame file is <num>.png writes <num+8> (interpolated), <num+4> and — except for the
+    clip's last window — <num+12> (deblurred); the six input frames are index + [-2..3] clamped to the clip."""
+    from bin_amd import harness
+    from bin_amd import test as run_test
+    for clip, first, n in (("b_clip", 40, 4), ("a_clip", 0, 3)):
+        d = tmp_path / clip
+        d.mkdir()
+        for k in range(n):
+            (d / f"{first + 8 * k:05d}.png").write_bytes(b"")
+        (d / "notes.txt").write_text("not a frame")
+    wins = run_test.list_windows(str(tmp_path))
+    assert [(c, i) for c, _, i in wins] == [("a_clip", 0), ("a_clip", 1), ("b_clip", 0), ("b_clip", 1), ("b_clip", 2)]
+    frames_b = wins[2][1]
+    assert frames_b == ["00040.png", "00048.png", "00056.png", "00064.png"]
+    assert run_test.output_names(frames_b, 0) == ("00048.png", "00044.png", "00052.png")
+    assert run_test.output_names(frames_b, 1) == ("00056.png", "00052.png", "00060.png")
+    assert run_test.output_names(frames_b, 2) == ("00064.png", "00060.png", None)          # last window: no second deblur
+    assert harness.window_frame_ids(0, 4) == [0, 0, 0, 1, 2, 3]
+    assert harness.window_frame_ids(2, 4) == [0, 1, 2, 3, 3, 3]
+    assert harness.window_frame_ids(5, 12) == [3, 4, 5, 6, 7, 8]
+    args = run_test.parse_args(["--input_path", "i", "--output_path", "o", "--opt", "x.yml", "--batch", "4"])
+    assert args.batch == 4 and args.gt_path is None and args.time_step == 0.5 and args.launcher == "none"
