@@ -274,3 +274,41 @@ def test_entry_points_parse_their_arguments():
         r = subprocess.run([sys.executable] + cmd, cwd=REPO, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (cmd, r.stderr[-500:])
         assert "usage" in r.stdout.lower()
+
+
+def test_harness_rules_properties():
+    """Property checks (hypothesis) of the host rules taken from test.py: padding (348-366), window frames (257-261),
+    window sharding."""
+    from hypothesis import given, settings, strategies as st
+    from bin_amd import harness
+    from bin_amd.utils import util
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.integers(2, 2000), st.integers(2, 3000))
+    def pads(h, w):
+        l, r, t, b = util.pad_sizes(h, w)
+        for size, lo, hi in ((w, l, r), (h, t, b)):
+            if size % 128 == 0:
+                assert (lo, hi) == (32, 32)                       # already a multiple: 32 px of context per side
+            else:
+                assert (size + lo + hi) % 128 == 0 and 0 <= hi - lo <= 1 and lo + hi < 128
+    pads()
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.integers(1, 500), st.integers(0, 499))
+    def frames(n, i):
+        i = i % n
+        ids = harness.window_frame_ids(i, n)
+        assert len(ids) == 6 and ids == sorted(ids) and ids[0] >= 0 and ids[-1] <= n - 1
+        assert ids[2] == i and all(b - a in (0, 1) for a, b in zip(ids, ids[1:]))
+    frames()
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.integers(0, 5000), st.integers(1, 64))
+    def shards(n, world):
+        spans = [harness.shard_windows(n, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [e - s for s, e in spans]
+        assert max(sizes) - min(sizes) <= 1
+    shards()
