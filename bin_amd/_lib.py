@@ -17,14 +17,14 @@ class BinConvDesc(C.Structure):
                 ("cin_chunks", C.c_int32), ("cout", C.c_int32), ("cout_pad", C.c_int32),
                 ("nterms", C.c_int32), ("epilogue", C.c_int32), ("relu", C.c_int32),
                 ("x_cpg", C.c_int32), ("x_group_stride", C.c_int64), ("n_images", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("reserved", C.c_int32), ("status", C.c_void_p)]
 
 
 class BinRdnPlan(C.Structure):
     _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("n_inputs", C.c_int32),
                 ("nterms", C.c_int32), ("reserved", C.c_int32),
                 ("w_hi", C.c_void_p * RDN_LAYERS), ("w_lo", C.c_void_p * RDN_LAYERS),
-                ("bias", C.c_void_p * RDN_LAYERS)]
+                ("bias", C.c_void_p * RDN_LAYERS), ("status", C.c_void_p), ("profiler", C.c_void_p)]
 
 
 class BinRdnBwdPlan(C.Structure):
@@ -32,7 +32,8 @@ class BinRdnBwdPlan(C.Structure):
                 ("nterms", C.c_int32), ("reserved", C.c_int32),
                 ("wt_hi", C.c_void_p * RDN_LAYERS), ("wt_lo", C.c_void_p * RDN_LAYERS),
                 ("zero_bias", C.c_void_p),
-                ("dw", C.c_void_p * RDN_LAYERS), ("db", C.c_void_p * RDN_LAYERS), ("gin", C.c_void_p * 5)]
+                ("dw", C.c_void_p * RDN_LAYERS), ("db", C.c_void_p * RDN_LAYERS), ("gin", C.c_void_p * 5),
+                ("status", C.c_void_p)]
 
 
 _SIGNATURES = {
@@ -71,7 +72,6 @@ _SIGNATURES = {
     "binhip_conv2d_bwd_data": (C.c_int, [C.POINTER(BinConvDesc)] + [C.c_void_p] * 7 + [C.c_int, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p,
                                          C.c_void_p, C.c_void_p]),
-    "binhip_wgrad_set_debug": (C.c_int, [C.c_int]),
     "binhip_wgrad_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
     "binhip_conv2d_bwd_weight": (C.c_int, [C.POINTER(BinConvDesc)] + [C.c_void_p] * 6 + [C.c_size_t, C.c_void_p,
                                            C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -88,15 +88,24 @@ _SIGNATURES = {
     "binhip_rdn_backward_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
     "binhip_rdn_backward": (C.c_int, [C.POINTER(BinRdnBwdPlan), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                       C.c_size_t, C.c_void_p]),
-    "binhip_set_variant": (C.c_int, [C.c_int, C.c_int]),
-    "binhip_profile_begin": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
-    "binhip_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)]),
-    "binhip_rdb_tail_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 10 + [C.c_int, C.c_void_p]),
-    "binhip_set_tail_depth": (C.c_int, [C.c_int]),
+    "binhip_profiler_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "binhip_profiler_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "binhip_profiler_destroy": (None, [C.c_void_p]),
+    "binhip_rdb_tail_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 10 +
+                            [C.c_int, C.c_void_p, C.c_void_p]),
     "binhip_rdn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "binhip_rdn_forward": (C.c_int, [C.POINTER(BinRdnPlan), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p,
                                      C.c_size_t, C.c_void_p]),
 }
+
+# Entry points that exist only in BINHIP_TUNING side builds (tools/: variant sweeps, ablations) — never in the product
+# library, and not declared in include/binhip.h.  Bound when present.
+_TUNING_SIGNATURES = {
+    "binhip_set_variant": (C.c_int, [C.c_int, C.c_int]),
+    "binhip_set_tail_depth": (C.c_int, [C.c_int]),
+    "binhip_wgrad_set_debug": (C.c_int, [C.c_int]),
+}
+STATUS_SATURATED = 1
 
 _lib = None
 
@@ -120,6 +129,11 @@ def lib():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
+        for name, (res, args) in _TUNING_SIGNATURES.items():
+            if hasattr(h, name):
+                fn = getattr(h, name)
+                fn.restype = res
+                fn.argtypes = args
         _lib = h
     return _lib
 

@@ -16,7 +16,7 @@ import os
 import torch
 
 from . import _lib as L
-from .ops import _ptr, _stream
+from .ops import _ptr, _stream, on_device, status_word
 from .rdn_plan import layer_names, rdn_forward, workspace
 
 
@@ -73,6 +73,7 @@ class _RdnFn(torch.autograd.Function):
         if nt_bwd != nterms:
             plan.reserved = L.BWD_SAVED_X3
         dgw.fill_plan(plan)
+        plan.status = status_word(dev).data_ptr()
         params = ctx.params
         direct = DIRECT_PARAM_GRADS and all(ctx.needs_input_grad[3 + k:])
         have = False
@@ -101,8 +102,9 @@ class _RdnFn(torch.autograd.Function):
                 gins.append(None)
         nbytes = lib.binhip_rdn_backward_workspace_bytes(n, h, w, k, nt_bwd)
         ws = workspace(nbytes, dev, key="bwd")
-        L.check(lib.binhip_rdn_backward(C.byref(plan), _ptr(ctx.saved_ws), ctx.saved_ws.numel(), _ptr(gout), _ptr(ws),
-                                        ws.numel(), _stream()), "rdn_backward")
+        with on_device(gout):
+            L.check(lib.binhip_rdn_backward(C.byref(plan), _ptr(ctx.saved_ws), ctx.saved_ws.numel(), _ptr(gout),
+                                            _ptr(ws), ws.numel(), _stream()), "rdn_backward")
         ctx.saved_ws = None
         if direct:
             if not have:

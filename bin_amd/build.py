@@ -9,7 +9,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["binhip_conv.hip", "binhip_fused.hip", "binhip_wgrad.hip", "binhip_misc.hip", "binhip_plan.hip"]
+SOURCES = ["binhip_conv.hip", "binhip_conv_x3.hip", "binhip_fused.hip", "binhip_wgrad.hip", "binhip_misc.hip", "binhip_plan.hip"]
 LIB_PATH = os.path.join(CSRC, "libbinhip.so")
 
 
@@ -22,27 +22,49 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=True):
-    """Compile every HIP source for gfx950 into bin_amd/csrc/libbinhip.so."""
-    if not force and not _stale():
+def build_library(force=False, verbose=True, defines=(), out=None):
+    """Compile every HIP source for gfx950 into bin_amd/csrc/libbinhip.so.
+
+    `defines` / `out`: side builds for tools/ (e.g. defines=("BINHIP_TUNING=1",), out="tools/_abl/libbinhip_tuning.so":
+    the kernel-variant / ablation switches, which the product library does not contain).  The sources are compiled in
+    parallel (one hipcc per file)."""
+    lib_path = out or LIB_PATH
+    if out is None and not force and not _stale():
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
+    objdir = CSRC if out is None else os.path.dirname(os.path.abspath(out))
+    os.makedirs(objdir, exist_ok=True)
+    tag = "" if out is None else "." + os.path.splitext(os.path.basename(out))[0]
+    procs, objs = [], []
     for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c",
-               os.path.join(CSRC, src), "-o", obj]
+        obj = os.path.join(objdir, src.replace(".hip", tag + ".o"))
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + [f"-D{d}" for d in defines] + \
+              ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
+        procs.append((cmd, subprocess.Popen(cmd)))
         objs.append(obj)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    return LIB_PATH
+    return lib_path
+
+
+TUNING_LIB = os.path.join(os.path.dirname(HERE), "tools", "_abl", "libbinhip_tuning.so")
+
+
+def build_tuning_library(verbose=True):
+    """Side build with the kernel-variant / ablation switches (BINHIP_TUNING): load it with BIN_AMD_LIB=<path>."""
+    return build_library(force=True, verbose=verbose, defines=("BINHIP_TUNING=1",), out=TUNING_LIB)
 
 
 if __name__ == "__main__":
-    build_library(force="--force" in sys.argv)
-    print(LIB_PATH)
+    if "--tuning" in sys.argv:
+        print(build_tuning_library())
+    else:
+        build_library(force="--force" in sys.argv)
+        print(LIB_PATH)

@@ -15,46 +15,10 @@
 // patch image is [channel half][pixel][16 B] (a 16-lane read group = 256 contiguous bytes, one per-lane
 // base + immediates), the weight slab keeps 16-byte slots XOR-swizzled by (row>>3)&1 from the relayout.
 // Precision: NT=1 -> one fp16 product; NT=3 -> hi/lo split, Ah*Bh + Al*Bh + Ah*Bl (fp32 class).
-#include "binhip_internal.h"
+#include "binhip_conv_common.h"
 #include <vector>
 #include <cstdio>
 #include <cstdlib>
-
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef __attribute__((address_space(3))) void lds_void_t;
-
-struct ConvKArgs {
-    const _Float16* x_hi;
-    const _Float16* x_lo;
-    const _Float16* w_hi;
-    const _Float16* w_lo;
-    const float* bias;
-    _Float16* y_hi;
-    _Float16* y_lo;
-    const _Float16* r_hi;
-    const _Float16* r_lo;
-    const _Float16* r2_hi;    // second residual (backward-data accumulation), same indexing as y
-    const _Float16* r2_lo;
-    const _Float16* m_hi;     // ReLU mask source (saved forward activation, hi plane), same indexing as y
-    float* out_f32;
-    const float* img[5];
-    long long group_stride;   // elements
-    int N, H, W;
-    int nchunks;
-    int cpg;
-    int tiles_x, tiles_y;
-    int relu, has_res, nimg, cout;
-    int xcd_remap;
-    int wt;                   // write-through (sc1) output stores
-    int och_limit;            // output chunks that exist at the destination (rows beyond are padding: not stored)
-    int dbg;                  // ablation switches (timing experiments only): 1 skip weight DMA, 2 skip patch DMA, 4 skip MFMA, 8 skip epilogue, 16 empty
-    int res_chunks;           // residual r applies to output chunks < res_chunks
-    int mask_from;            // mask applies to output chunks >= mask_from (when m_hi != null)
-    int y_cpg;                // output chunk grouping (<=0: one group)
-    long long y_group_stride;
-};
 
 template <int KS, int MT, int WM, int R, int WN, int KC, int NT, int NBUF, int EPI>
 struct ConvCfg {
@@ -79,12 +43,17 @@ struct ConvCfg {
     static_assert(NBUF <= 2 || (NBUF - 2) * PS <= 63, "vmcnt immediate range");
 };
 
-// BINHIP_ABLATE (tools/ablate_kloop.py builds side libraries with it; 0 in the product): timing-only variants of the
-// K-loop — 1 no MFMA (fragment loads kept alive), 2 no fragment loads (MFMA on undefined registers), 3 no per-stage
-// barrier, 4 no DMA instructions, 5 three-convs-in-one-launch without inter-workgroup sync (dbg bit 32).  Results are
-// garbage by construction.
+// BINHIP_ABLATE (side builds only; 0 in the product): timing-only variants of the K-loop — 1 no MFMA (fragment loads
+// kept alive), 2 no fragment loads (MFMA on undefined registers), 3 no per-stage barrier, 4 no DMA instructions.
+// Results are garbage by construction (round-1 findings: profiles/r01_layer_variants.md).
 #ifndef BINHIP_ABLATE
 #define BINHIP_ABLATE 0
+#endif
+// runtime ablation switches exist in BINHIP_TUNING side builds only; in the product the tests fold to `false`
+#if BINHIP_TUNING
+#define BH_DBG(a, bit) ((a).dbg & (bit))
+#else
+#define BH_DBG(a, bit) false
 #endif
 __device__ __forceinline__ half8 lds_ld8(const char* p) {
 #if BINHIP_ABLATE == 2
@@ -102,20 +71,6 @@ __device__ __forceinline__ floatx16 mfma16(half8 a, half8 b, floatx16 c) {
 #else
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 #endif
-}
-
-// 16-byte plane store.  wt != 0: write-through (sc1) so the XCD's L2 holds no dirty output lines at the end of the
-// kernel: the kernel-boundary release then has nothing to write back (MI355X: 8 XCDs with private, mutually
-// non-coherent L2s => every boundary flushes dirty lines; 16.5 MB of output costs ~2.8 us there).
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store16(_Float16* base, long long off_elems, uint4 v, int wt) {
-    if (wt) {
-        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0xFFFFFFFFu, 0x00020000);
-        u32x4 d = {v.x, v.y, v.z, v.w};
-        __builtin_amdgcn_raw_buffer_store_b128(d, rs, (int)(off_elems * 2), 0, 16);
-    } else {
-        *reinterpret_cast<uint4*>(base + off_elems) = v;
-    }
 }
 
 // Issue the LDS-DMA of K-stage `st` (KC chunks x NPL planes: input patch + weight slab) into buffer `buf`.
@@ -143,7 +98,7 @@ __device__ __forceinline__ void issue_stage(const ConvKArgs& a, char* smem, int 
 #pragma unroll
                 for (int j = 0; j < C::NPJ; ++j) {
                     const int i = wave + C::NW * j;
-                    const bool real = ((C::PP % C::NW == 0) || (i < C::PP)) && !(a.dbg & 2);
+                    const bool real = ((C::PP % C::NW == 0) || (i < C::PP)) && !BH_DBG(a, 2);
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(real ? lds + i * 1024 : dummy), 16,
                                                              real ? voff[j] : 0x80000000u, 0, 0, 0);
                 }
@@ -154,7 +109,7 @@ __device__ __forceinline__ void issue_stage(const ConvKArgs& a, char* smem, int 
 #pragma unroll
                 for (int j = 0; j < C::NWJ; ++j) {
                     const int i = wave + C::NW * j;
-                    const bool real = ((C::WP % C::NW == 0) || (i < C::WP)) && !(a.dbg & 1);
+                    const bool real = ((C::WP % C::NW == 0) || (i < C::WP)) && !BH_DBG(a, 1);
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(ws, (lds_void_t*)(real ? lds + (C::PP + i) * 1024 : dummy), 16,
                                                              real ? (unsigned)(lane * 16) : 0x80000000u,
                                                              real ? i * 1024 : 0, 0, 0);
@@ -162,11 +117,6 @@ __device__ __forceinline__ void issue_stage(const ConvKArgs& a, char* smem, int 
             }
         }
     }
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // Operand fragments of one (chunk, dx) step: R+KS-1 patch rows (B) and the KS x MT weight tiles of this tap column (A).
@@ -243,11 +193,7 @@ __device__ __forceinline__ void compute_stage(const char* smem, int st, int buf,
 
 template <int KS, int MT, int WM, int R, int WN, int KC, int NT, int NBUF, int EPI>
 __global__ void __launch_bounds__(64 * WM * WN)
-#if BINHIP_ABLATE == 5
-conv_mfma_kernel(const ConvKArgs a0) {
-#else
 conv_mfma_kernel(const ConvKArgs a) {
-#endif
     using C = ConvCfg<KS, MT, WM, R, WN, KC, NT, NBUF, EPI>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -259,25 +205,9 @@ conv_mfma_kernel(const ConvKArgs a) {
     const int n = lane & 31;     // pixel column (B/N index) and cout row (A/M index) of this lane
     const int kg = lane >> 5;    // which 8-channel half of the 16-channel chunk
 
-#if BINHIP_ABLATE == 5
-    // timing experiment (tools/ablate_kloop.py): the three Cout=32 convs of a dense block as three PHASES of one launch
-    // with only a workgroup barrier in between — no inter-workgroup halo dependency, so the results are garbage; it
-    // measures what removing two launch boundaries per block could save at most
-    ConvKArgs a = a0;
-    const int nph = (KS == 3 && MT == 1 && EPI == BINHIP_EPI_PLANES && (a0.dbg & 32)) ? 3 : 1;
-    for (int ph = 0; ph < nph; ++ph) {
-    a.nchunks = a0.nchunks + 2 * ph;
-    a.y_hi = a0.y_hi + (long long)2 * ph * a0.N * a0.H * a0.W * 16;
-    if (ph) __syncthreads();
-#endif
-    if (a.dbg & 16) return;      // timing experiments: empty kernel (launch + boundary only)
+    if (BH_DBG(a, 16)) return;   // timing experiments: empty kernel (launch + boundary only)
     int bid = blockIdx.x;
-    if (a.xcd_remap) {
-        // consecutive workgroup ids land on different XCDs (private L2s): give each XCD a contiguous band of tiles
-        // so the halo rows/columns neighbouring tiles share are L2 hits (bijective for any grid size)
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-    }
+    if (a.xcd_remap) bid = xcd_band(bid, gridDim.x);
     const int tx = bid % a.tiles_x;
     bid /= a.tiles_x;
     const int ty = bid % a.tiles_y;
@@ -356,151 +286,18 @@ conv_mfma_kernel(const ConvKArgs a) {
         }
     }
 
-    // ---- epilogue -------------------------------------------------------------------------------
-    // acc[mt][r][4g+j] = D[cout = 8g + 4*kg + j][pixel = n]  (32x32 MFMA C/D layout): a lane holds 4 consecutive
-    // channels of one pixel per g, and lanes n / n+32 hold the two halves of each 8-channel slot.  One
-    // v_permlane32_swap per dword turns a (g even, g odd) pair into full 16-byte slots — lanes 0-31 get slot 0, lanes
-    // 32-63 slot 1 of the same pixel — so every store instruction writes 32 pixels x 32 B = 1 KiB contiguous.
-    if (a.dbg & 8) { if (acc[0][0][0] == 12345.f) a.y_hi[0] = (_Float16)1.f; return; }   // timing: no epilogue
-    const int gx = tx0 + n;
-    if constexpr (EPI == BINHIP_EPI_FINAL) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int gy = ty0 + wn * R + r;
-            if (!((gy < H) && (gx < W)) || kg != 0 || z != 0 || wm != 0) continue;
-            const float4 bv = *reinterpret_cast<const float4*>(a.bias);
-            const float v[4] = {acc[0][r][0] + bv.x, acc[0][r][1] + bv.y, acc[0][r][2] + bv.z, acc[0][r][3] + bv.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (j >= a.cout) break;
-                const long long idx = (((long long)img * a.cout + j) * H + gy) * W + gx;
-                float s = 0.f;
-                if (a.nimg > 0) {
-                    s = a.img[0][idx];
-                    for (int t = 1; t < a.nimg; ++t) s += a.img[t][idx];
-                    s = s / (float)a.nimg;
-                }
-                a.out_f32[idx] = v[j] + s;
-            }
-        }
-    } else {
-        union H4 { half4 h; unsigned u[2]; };
-        const int gxc = gx < W ? gx : W - 1;     // clamped coordinates: loads need no branch, stores are predicated
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int gy = ty0 + wn * R + r;
-            const bool ok = (gy < H) && (gx < W);
-            const int gyc = gy < H ? gy : H - 1;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-                for (int gp = 0; gp < 2; ++gp) {
-                    H4 hv[2], lv[2];
-                    long long o_slot = 0;        // element offset of this lane's 16-byte slot after the swap
-#pragma unroll
-                    for (int ge = 0; ge < 2; ++ge) {
-                        const int g = 2 * gp + ge;
-                        const int co = z * C::COUTB + (wm * MT + mt) * 32 + 8 * g + 4 * kg;
-                        const float4 bv = *reinterpret_cast<const float4*>(a.bias + co);
-                        float v[4] = {acc[mt][r][4 * g + 0] + bv.x, acc[mt][r][4 * g + 1] + bv.y,
-                                      acc[mt][r][4 * g + 2] + bv.z, acc[mt][r][4 * g + 3] + bv.w};
-                        long long o;
-                        if constexpr (EPI == BINHIP_EPI_SHUFFLE) {
-                            const int cq = (a.cout + 3) / 4;      // channels after the shuffle
-                            const int sub = co / cq, cc = co - sub * cq;
-                            const int oy = 2 * gyc + (sub >> 1), ox = 2 * gxc + (sub & 1);
-                            o = (long long)(cc >> 4) * (plane_elems * 4) +
-                                ((((long long)img * 2 * H + oy) * (2 * W) + ox) << 4) + (cc & 15);
-                        } else {
-                            const int och = co >> 4;
-                            const long long pix16 = ((((long long)img * H + gyc) * W + gxc) << 4) + (co & 15);
-                            o = (a.y_cpg > 0)
-                                ? (long long)(och / a.y_cpg) * a.y_group_stride + (long long)(och % a.y_cpg) * plane_elems + pix16
-                                : (long long)och * plane_elems + pix16;
-                            {
-                                if (a.has_res && och < a.res_chunks && och < a.och_limit) {
-                                    const half4 rh = *reinterpret_cast<const half4*>(a.r_hi + o);
-#pragma unroll
-                                    for (int j = 0; j < 4; ++j) v[j] += (float)rh[j];
-                                    if constexpr (NT == 3) {
-                                        const half4 rl = *reinterpret_cast<const half4*>(a.r_lo + o);
-#pragma unroll
-                                        for (int j = 0; j < 4; ++j) v[j] += (float)rl[j];
-                                    }
-                                }
-                                if (a.r2_hi && och < a.och_limit) {
-                                    const half4 rh = *reinterpret_cast<const half4*>(a.r2_hi + o);
-#pragma unroll
-                                    for (int j = 0; j < 4; ++j) v[j] += (float)rh[j];
-                                    if constexpr (NT == 3) {
-                                        const half4 rl = *reinterpret_cast<const half4*>(a.r2_lo + o);
-#pragma unroll
-                                        for (int j = 0; j < 4; ++j) v[j] += (float)rl[j];
-                                    }
-                                }
-                            }
-                            if (a.relu) {
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-                            }
-                            if (a.m_hi && och >= a.mask_from && och < a.och_limit) {
-                                const half4 mh = *reinterpret_cast<const half4*>(a.m_hi + o);
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) v[j] = ((float)mh[j] > 0.f) ? v[j] : 0.f;
-                            }
-                        }
-                        // after the swap, lanes 0-31 own slot 0 (g even) and lanes 32-63 slot 1 (g odd) of pixel n:
-                        // the slot start is this (g, kg=0) element offset
-                        if (ge == kg) o_slot = o - 4 * kg;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            hv[ge].h[j] = (_Float16)v[j];
-                            lv[ge].h[j] = (_Float16)(v[j] - (float)hv[ge].h[j]);
-                        }
-                    }
-                    // vdst = even group, src = odd group: upper half of vdst <-> lower half of src
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        auto sw = __builtin_amdgcn_permlane32_swap(hv[0].u[k], hv[1].u[k], false, false);
-                        hv[0].u[k] = sw[0]; hv[1].u[k] = sw[1];
-                        if constexpr (NT == 3) {
-                            auto sl = __builtin_amdgcn_permlane32_swap(lv[0].u[k], lv[1].u[k], false, false);
-                            lv[0].u[k] = sl[0]; lv[1].u[k] = sl[1];
-                        }
-                    }
-                    if (ok && ((z * C::COUTB + (wm * MT + mt) * 32 + 16 * gp) >> 4) < a.och_limit) {
-                        store16(a.y_hi, o_slot, make_uint4(hv[0].u[0], hv[0].u[1], hv[1].u[0], hv[1].u[1]), a.wt);
-                        if constexpr (NT == 3)
-                            store16(a.y_lo, o_slot, make_uint4(lv[0].u[0], lv[0].u[1], lv[1].u[0], lv[1].u[1]), a.wt);
-                    }
-                }
-            }
-        }
-    }
-#if BINHIP_ABLATE == 5
-    }
-#endif
+    // ---- epilogue (binhip_conv_common.h) ----------------------------------------------------------
+    if (BH_DBG(a, 8)) { if (acc[0][0][0] == 12345.f) a.y_hi[0] = (_Float16)1.f; return; }   // timing: no epilogue
+    conv_epilogue<MT, R, NT, EPI>(a, acc, img, ty0 + wn * R, tx0, z * C::COUTB + wm * MT * 32, z == 0 && wm == 0, n, kg,
+                                  plane_elems);
 }
 
 // ---------------------------------------------------------------------------------------------------
 template <int KS, int MT, int WM, int R, int WN, int KC, int NT, int NBUF, int EPI>
 static int launch_cfg(const ConvKArgs& ka, int cout_pad, hipStream_t s) {
     using C = ConvCfg<KS, MT, WM, R, WN, KC, NT, NBUF, EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<KS, MT, WM, R, WN, KC, NT, NBUF, EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-        if (getenv("BINHIP_DEBUG")) {
-            int nb = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(
-                &nb, reinterpret_cast<const void*>(&conv_mfma_kernel<KS, MT, WM, R, WN, KC, NT, NBUF, EPI>), 64 * C::NW,
-                C::LDS_BYTES);
-            fprintf(stderr, "[binhip] conv<%d,%d,%d,%d,%d,%d,%d,%d,%d> threads %d LDS %d B -> %d workgroups/CU (API)\n", KS, MT,
-                    WM, R, WN, KC, NT, NBUF, EPI, 64 * C::NW, C::LDS_BYTES, nb);
-        }
-    }
+    static std::atomic<unsigned long long> lds_set{0};
+    if (int rc = bh_set_max_lds(&conv_mfma_kernel<KS, MT, WM, R, WN, KC, NT, NBUF, EPI>, C::LDS_BYTES, lds_set)) return rc;
     ConvKArgs a = ka;
     a.tiles_x = (a.W + 31) / 32;
     a.tiles_y = (a.H + C::TH - 1) / C::TH;
@@ -510,17 +307,15 @@ static int launch_cfg(const ConvKArgs& ka, int cout_pad, hipStream_t s) {
     return 0;
 }
 
-// ---- optional live profiling of ONE kernel class with HIP events on the launch stream -------------
-// (bench.py's roofline leg: average duration of the dominant kernel inside the timed region)
-namespace {
-struct Prof {
-    bool active = false;
+// ---- optional live timing of ONE kernel class with HIP events on the launch stream ---------------------
+// (bench.py's roofline leg: average duration of the dominant kernel inside the timed region).  An explicit handle
+// the caller creates and passes with each plan — the library keeps no process-global state.
+struct BinhipProfiler {
     int ks = 0, cout_pad = 0, epi = 0;
     std::vector<hipEvent_t> ev;   // pairs: start, stop
     size_t used = 0;
-} g_prof;
-constexpr size_t PROF_MAX_PAIRS = 16384;
-}  // namespace
+};
+namespace { constexpr size_t PROF_MAX_PAIRS = 16384; }
 
 int bh_conv_cout_block(int ksize, int cout_pad, int nterms) {
     if (cout_pad <= 0 || cout_pad % 32) return -1;
@@ -534,6 +329,7 @@ int bh_conv_cout_block(int ksize, int cout_pad, int nterms) {
 }
 
 static int bh_dispatch_conv(const ConvKArgs& a, int k, int cp, int nt, int e, hipStream_t s);
+int bh_launch_conv_x3(const ConvKArgs& a, int cout_pad, int epilogue, hipStream_t s);   // binhip_conv_x3.hip
 
 int bh_launch_conv(const BhConvCall& c, hipStream_t s) {
     const BinConvDesc& d = c.d;
@@ -550,6 +346,7 @@ int bh_launch_conv(const BhConvCall& c, hipStream_t s) {
     a.r_hi = (const _Float16*)c.r_hi; a.r_lo = (const _Float16*)c.r_lo;
     a.r2_hi = (const _Float16*)c.r2_hi; a.r2_lo = (const _Float16*)c.r2_lo;
     a.m_hi = (const _Float16*)c.m_hi;
+    a.flags = (unsigned*)c.status;
     a.res_chunks = c.res_chunks > 0 ? c.res_chunks : (1 << 30);
     a.mask_from = c.mask_from;
     a.y_cpg = c.y_cpg; a.y_group_stride = c.y_group_stride;
@@ -563,7 +360,7 @@ int bh_launch_conv(const BhConvCall& c, hipStream_t s) {
     a.relu = d.relu; a.has_res = (c.r_hi != nullptr); a.nimg = d.n_images; a.cout = d.cout;
     a.och_limit = (d.epilogue == BINHIP_EPI_PLANES) ? (d.cout + 15) / 16 : (1 << 30);
     a.tiles_x = a.tiles_y = 0;
-    a.xcd_remap = 0;
+    a.xcd_remap = 1;
     a.dbg = 0;
     a.wt = 0;
     const int P = BINHIP_EPI_PLANES, S = BINHIP_EPI_SHUFFLE, F = BINHIP_EPI_FINAL;
@@ -579,160 +376,90 @@ int bh_launch_conv(const BhConvCall& c, hipStream_t s) {
         return BINHIP_E_ARG;
     }
     const int k = d.ksize, cp = d.cout_pad, nt = d.nterms, e = d.epilogue;
-    if (g_prof.active && k == g_prof.ks && cp == g_prof.cout_pad && e == g_prof.epi &&
-        g_prof.used + 2 <= g_prof.ev.size()) {
-        hipEvent_t e0 = g_prof.ev[g_prof.used], e1 = g_prof.ev[g_prof.used + 1];
+    BinhipProfiler* pr = c.prof;
+    if (pr && k == pr->ks && cp == pr->cout_pad && e == pr->epi && pr->used + 2 <= pr->ev.size()) {
+        hipEvent_t e0 = pr->ev[pr->used], e1 = pr->ev[pr->used + 1];
         (void)hipEventRecord(e0, s);
         const int rc = bh_dispatch_conv(a, k, cp, nt, e, s);
         (void)hipEventRecord(e1, s);
-        g_prof.used += 2;
+        pr->used += 2;
         return rc;
     }
     return bh_dispatch_conv(a, k, cp, nt, e, s);
 }
 
-// Kernel-configuration variants per layer class (tuning knob, see tools/bench_layers.py); the defaults below are
-// the measured-best ones on MI355X.
-// -1 = automatic (measured-best on MI355X at the 720p working size, see profiles/r01_layer_variants.md)
-static int g_variant[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
-static int g_xcd_remap = 1;
-static int g_dbg = 0;
-static int g_wt = 1;
+// Kernel configuration per layer class: the measured-best tile shapes on MI355X at the 720p working size
+// (profiles/r01_layer_variants.md, profiles/r02_*).  BINHIP_TUNING side builds (tools/) additionally compile the
+// alternatives below and the process-global switches that pick them; the product library has neither.
 enum { CLS_K3C32 = 0, CLS_K1C96 = 1, CLS_K3C96 = 2, CLS_SHUFFLE = 3, CLS_FINAL = 4, CLS_K5 = 5 };
+#if BINHIP_TUNING
+static int g_variant[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+static int g_xcd_remap = 1, g_dbg = 0, g_wt = 1;
+#define BH_VARIANT(cls) g_variant[cls]
+#else
+#define BH_VARIANT(cls) (-1)
+#endif
 
 static int bh_dispatch_conv(const ConvKArgs& a0, int k, int cp, int nt, int e, hipStream_t s) {
     const int P = BINHIP_EPI_PLANES, S = BINHIP_EPI_SHUFFLE, F = BINHIP_EPI_FINAL;
     const int cb = bh_conv_cout_block(k, cp, nt);
     if (cb <= 0 || cp % cb) return BINHIP_E_SHAPE;
     ConvKArgs a = a0;
+    int wt_on = 1;
+#if BINHIP_TUNING
     a.xcd_remap = g_xcd_remap;
     a.dbg = g_dbg;
+    wt_on = g_wt;
+#endif
     {   // 32-bit buffer offsets: write-through path only while the whole output tensor stays below 4 GiB
         const long long out_chunks = (e == BINHIP_EPI_SHUFFLE) ? (a.cout / 4 + 15) / 16 : (cp + 15) / 16;
         const long long px = (long long)a.N * a.H * a.W * ((e == BINHIP_EPI_SHUFFLE) ? 4 : 1);
         const long long span = (a.y_cpg > 0 ? ((out_chunks + a.y_cpg - 1) / a.y_cpg) * a.y_group_stride * 2 : out_chunks * px * 32);
         // PLANES only: the PixelShuffle store (16 B per lane at a 64-B stride) relies on L2 to merge partial lines
-        a.wt = (g_wt && e == BINHIP_EPI_PLANES && span < (1ll << 32) - 64) ? 1 : 0;
+        a.wt = (wt_on && e == BINHIP_EPI_PLANES && span < (1ll << 32) - 64) ? 1 : 0;
     }
     //                                   KS MT WM R WN KC NT NBUF EPI
     if (nt == 1) {
-        if (e == F && k == 3 && cp == 32) {
-            switch (g_variant[CLS_FINAL]) {
-                case 1: return launch_cfg<3, 1, 1, 2, 8, 1, 1, 2, F>(a, cp, s);    // 8 waves, 16x32 tile
-                case 2: return launch_cfg<3, 1, 1, 4, 8, 1, 1, 2, F>(a, cp, s);    // 8 waves, 32x32 tile
-                case 3: return launch_cfg<3, 1, 1, 2, 4, 1, 1, 2, F>(a, cp, s);    // 4 waves, 8x32 tile
-                case 0: return launch_cfg<3, 1, 1, 4, 4, 1, 1, 2, F>(a, cp, s);
-                default: return launch_cfg<3, 1, 1, 2, 8, 1, 1, 2, F>(a, cp, s);   // 8 waves, 16x32 tile: 45 vs 55 us
-            }
-        }
-        if (e == S && k == 3 && cp == 256) {
-            switch (g_variant[CLS_SHUFFLE]) {
-                case 0: return launch_cfg<3, 2, 2, 4, 2, 1, 1, 2, S>(a, cp, s);
-                default: return launch_cfg<3, 2, 2, 4, 4, 1, 1, 2, S>(a, cp, s);     // 8 waves, 16x32 tile
-            }
-        }
+        if (e == F && k == 3 && cp == 32) return launch_cfg<3, 1, 1, 2, 8, 1, 1, 2, F>(a, cp, s);     // 8 waves, 16x32 tile
+        if (e == S && k == 3 && cp == 256) return launch_cfg<3, 2, 2, 4, 4, 1, 1, 2, S>(a, cp, s);    // 8 waves, 16x32 tile, 128 rows
         if (e == P && k == 3 && cb == 32) {
-            switch (g_variant[CLS_K3C32]) {
-                case 1: return launch_cfg<3, 1, 1, 4, 4, 1, 1, 3, P>(a, cp, s);
-                case 2: return launch_cfg<3, 1, 1, 4, 4, 1, 1, 4, P>(a, cp, s);
-                case 3: return launch_cfg<3, 1, 1, 4, 8, 1, 1, 2, P>(a, cp, s);
-                case 4: return launch_cfg<3, 1, 1, 4, 8, 1, 1, 3, P>(a, cp, s);
-                case 5: return launch_cfg<3, 1, 1, 2, 4, 1, 1, 2, P>(a, cp, s);
-                case 6: return launch_cfg<3, 1, 1, 2, 4, 1, 1, 3, P>(a, cp, s);
-                case 7: return launch_cfg<3, 1, 1, 2, 8, 1, 1, 2, P>(a, cp, s);
-                case 8: return launch_cfg<3, 1, 1, 3, 4, 1, 1, 2, P>(a, cp, s);
-                case 9: return launch_cfg<3, 1, 1, 2, 8, 1, 1, 3, P>(a, cp, s);
-                case 10: return launch_cfg<3, 1, 1, 3, 4, 1, 1, 3, P>(a, cp, s);   // 12x32 tile, depth 3, 73 KB -> 2 wg/CU
-                case 11: return launch_cfg<3, 1, 1, 2, 4, 1, 1, 4, P>(a, cp, s);   // 8x32 tile, depth 4, 81 KB
-                case 12: return launch_cfg<3, 1, 1, 2, 16, 1, 1, 2, P>(a, cp, s);  // 16 waves, 32x32 tile, 1 wg/CU: weights once per CU
-                case 0: return launch_cfg<3, 1, 1, 4, 4, 1, 1, 2, P>(a, cp, s);
-                default: return launch_cfg<3, 1, 1, 2, 8, 1, 1, 2, P>(a, cp, s);     // 8 waves x 2 rows, 16x32 tile
-            }
+#if BINHIP_TUNING
+            if (BH_VARIANT(CLS_K3C32) == 0) return launch_cfg<3, 1, 1, 4, 4, 1, 1, 2, P>(a, cp, s);    // 4 waves x 4 rows
+            if (BH_VARIANT(CLS_K3C32) == 12) return launch_cfg<3, 1, 1, 2, 16, 1, 1, 2, P>(a, cp, s);  // 16 waves, 32x32 tile
+#endif
+            return launch_cfg<3, 1, 1, 2, 8, 1, 1, 2, P>(a, cp, s);                                     // 8 waves x 2 rows, 16x32 tile
         }
         if (e == P && k == 3 && cb == 64)  return launch_cfg<3, 2, 1, 2, 4, 1, 1, 2, P>(a, cp, s);
-        if (e == P && k == 3 && cb == 96) {
-            switch (g_variant[CLS_K3C96]) {
-                case 1: return launch_cfg<3, 3, 1, 2, 4, 1, 1, 3, P>(a, cp, s);
-                case 2: return launch_cfg<3, 3, 1, 2, 8, 1, 1, 2, P>(a, cp, s);    // 8 waves, 16x32 tile
-                case 3: return launch_cfg<3, 3, 1, 1, 8, 1, 1, 2, P>(a, cp, s);    // 8 waves x 1 row, 8x32 tile
-                case 4: return launch_cfg<3, 3, 1, 1, 4, 1, 1, 2, P>(a, cp, s);    // 4 waves x 1 row, 4x32 tile
-                default: return launch_cfg<3, 3, 1, 2, 4, 1, 1, 2, P>(a, cp, s);
-            }
-        }
+        if (e == P && k == 3 && cb == 96)  return launch_cfg<3, 3, 1, 2, 4, 1, 1, 2, P>(a, cp, s);
         if (e == P && k == 1 && cb == 224) return launch_cfg<1, 7, 1, 1, 8, 2, 1, 2, P>(a, cp, s);   // LFF dgrad, 8 waves x 1 row
         if (e == P && k == 1 && cb == 192) return launch_cfg<1, 6, 1, 1, 8, 2, 1, 2, P>(a, cp, s);   // GFF.0 dgrad
         if (e == P && k == 1 && cb == 32)  return launch_cfg<1, 1, 1, 4, 4, 4, 1, 2, P>(a, cp, s);
         if (e == P && k == 1 && cb == 96) {
-            switch (g_variant[CLS_K1C96]) {
-                case 1: return launch_cfg<1, 3, 1, 2, 4, 2, 1, 2, P>(a, cp, s);
-                case 2: return launch_cfg<1, 3, 1, 2, 4, 2, 1, 3, P>(a, cp, s);
-                case 3: return launch_cfg<1, 3, 1, 4, 4, 2, 1, 2, P>(a, cp, s);
-                case 4: return launch_cfg<1, 3, 1, 2, 4, 1, 1, 4, P>(a, cp, s);
-                case 5: return launch_cfg<1, 3, 1, 4, 4, 2, 1, 3, P>(a, cp, s);
-                case 6: return launch_cfg<1, 3, 1, 2, 8, 2, 1, 2, P>(a, cp, s);    // 8 waves, 16x32 tile
-                case 7: return launch_cfg<1, 3, 1, 1, 8, 2, 1, 2, P>(a, cp, s);    // 8 waves x 1 row
-                case 0: return launch_cfg<1, 3, 1, 2, 4, 4, 1, 2, P>(a, cp, s);
-                default:
-                    // short K (LFF, LFF dgrad): 8 waves x 1 row, 38.6 vs 49.6 us; long K (GFF.0, 72 chunks): the 4-wave tile
-                    if (a.nchunks >= 32) return launch_cfg<1, 3, 1, 2, 4, 2, 1, 2, P>(a, cp, s);
-                    return launch_cfg<1, 3, 1, 1, 8, 2, 1, 2, P>(a, cp, s);
-            }
+            // short K (LFF, LFF dgrad): 8 waves x 1 row, 38.6 vs 49.6 us; long K (GFF.0, 72 chunks): the 4-wave tile
+            if (a.nchunks >= 32) return launch_cfg<1, 3, 1, 2, 4, 2, 1, 2, P>(a, cp, s);
+            return launch_cfg<1, 3, 1, 1, 8, 2, 1, 2, P>(a, cp, s);
         }
-        if (e == P && k == 5 && cb == 32) {
-            switch (g_variant[CLS_K5]) {
-                case 1: return launch_cfg<5, 1, 1, 2, 8, 1, 1, 2, P>(a, cp, s);    // 8 waves, 16x32 tile
-                case 2: return launch_cfg<5, 1, 1, 4, 8, 1, 1, 2, P>(a, cp, s);    // 8 waves, 32x32 tile
-                case 3: return launch_cfg<5, 1, 1, 2, 4, 1, 1, 2, P>(a, cp, s);    // 4 waves, 8x32 tile
-                case 0: return launch_cfg<5, 1, 1, 4, 4, 1, 1, 2, P>(a, cp, s);
-                default: return launch_cfg<5, 1, 1, 2, 8, 1, 1, 2, P>(a, cp, s);   // 8 waves, 16x32 tile: 69 vs 83 us
-            }
-        }
+        if (e == P && k == 5 && cb == 32)  return launch_cfg<5, 1, 1, 2, 8, 1, 1, 2, P>(a, cp, s);   // 8 waves, 16x32 tile
     } else {
-        if (e == F && k == 3 && cp == 32) {
-            switch (g_variant[CLS_FINAL]) {
-                case 0: return launch_cfg<3, 1, 1, 4, 4, 1, 3, 2, F>(a, cp, s);
-                default: return launch_cfg<3, 1, 1, 2, 8, 1, 3, 2, F>(a, cp, s);   // 130 vs 162 us
-            }
+        if ((e == F && k == 3 && cp == 32) || (e == P && k == 3 && cb == 32)) {
+#if BINHIP_TUNING
+            // the generic both-planes-per-stage kernel (117 KB LDS, 157 VGPRs, 1 workgroup/CU): round-1 default
+            if (BH_VARIANT(e == F ? CLS_FINAL : CLS_K3C32) == 1)
+                return e == F ? launch_cfg<3, 1, 1, 2, 8, 1, 3, 2, F>(a, cp, s) : launch_cfg<3, 1, 1, 2, 8, 1, 3, 2, P>(a, cp, s);
+#endif
+            return bh_launch_conv_x3(a, cp, e, s);      // plane-split stages, 2 workgroups/CU (binhip_conv_x3.hip)
         }
         if (e == S && k == 3 && cp == 256) return launch_cfg<3, 1, 2, 4, 2, 1, 3, 2, S>(a, cp, s);
-        if (e == P && k == 3 && cb == 32) {
-            switch (g_variant[CLS_K3C32]) {
-                case 1: return launch_cfg<3, 1, 1, 2, 4, 1, 3, 3, P>(a, cp, s);
-                case 2: return launch_cfg<3, 1, 1, 2, 4, 1, 3, 2, P>(a, cp, s);
-                case 0: return launch_cfg<3, 1, 1, 4, 4, 1, 3, 2, P>(a, cp, s);
-                case 3: return launch_cfg<3, 1, 1, 1, 8, 1, 3, 2, P>(a, cp, s);    // 8 waves x 1 row, 8x32 tile, 80 KB
-                case 4: return launch_cfg<3, 1, 1, 1, 4, 1, 3, 2, P>(a, cp, s);    // 4 waves x 1 row, 4x32 tile
-                default: return launch_cfg<3, 1, 1, 2, 8, 1, 3, 2, P>(a, cp, s);
-            }
-        }
         if (e == P && k == 3 && cb == 64)  return launch_cfg<3, 2, 1, 2, 4, 1, 3, 2, P>(a, cp, s);
-        if (e == P && k == 3 && cb == 96) {
-            switch (g_variant[CLS_K3C96]) {
-                case 0: return launch_cfg<3, 3, 1, 2, 4, 1, 3, 2, P>(a, cp, s);
-                default: return launch_cfg<3, 3, 1, 1, 8, 1, 3, 2, P>(a, cp, s);   // 8 waves x 1 row: 168 vs 184 us
-            }
-        }
+        if (e == P && k == 3 && cb == 96)  return launch_cfg<3, 3, 1, 1, 8, 1, 3, 2, P>(a, cp, s);   // 8 waves x 1 row: 168 vs 184 us
         if (e == P && k == 1 && cb == 224) return launch_cfg<1, 7, 1, 1, 8, 1, 3, 2, P>(a, cp, s);   // LFF dgrad
         if (e == P && k == 1 && cb == 192) return launch_cfg<1, 6, 1, 1, 8, 1, 3, 2, P>(a, cp, s);   // GFF.0 dgrad
         if (e == P && k == 1 && cb == 32)  return launch_cfg<1, 1, 1, 4, 4, 2, 3, 2, P>(a, cp, s);
         if (e == P && k == 1 && cb == 96) {
-            switch (g_variant[CLS_K1C96]) {
-                case 1: return launch_cfg<1, 3, 1, 2, 4, 1, 3, 3, P>(a, cp, s);
-                case 0: return launch_cfg<1, 3, 1, 2, 4, 2, 3, 2, P>(a, cp, s);
-                case 2: return launch_cfg<1, 3, 1, 1, 8, 1, 3, 2, P>(a, cp, s);    // 8 waves x 1 row
-                case 3: return launch_cfg<1, 3, 1, 1, 8, 2, 3, 2, P>(a, cp, s);
-                case 4: return launch_cfg<1, 3, 1, 2, 4, 1, 3, 2, P>(a, cp, s);
-                default:
-                    if (a.nchunks >= 32) return launch_cfg<1, 3, 1, 2, 4, 1, 3, 2, P>(a, cp, s);
-                    return launch_cfg<1, 3, 1, 1, 8, 1, 3, 2, P>(a, cp, s);    // LFF 90 vs 108 us
-            }
+            if (a.nchunks >= 32) return launch_cfg<1, 3, 1, 2, 4, 1, 3, 2, P>(a, cp, s);
+            return launch_cfg<1, 3, 1, 1, 8, 1, 3, 2, P>(a, cp, s);    // LFF 90 vs 108 us
         }
-        if (e == P && k == 5 && cb == 32) {
-            switch (g_variant[CLS_K5]) {
-                case 0: return launch_cfg<5, 1, 1, 4, 4, 1, 3, 1, P>(a, cp, s);
-                default: return launch_cfg<5, 1, 1, 2, 8, 1, 3, 1, P>(a, cp, s);
-            }
-        }
+        if (e == P && k == 5 && cb == 32)  return launch_cfg<5, 1, 1, 2, 8, 1, 3, 1, P>(a, cp, s);
     }
     return BINHIP_E_SHAPE;
 }
@@ -904,10 +631,12 @@ int binhip_conv2d_bwd_data(const BinConvDesc* d, const void* gy_hi, const void* 
     c.m_hi = mask_hi; c.mask_from = mask_from;
     c.y_cpg = y_cpg; c.y_group_stride = y_group_stride;
     c.y_hi = gx_hi; c.y_lo = gx_lo; c.y_f32 = nullptr;
+    c.status = d->status;
     for (int i = 0; i < 5; ++i) c.images[i] = nullptr;
     return bh_launch_conv(c, (hipStream_t)stream);
 }
 
+#if BINHIP_TUNING
 int binhip_set_variant(int layer_class, int variant) {
     if (layer_class == -1) { g_xcd_remap = variant; return 0; }
     if (layer_class == -2) { g_dbg = variant; return 0; }
@@ -916,38 +645,45 @@ int binhip_set_variant(int layer_class, int variant) {
     g_variant[layer_class] = variant;
     return 0;
 }
+#endif
 
-int binhip_profile_begin(int ksize, int cout_pad, int epilogue, int max_launches) {
-    if (max_launches <= 0 || (size_t)max_launches > PROF_MAX_PAIRS) return BINHIP_E_ARG;
-    while (g_prof.ev.size() < (size_t)max_launches * 2) {
+int binhip_profiler_create(int ksize, int cout_pad, int epilogue, int max_launches, BinhipProfiler** out) {
+    if (!out || max_launches <= 0 || (size_t)max_launches > PROF_MAX_PAIRS) return BINHIP_E_ARG;
+    BinhipProfiler* p = new BinhipProfiler();
+    p->ks = ksize; p->cout_pad = cout_pad; p->epi = epilogue;
+    for (int i = 0; i < 2 * max_launches; ++i) {
         hipEvent_t ev;
         hipError_t e = hipEventCreate(&ev);
-        if (e != hipSuccess) return (int)e;
-        g_prof.ev.push_back(ev);
+        if (e != hipSuccess) { binhip_profiler_destroy(p); return (int)e; }
+        p->ev.push_back(ev);
     }
-    g_prof.ks = ksize; g_prof.cout_pad = cout_pad; g_prof.epi = epilogue;
-    g_prof.used = 0;
-    g_prof.active = true;
+    *out = p;
     return 0;
 }
 
-int binhip_profile_end(double* total_ms, int* launches) {
-    g_prof.active = false;
+int binhip_profiler_read(BinhipProfiler* p, double* total_ms, int* launches) {
+    if (!p) return BINHIP_E_ARG;
     double tot = 0.0;
     int n = 0;
-    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
-        hipError_t e = hipEventSynchronize(g_prof.ev[i + 1]);
+    for (size_t i = 0; i + 1 < p->used; i += 2) {
+        hipError_t e = hipEventSynchronize(p->ev[i + 1]);
         if (e != hipSuccess) return (int)e;
         float ms = 0.f;
-        e = hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]);
+        e = hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]);
         if (e != hipSuccess) return (int)e;
         tot += ms;
         ++n;
     }
     if (total_ms) *total_ms = tot;
     if (launches) *launches = n;
-    g_prof.used = 0;
+    p->used = 0;
     return 0;
+}
+
+void binhip_profiler_destroy(BinhipProfiler* p) {
+    if (!p) return;
+    for (hipEvent_t ev : p->ev) (void)hipEventDestroy(ev);
+    delete p;
 }
 
 int binhip_conv_cout_block(int ksize, int cout_pad, int nterms) { return bh_conv_cout_block(ksize, cout_pad, nterms); }
@@ -981,6 +717,7 @@ int binhip_conv2d_fwd(const BinConvDesc* d, const void* x_hi, const void* x_lo, 
     c.d = *d;
     c.x_hi = x_hi; c.x_lo = x_lo; c.w_hi = w_hi; c.w_lo = w_lo; c.bias = bias;
     c.r_hi = res_hi; c.r_lo = res_lo; c.y_hi = y_hi; c.y_lo = y_lo; c.y_f32 = y_f32;
+    c.status = d->status;
     for (int i = 0; i < 5; ++i) c.images[i] = (images && i < d->n_images) ? images[i] : nullptr;
     if (d->epilogue == BINHIP_EPI_FINAL && d->n_images > 0 && !images) return BINHIP_E_ARG;
     return bh_launch_conv(c, (hipStream_t)stream);

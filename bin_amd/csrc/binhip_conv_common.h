@@ -1,0 +1,212 @@
+// Shared device-side pieces of the convolution kernels (binhip_conv.hip, binhip_conv_x3.hip): kernel argument block,
+// LDS-DMA / store helpers and the epilogue (bias, residuals, ReLU, ReLU-mask, fp16 hi/lo split, 16-byte plane stores,
+// PixelShuffle scatter, fp32 NCHW final output).  Internal — not part of the C ABI.
+#pragma once
+#include "binhip_internal.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvKArgs {
+    const _Float16* x_hi;
+    const _Float16* x_lo;
+    const _Float16* w_hi;
+    const _Float16* w_lo;
+    const float* bias;
+    _Float16* y_hi;
+    _Float16* y_lo;
+    const _Float16* r_hi;
+    const _Float16* r_lo;
+    const _Float16* r2_hi;    // second residual (backward-data accumulation), same indexing as y
+    const _Float16* r2_lo;
+    const _Float16* m_hi;     // ReLU mask source (saved forward activation, hi plane), same indexing as y
+    float* out_f32;
+    const float* img[5];
+    unsigned* flags;          // device status word (bit 0: an output left the fp16 range and was clamped); may be null
+    long long group_stride;   // elements
+    int N, H, W;
+    int nchunks;
+    int cpg;
+    int tiles_x, tiles_y;
+    int relu, has_res, nimg, cout;
+    int xcd_remap;
+    int wt;                   // write-through (sc1) output stores
+    int och_limit;            // output chunks that exist at the destination (rows beyond are padding: not stored)
+    int dbg;                  // BINHIP_TUNING side builds only: ablation switches (timing experiments, results invalid)
+    int res_chunks;           // residual r applies to output chunks < res_chunks
+    int mask_from;            // mask applies to output chunks >= mask_from (when m_hi != null)
+    int y_cpg;                // output chunk grouping (<=0: one group)
+    long long y_group_stride;
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// fp16 storage range.  The reference computes in fp32 (RDN.py:141, no AMP), so a value beyond +-65504 is legal there;
+// here it cannot be stored in an fp16 hi plane.  Rather than let hi = inf, lo = -inf poison every later layer with NaN,
+// the epilogue saturates hi to +-65504 (lo then carries what it can of the rest) and raises bit 0 of the status word,
+// which the host checks (bin_amd/ops.py: RuntimeError "fp16 range exceeded").  Documented in include/binhip.h.
+#define BINHIP_F16_MAX 65504.0f
+#define BINHIP_FLAG_SATURATED 1u
+
+// returns hi; sat |= (v left the range or is NaN: c != v holds for NaN too)
+__device__ __forceinline__ _Float16 split_hi(float v, bool& sat) {
+    const float c = fminf(fmaxf(v, -BINHIP_F16_MAX), BINHIP_F16_MAX);
+    sat = sat || (c != v);
+    return (_Float16)c;
+}
+
+// 16-byte plane store.  wt != 0: write-through (sc1) so the XCD's L2 holds no dirty output lines at the end of the
+// kernel: the kernel-boundary release then has nothing to write back (MI355X: 8 XCDs with private, mutually
+// non-coherent L2s => every boundary flushes dirty lines; 16.5 MB of output costs ~2.8 us there).
+__device__ __forceinline__ void store16(_Float16* base, long long off_elems, uint4 v, int wt) {
+    if (wt) {
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0xFFFFFFFFu, 0x00020000);
+        u32x4 d = {v.x, v.y, v.z, v.w};
+        __builtin_amdgcn_raw_buffer_store_b128(d, rs, (int)(off_elems * 2), 0, 16);
+    } else {
+        *reinterpret_cast<uint4*>(base + off_elems) = v;
+    }
+}
+
+// consecutive workgroup ids land on different XCDs (private L2s): give each XCD a contiguous band of tiles so the
+// halo rows/columns neighbouring tiles share are L2 hits (bijective for any grid size)
+__device__ __forceinline__ int xcd_band(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+// ---- epilogue ---------------------------------------------------------------------------------------
+// acc[mt][r][4g+j] = D[cout = 8g + 4*kg + j][pixel = n]  (32x32 MFMA C/D layout): a lane holds 4 consecutive
+// channels of one pixel per g, and lanes n / n+32 hold the two halves of each 8-channel slot.  One
+// v_permlane32_swap per dword turns a (g even, g odd) pair into full 16-byte slots — lanes 0-31 get slot 0, lanes
+// 32-63 slot 1 of the same pixel — so every store instruction writes 32 pixels x 32 B = 1 KiB contiguous.
+// row0 = first image row of this wave's R rows, co0 = first output channel of this wave's MT x 32 rows.
+template <int MT, int R, int NT, int EPI>
+__device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, floatx16 (&acc)[MT][R], int img, int row0, int tx0,
+                                              int co0, bool first_col, int n, int kg, long long plane_elems) {
+    const int H = a.H, W = a.W;
+    const int gx = tx0 + n;
+    if constexpr (EPI == BINHIP_EPI_FINAL) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int gy = row0 + r;
+            if (!((gy < H) && (gx < W)) || kg != 0 || !first_col) continue;
+            const float4 bv = *reinterpret_cast<const float4*>(a.bias);
+            const float v[4] = {acc[0][r][0] + bv.x, acc[0][r][1] + bv.y, acc[0][r][2] + bv.z, acc[0][r][3] + bv.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j >= a.cout) break;
+                const long long idx = (((long long)img * a.cout + j) * H + gy) * W + gx;
+                float s = 0.f;
+                if (a.nimg > 0) {
+                    s = a.img[0][idx];
+                    for (int t = 1; t < a.nimg; ++t) s += a.img[t][idx];
+                    s = s / (float)a.nimg;
+                }
+                a.out_f32[idx] = v[j] + s;
+            }
+        }
+    } else {
+        union H4 { half4 h; unsigned u[2]; };
+        bool sat = false;
+        const int gxc = gx < W ? gx : W - 1;     // clamped coordinates: loads need no branch, stores are predicated
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int gy = row0 + r;
+            const bool ok = (gy < H) && (gx < W);
+            const int gyc = gy < H ? gy : H - 1;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    H4 hv[2], lv[2];
+                    long long o_slot = 0;        // element offset of this lane's 16-byte slot after the swap
+#pragma unroll
+                    for (int ge = 0; ge < 2; ++ge) {
+                        const int g = 2 * gp + ge;
+                        const int co = co0 + mt * 32 + 8 * g + 4 * kg;
+                        const float4 bv = *reinterpret_cast<const float4*>(a.bias + co);
+                        float v[4] = {acc[mt][r][4 * g + 0] + bv.x, acc[mt][r][4 * g + 1] + bv.y,
+                                      acc[mt][r][4 * g + 2] + bv.z, acc[mt][r][4 * g + 3] + bv.w};
+                        long long o;
+                        if constexpr (EPI == BINHIP_EPI_SHUFFLE) {
+                            const int cq = (a.cout + 3) / 4;      // channels after the shuffle
+                            const int sub = co / cq, cc = co - sub * cq;
+                            const int oy = 2 * gyc + (sub >> 1), ox = 2 * gxc + (sub & 1);
+                            o = (long long)(cc >> 4) * (plane_elems * 4) +
+                                ((((long long)img * 2 * H + oy) * (2 * W) + ox) << 4) + (cc & 15);
+                        } else {
+                            const int och = co >> 4;
+                            const long long pix16 = ((((long long)img * H + gyc) * W + gxc) << 4) + (co & 15);
+                            o = (a.y_cpg > 0)
+                                ? (long long)(och / a.y_cpg) * a.y_group_stride + (long long)(och % a.y_cpg) * plane_elems + pix16
+                                : (long long)och * plane_elems + pix16;
+                            if (a.has_res && och < a.res_chunks && och < a.och_limit) {
+                                const half4 rh = *reinterpret_cast<const half4*>(a.r_hi + o);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v[j] += (float)rh[j];
+                                if constexpr (NT == 3) {
+                                    const half4 rl = *reinterpret_cast<const half4*>(a.r_lo + o);
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) v[j] += (float)rl[j];
+                                }
+                            }
+                            if (a.r2_hi && och < a.och_limit) {
+                                const half4 rh = *reinterpret_cast<const half4*>(a.r2_hi + o);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v[j] += (float)rh[j];
+                                if constexpr (NT == 3) {
+                                    const half4 rl = *reinterpret_cast<const half4*>(a.r2_lo + o);
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) v[j] += (float)rl[j];
+                                }
+                            }
+                            if (a.relu) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                            }
+                            if (a.m_hi && och >= a.mask_from && och < a.och_limit) {
+                                const half4 mh = *reinterpret_cast<const half4*>(a.m_hi + o);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v[j] = ((float)mh[j] > 0.f) ? v[j] : 0.f;
+                            }
+                        }
+                        // after the swap, lanes 0-31 own slot 0 (g even) and lanes 32-63 slot 1 (g odd) of pixel n:
+                        // the slot start is this (g, kg=0) element offset
+                        if (ge == kg) o_slot = o - 4 * kg;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const _Float16 hj = split_hi(v[j], sat);
+                            hv[ge].h[j] = hj;
+                            lv[ge].h[j] = (_Float16)(v[j] - (float)hj);
+                        }
+                    }
+                    // vdst = even group, src = odd group: upper half of vdst <-> lower half of src
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        auto sw = __builtin_amdgcn_permlane32_swap(hv[0].u[k], hv[1].u[k], false, false);
+                        hv[0].u[k] = sw[0]; hv[1].u[k] = sw[1];
+                        if constexpr (NT == 3) {
+                            auto sl = __builtin_amdgcn_permlane32_swap(lv[0].u[k], lv[1].u[k], false, false);
+                            lv[0].u[k] = sl[0]; lv[1].u[k] = sl[1];
+                        }
+                    }
+                    if (ok && ((co0 + mt * 32 + 16 * gp) >> 4) < a.och_limit) {
+                        store16(a.y_hi, o_slot, make_uint4(hv[0].u[0], hv[0].u[1], hv[1].u[0], hv[1].u[1]), a.wt);
+                        if constexpr (NT == 3)
+                            store16(a.y_lo, o_slot, make_uint4(lv[0].u[0], lv[0].u[1], lv[1].u[0], lv[1].u[1]), a.wt);
+                    }
+                }
+            }
+        }
+        if (a.flags && __builtin_amdgcn_ballot_w64(sat) != 0 && (threadIdx.x & 63) == 0)
+            atomicOr(a.flags, BINHIP_FLAG_SATURATED);
+    }
+}
+

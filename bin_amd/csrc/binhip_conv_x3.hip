@@ -1,0 +1,203 @@
+// binhip_conv_x3.hip — the fp32-class (hi/lo split, three MFMA products) 3x3 / Cout-block-32 convolution with
+// PLANE-SPLIT K-stages, sized so that TWO workgroups share a CU.
+//
+// Same math and data layouts as conv_mfma_kernel<..., NT = 3, ...> (binhip_conv.hip; reference RDN.py:141 RDB_Conv,
+// :207 UPNet.2 and the gather-form dense-block backward-data convs of the same shape), different pipeline.  The
+// generic kernel stages BOTH precision planes of a 16-channel chunk per K-stage (patch hi+lo 40 KB, weights hi+lo
+// 18 KB, double-buffered = 117 KB) and holds two full fragment sets (157 VGPRs): one 8-wave workgroup per CU, so a
+// launch of 504 tiles runs as two rounds whose DMA prologues and store epilogues overlap with nothing, and kernels
+// of other streams cannot co-reside.  Here a chunk is two sub-stages,
+//     hi:  acc += Wlo * Xhi ; acc += Whi * Xhi      (patch hi plane, both weight planes)
+//     lo:  acc += Whi * Xlo                         (patch lo plane, hi weights again)
+// with the 20 KB patch planes double-buffered per SUB-stage and the 18 KB weight slab double-buffered per CHUNK:
+// 2 x 20 + 2 x 18 + 1 = 77 KB of LDS and <= 128 VGPRs (one B set per tap column, A fragments per tap) ->
+// 2 workgroups / CU = 4 waves / SIMD.  One workgroup's prologue / epilogue / barrier waits are covered by the other's
+// MFMAs (they drift apart on their own: the matrix pipe arbitrates by age), and tails of a launch are filled by the
+// next stream's workgroups.
+#include "binhip_conv_common.h"
+
+template <int KS, int R, int WN>
+struct X3Cfg {
+    static constexpr int PAD = KS / 2;
+    static constexpr int TH = R * WN;
+    static constexpr int PH = TH + KS - 1;
+    static constexpr int PW = 32 + KS - 1;
+    static constexpr int PP = (PH * PW * 2 + 63) / 64;     // 1-KiB DMA pieces of one patch plane
+    static constexpr int WP = KS * KS;                     // 1-KiB pieces of one weight plane (32 rows x 32 B per tap)
+    static constexpr int NW = WN;
+    static constexpr int PATCH_BYTES = PP * 1024;
+    static constexpr int WBUF_BYTES = 2 * WP * 1024;       // hi taps, then lo taps
+    static constexpr int LDS_BYTES = 2 * PATCH_BYTES + 2 * WBUF_BYTES;
+    static constexpr int NPJ = (PP + NW - 1) / NW;
+    static constexpr int NWJ = (2 * WP + NW - 1) / NW;
+    static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+};
+
+template <class C>
+__device__ __forceinline__ void x3_issue_patch(const ConvKArgs& a, char* smem, int c, int pl, int buf, int wave,
+                                               const unsigned* voff, long long plane_elems, unsigned plane_bytes) {
+    const _Float16* xb = pl ? a.x_lo : a.x_hi;
+    const long long coff = (a.cpg > 0) ? (long long)(c / a.cpg) * a.group_stride + (long long)(c % a.cpg) * plane_elems
+                                       : (long long)c * plane_elems;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(xb + coff), 0, plane_bytes, 0x00020000);
+    char* lds = smem + buf * C::PATCH_BYTES;
+    // every sub-stage is waited for with vmcnt(0), so waves need not issue equal instruction counts: pieces beyond the
+    // image are simply skipped (wave-uniform branch)
+#pragma unroll
+    for (int j = 0; j < C::NPJ; ++j) {
+        const int i = wave + C::NW * j;
+        if ((C::PP % C::NW == 0) || (i < C::PP))
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(lds + i * 1024), 16, voff[j], 0, 0, 0);
+    }
+}
+
+template <class C, int KS>
+__device__ __forceinline__ void x3_issue_weights(const ConvKArgs& a, char* smem, int c, int buf, int wave, int lane, int z) {
+    const long long woff = ((long long)z * a.nchunks + c) * (KS * KS * 32 * 16);
+    __amdgpu_buffer_rsrc_t wh = __builtin_amdgcn_make_buffer_rsrc((void*)(a.w_hi + woff), 0, KS * KS * 1024, 0x00020000);
+    __amdgpu_buffer_rsrc_t wl = __builtin_amdgcn_make_buffer_rsrc((void*)(a.w_lo + woff), 0, KS * KS * 1024, 0x00020000);
+    char* lds = smem + 2 * C::PATCH_BYTES + buf * C::WBUF_BYTES;
+#pragma unroll
+    for (int j = 0; j < C::NWJ; ++j) {
+        const int i = wave + C::NW * j;                  // piece: 0..WP-1 hi taps, WP..2WP-1 lo taps
+        if (((2 * C::WP) % C::NW == 0) || (i < 2 * C::WP)) {
+            const bool lo = i >= C::WP;
+            const int t = lo ? i - C::WP : i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(lo ? wl : wh, (lds_void_t*)(lds + i * 1024), 16,
+                                                     (unsigned)(lane * 16), t * 1024, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ half8 x3_ld8(const char* p) { return *reinterpret_cast<const half8*>(p); }
+
+// One sub-stage out of LDS.  HI: both weight planes against the hi patch (2 products); !HI: hi weights against the lo
+// patch.  Tap order dx-major: the R+KS-1 patch-row fragments of a tap column are fetched once and serve its KS taps;
+// weight fragments are fetched one tap ahead, the next column's patch rows at the column's first tap.
+template <class C, int KS, int R, bool HI>
+__device__ __forceinline__ void x3_compute(const char* pb, const char* wb, int a_lane_off, int b_lane_off,
+                                           floatx16 (&acc)[R]) {
+    constexpr int NTAP = KS * KS;
+    half8 B[2][R + KS - 1];
+    half8 Ah[2], Al[2];
+    auto load_b = [&](int dx, half8 (&dst)[R + KS - 1]) {
+#pragma unroll
+        for (int rr = 0; rr < R + KS - 1; ++rr) dst[rr] = x3_ld8(pb + b_lane_off + (rr * C::PW + dx) * 16);
+    };
+    auto load_a = [&](int s, half8& h, half8& l) {
+        const int dx = s / KS, dy = s % KS;
+        const int off = ((dy * KS + dx) * 32) * 32 + a_lane_off;
+        h = x3_ld8(wb + off);
+        if constexpr (HI) l = x3_ld8(wb + C::WP * 1024 + off);
+    };
+    load_b(0, B[0]);
+    load_a(0, Ah[0], Al[0]);
+#pragma unroll
+    for (int s = 0; s < NTAP; ++s) {
+        const int dx = s / KS, dy = s % KS;
+        if (s + 1 < NTAP) load_a(s + 1, Ah[(s + 1) & 1], Al[(s + 1) & 1]);
+        if (dy == 0 && dx + 1 < KS) load_b(dx + 1, B[(dx + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (HI) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[s & 1], B[dx & 1][r + dy], acc[r], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[s & 1], B[dx & 1][r + dy], acc[r], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int KS, int R, int WN, int EPI>
+__global__ void __launch_bounds__(64 * WN) __attribute__((amdgpu_waves_per_eu(4, 4)))
+conv_x3_kernel(const ConvKArgs a) {
+    using C = X3Cfg<KS, R, WN>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31;     // pixel column (B/N index) and cout row (A/M index) of this lane
+    const int kg = lane >> 5;    // which 8-channel half of the 16-channel chunk
+
+    int bid = blockIdx.x;
+    if (a.xcd_remap) bid = xcd_band(bid, gridDim.x);
+    const int tx = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y;
+    const int img = bid / a.tiles_y;
+    const int z = blockIdx.y;
+    const int tx0 = tx * 32, ty0 = ty * C::TH;
+    const int H = a.H, W = a.W;
+    const long long plane_elems = (long long)a.N * H * W * 16;
+    const unsigned plane_bytes = (unsigned)(plane_elems * 2);
+
+    // per-lane source offsets of the patch DMA pieces (stage independent); LDS image = [channel half][patch pixel][16 B]
+    unsigned voff[C::NPJ];
+#pragma unroll
+    for (int j = 0; j < C::NPJ; ++j) {
+        const int i = wave + C::NW * j;
+        const int q = i * 64 + lane;
+        const int cg = q >= C::PH * C::PW ? 1 : 0;
+        const int p = q - cg * (C::PH * C::PW);
+        const int py = p / C::PW;
+        const int px = p - py * C::PW;
+        const int gy = ty0 + py - C::PAD;
+        const int gx = tx0 + px - C::PAD;
+        const bool ok = (p < C::PH * C::PW) && (gy >= 0) && (gy < H) && (gx >= 0) && (gx < W);
+        voff[j] = ok ? (unsigned)((((long long)img * H + gy) * W + gx) * 32 + cg * 16) : 0x80000000u;
+    }
+
+    floatx16 acc[1][R];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[0][r][e] = 0.f;
+
+    const int nchunks = a.nchunks;
+    const int a_lane_off = n * 32 + ((kg ^ ((n >> 3) & 1)) << 4);
+    const int b_lane_off = (kg * (C::PH * C::PW) + wave * R * C::PW + n) * 16;
+
+    x3_issue_weights<C, KS>(a, smem, 0, 0, wave, lane, z);
+    x3_issue_patch<C>(a, smem, 0, 0, 0, wave, voff, plane_elems, plane_bytes);
+    for (int c = 0; c < nchunks; ++c) {
+        const char* wb = smem + 2 * C::PATCH_BYTES + (c & 1) * C::WBUF_BYTES;
+        // ---- hi sub-stage (the long one: 2 products): meanwhile the lo patch plane and the NEXT chunk's weights land
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        x3_issue_patch<C>(a, smem, c, 1, 1, wave, voff, plane_elems, plane_bytes);
+        if (c + 1 < nchunks) x3_issue_weights<C, KS>(a, smem, c + 1, (c + 1) & 1, wave, lane, z);
+        x3_compute<C, KS, R, true>(smem, wb, a_lane_off, b_lane_off, acc[0]);
+        // ---- lo sub-stage: meanwhile the next chunk's hi patch plane lands
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < nchunks) x3_issue_patch<C>(a, smem, c + 1, 0, 0, wave, voff, plane_elems, plane_bytes);
+        x3_compute<C, KS, R, false>(smem + C::PATCH_BYTES, wb, a_lane_off, b_lane_off, acc[0]);
+    }
+    conv_epilogue<1, R, 3, EPI>(a, acc, img, ty0 + wave * R, tx0, z * 32, z == 0, n, kg, plane_elems);
+}
+
+template <int KS, int R, int WN, int EPI>
+static int launch_x3(const ConvKArgs& ka, int cout_pad, hipStream_t s) {
+    using C = X3Cfg<KS, R, WN>;
+    static std::atomic<unsigned long long> lds_set{0};
+    if (int rc = bh_set_max_lds(&conv_x3_kernel<KS, R, WN, EPI>, C::LDS_BYTES, lds_set)) return rc;
+    ConvKArgs a = ka;
+    a.tiles_x = (a.W + 31) / 32;
+    a.tiles_y = (a.H + C::TH - 1) / C::TH;
+    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N), (unsigned)(cout_pad / 32));
+    conv_x3_kernel<KS, R, WN, EPI><<<grid, dim3(64 * C::NW), C::LDS_BYTES, s>>>(a);
+    BH_CHECK_LAUNCH();
+    return 0;
+}
+
+// entry for the dispatcher in binhip_conv.hip: 3x3, 32-row output blocks, nterms = 3
+int bh_launch_conv_x3(const ConvKArgs& a, int cout_pad, int epilogue, hipStream_t s) {
+    if (epilogue == BINHIP_EPI_PLANES) return launch_x3<3, 2, 8, BINHIP_EPI_PLANES>(a, cout_pad, s);
+    if (epilogue == BINHIP_EPI_FINAL) return launch_x3<3, 2, 8, BINHIP_EPI_FINAL>(a, cout_pad, s);
+    return BINHIP_E_SHAPE;
+}

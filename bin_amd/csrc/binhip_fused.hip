@@ -9,12 +9,7 @@
 // 512 threads (8 wave64), tile 16 rows x 32 cols, wave w owns rows 2w, 2w+1: 2 conv accumulators + 6 LFF accumulators
 // (128 regs).  K-stage = patch 18x34x16ch (20 KiB) + conv weights (9 KiB) + LFF weights (3 KiB) per precision plane,
 // LDS-DMA ring with counted vmcnt (see binhip_conv.hip for the layout / swizzle conventions, which are shared).
-#include "binhip_internal.h"
-
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef __attribute__((address_space(3))) void lds_void_t;
+#include "binhip_conv_common.h"
 
 struct TailKArgs {
     const _Float16 *x_hi, *x_lo;       // dense block buffer, chunk 0
@@ -23,6 +18,7 @@ struct TailKArgs {
     const float *bc, *bl;              // biases (32 / 96 floats)
     _Float16 *y_hi, *y_lo;             // output planes (6 chunks)
     _Float16 *o3_hi, *o3_lo;           // optional: where to keep o3 (2 chunks) for the backward pass
+    unsigned* flags;                   // device status word (BINHIP_STATUS_*), may be null
     int N, H, W, tiles_x, tiles_y, xcd_remap, wt;
 };
 
@@ -44,23 +40,6 @@ struct TailCfg {
 };
 
 __device__ __forceinline__ half8 ld8(const char* p) { return *reinterpret_cast<const half8*>(p); }
-
-// write-through (sc1) 16-byte plane store: leaves no dirty lines for the kernel-boundary L2 write-back (see binhip_conv.hip)
-typedef unsigned u32x4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store16_wt(_Float16* base, long long off_elems, uint4 v, int wt) {
-    if (wt) {
-        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0xFFFFFFFFu, 0x00020000);
-        u32x4f d = {v.x, v.y, v.z, v.w};
-        __builtin_amdgcn_raw_buffer_store_b128(d, rs, (int)(off_elems * 2), 0, 16);
-    } else {
-        *reinterpret_cast<uint4*>(base + off_elems) = v;
-    }
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vm() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 template <class C>
 __device__ __forceinline__ void tail_issue(const TailKArgs& a, char* smem, int c, int buf, int wave, int lane,
@@ -108,10 +87,7 @@ rdb_tail_kernel(const TailKArgs a) {
     const int n = lane & 31, kg = lane >> 5;
 
     int bid = blockIdx.x;
-    if (a.xcd_remap) {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-    }
+    if (a.xcd_remap) bid = xcd_band(bid, gridDim.x);
     const int tx = bid % a.tiles_x;
     bid /= a.tiles_x;
     const int ty = bid % a.tiles_y;
@@ -172,9 +148,9 @@ rdb_tail_kernel(const TailKArgs a) {
     for (int st = 0; st < C::NCHUNK; ++st) {
         int yf = C::NCHUNK - 1 - st;
         yf = yf > NBUF - 2 ? NBUF - 2 : yf;
-        if (NBUF >= 4 && yf >= 2) wait_vm<(NBUF >= 4 ? 2 : 0) * C::PS>();
-        else if (NBUF >= 3 && yf >= 1) wait_vm<(NBUF >= 3 ? 1 : 0) * C::PS>();
-        else wait_vm<0>();
+        if (NBUF >= 4 && yf >= 2) wait_vmcnt<(NBUF >= 4 ? 2 : 0) * C::PS>();
+        else if (NBUF >= 3 && yf >= 1) wait_vmcnt<(NBUF >= 3 ? 1 : 0) * C::PS>();
+        else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (st + NBUF - 1 < C::NCHUNK)
@@ -248,6 +224,7 @@ rdb_tail_kernel(const TailKArgs a) {
     constexpr int O3_PLANE = C::NW * C::R * 2 * 32 * 32;     // hi tiles of all waves, then lo tiles
     const int gx = tx0 + n;
     union H4 { half4 h; unsigned u[2]; };
+    bool sat = false;
 #pragma unroll
     for (int r = 0; r < C::R; ++r) {
         const int gy = ty0 + wave * C::R + r;
@@ -264,8 +241,9 @@ rdb_tail_kernel(const TailKArgs a) {
                                     fmaxf(accc[r][4 * g + 2] + bv.z, 0.f), fmaxf(accc[r][4 * g + 3] + bv.w, 0.f)};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    hv[ge].h[j] = (_Float16)v[j];
-                    lv[ge].h[j] = (_Float16)(v[j] - (float)hv[ge].h[j]);
+                    const _Float16 hj = split_hi(v[j], sat);
+                    hv[ge].h[j] = hj;
+                    lv[ge].h[j] = (_Float16)(v[j] - (float)hj);
                 }
                 const int off = ((gp * C::R + r) * 32 + n) * 32 + ((ge ^ ((n >> 3) & 1)) << 4) + kg * 8;
                 *reinterpret_cast<half4*>(o3 + off) = hv[ge].h;
@@ -344,8 +322,9 @@ rdb_tail_kernel(const TailKArgs a) {
                     if (ge == kg) o_slot = o - 4 * kg;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        hv[ge].h[j] = (_Float16)v[j];
-                        lv[ge].h[j] = (_Float16)(v[j] - (float)hv[ge].h[j]);
+                        const _Float16 hj = split_hi(v[j], sat);
+                        hv[ge].h[j] = hj;
+                        lv[ge].h[j] = (_Float16)(v[j] - (float)hj);
                     }
                 }
 #pragma unroll
@@ -358,25 +337,21 @@ rdb_tail_kernel(const TailKArgs a) {
                     }
                 }
                 if (ok) {
-                    store16_wt(a.y_hi, o_slot, make_uint4(hv[0].u[0], hv[0].u[1], hv[1].u[0], hv[1].u[1]), a.wt);
+                    store16(a.y_hi, o_slot, make_uint4(hv[0].u[0], hv[0].u[1], hv[1].u[0], hv[1].u[1]), a.wt);
                     if constexpr (NT == 3)
-                        store16_wt(a.y_lo, o_slot, make_uint4(lv[0].u[0], lv[0].u[1], lv[1].u[0], lv[1].u[1]), a.wt);
+                        store16(a.y_lo, o_slot, make_uint4(lv[0].u[0], lv[0].u[1], lv[1].u[0], lv[1].u[1]), a.wt);
                 }
             }
         }
     }
+    if (a.flags && __builtin_amdgcn_ballot_w64(sat) != 0 && lane == 0) atomicOr(a.flags, BINHIP_FLAG_SATURATED);
 }
 
 template <int NT, int NBUF>
 static int launch_tail(const TailKArgs& a0, hipStream_t s) {
     using C = TailCfg<NT, NBUF>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rdb_tail_kernel<NT, NBUF>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> lds_set{0};
+    if (int rc = bh_set_max_lds(&rdb_tail_kernel<NT, NBUF>, C::LDS_BYTES, lds_set)) return rc;
     TailKArgs a = a0;
     a.tiles_x = (a.W + 31) / 32;
     a.tiles_y = (a.H + C::TH - 1) / C::TH;
@@ -385,13 +360,15 @@ static int launch_tail(const TailKArgs& a0, hipStream_t s) {
     return 0;
 }
 
+#if BINHIP_TUNING
 static int g_tail_depth = 0;   // 0 = default
+#endif
 
 extern "C" {
 
 int binhip_rdb_tail_fwd(int N, int H, int W, int nterms, const void* blk_hi, const void* blk_lo, const void* wc_hi,
                         const void* wc_lo, const float* bias_c, const void* wl_hi, const void* wl_lo, const float* bias_l,
-                        void* y_hi, void* y_lo, int store_o3, void* stream) {
+                        void* y_hi, void* y_lo, int store_o3, void* status, void* stream) {
     if (!blk_hi || !wc_hi || !wl_hi || !bias_c || !bias_l || !y_hi) return BINHIP_E_ARG;
     if (nterms != 1 && nterms != 3) return BINHIP_E_ARG;
     if (nterms == 3 && (!blk_lo || !wc_lo || !wl_lo || !y_lo)) return BINHIP_E_ARG;
@@ -406,19 +383,22 @@ int binhip_rdb_tail_fwd(int N, int H, int W, int nterms, const void* blk_hi, con
     const long long plane = (long long)N * H * W * 16;
     a.o3_hi = store_o3 ? (_Float16*)blk_hi + 12 * plane : nullptr;
     a.o3_lo = (store_o3 && nterms == 3) ? (_Float16*)blk_lo + 12 * plane : nullptr;
+    a.flags = (unsigned*)status;
     a.N = N; a.H = H; a.W = W; a.tiles_x = a.tiles_y = 0; a.xcd_remap = 1;
     a.wt = (6 * plane * 2 < (1ll << 32) - 64) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     if (nterms == 1) {
-        switch (g_tail_depth) {
-            case 3: return launch_tail<1, 3>(a, s);
-            case 4: return launch_tail<1, 4>(a, s);
-            default: return launch_tail<1, 2>(a, s);     // measured best on MI355X (56.7 vs 63 us at 384x672)
-        }
+#if BINHIP_TUNING
+        if (g_tail_depth == 3) return launch_tail<1, 3>(a, s);
+        if (g_tail_depth == 4) return launch_tail<1, 4>(a, s);
+#endif
+        return launch_tail<1, 2>(a, s);     // ring depth 2: measured best on MI355X (56.7 vs 63 us at 384x672)
     }
     return launch_tail<3, 2>(a, s);
 }
 
+#if BINHIP_TUNING
 int binhip_set_tail_depth(int depth) { g_tail_depth = depth; return 0; }
+#endif
 
 }  // extern "C"

@@ -4,7 +4,14 @@
 #include <stdint.h>
 #include "../../include/binhip.h"
 
-#define BINHIP_VERSION 100
+#define BINHIP_VERSION 200
+
+// BINHIP_TUNING (side builds for tools/: kernel-variant sweeps and ablations; 0 in the product): compiles the
+// alternative tile configurations and the process-global switches that select them.  The product library has neither.
+#ifndef BINHIP_TUNING
+#define BINHIP_TUNING 0
+#endif
+
 
 // Chunk-plane helpers -------------------------------------------------------------------------
 // CP tensor: fp16 [chunk][N][H][W][16]; plane_elems = N*H*W*16.
@@ -33,6 +40,24 @@ struct BhConvCall {
     void *y_hi, *y_lo;
     float* y_f32;
     const float* images[5];
+    void* status = nullptr;                          // device status word (BINHIP_STATUS_*), may be null
+    BinhipProfiler* prof = nullptr;                  // optional live-timing handle (binhip_profiler_create)
 };
 int bh_launch_conv(const BhConvCall& c, hipStream_t s);
 int bh_conv_cout_block(int ksize, int cout_pad, int nterms);
+
+// per-device one-time hipFuncSetAttribute(MaxDynamicSharedMemorySize): the attribute is per device, so the cache is a
+// bit per device ordinal (immutable once set; racing threads at worst set the attribute twice)
+#include <atomic>
+template <class K>
+static inline int bh_set_max_lds(K kernel, int bytes, std::atomic<unsigned long long>& done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return 0;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    done.fetch_or(bit, std::memory_order_release);
+    return 0;
+}

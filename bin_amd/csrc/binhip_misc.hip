@@ -445,9 +445,9 @@ int binhip_version(void) { return BINHIP_VERSION; }
 int binhip_device_cus(void) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -1;
-    hipDeviceProp_t p;
-    if (hipGetDeviceProperties(&p, dev) != hipSuccess) return -1;
-    return p.multiProcessorCount;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+    return n;
 }
 
 int binhip_nchw_to_planes(const float* x, int N, int C, int H, int W, void* y_hi, void* y_lo, void* stream) {

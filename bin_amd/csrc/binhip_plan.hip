@@ -81,7 +81,7 @@ int binhip_rdn_forward(const BinRdnPlan* p, const float* const* inputs, float* o
         BhConvCall c;
         c.d.N = N; c.d.H = Hc; c.d.W = Wc; c.d.ksize = ks; c.d.cin_chunks = cin_chunks; c.d.cout = cout;
         c.d.cout_pad = cout_pad; c.d.nterms = nt; c.d.epilogue = epi; c.d.relu = relu;
-        c.d.x_cpg = cpg; c.d.x_group_stride = gstride; c.d.n_images = 0; c.d.reserved = 0;
+        c.d.x_cpg = cpg; c.d.x_group_stride = gstride; c.d.n_images = 0; c.d.reserved = 0; c.d.status = p->status;
         c.x_hi = HI(x_off); c.x_lo = LO(x_off, x_size);
         c.w_hi = p->w_hi[layer]; c.w_lo = p->w_lo[layer]; c.bias = p->bias[layer];
         c.r_hi = (r_off >= 0) ? HI(r_off) : nullptr;
@@ -89,6 +89,8 @@ int binhip_rdn_forward(const BinRdnPlan* p, const float* const* inputs, float* o
         c.y_hi = (y_off >= 0) ? HI(y_off) : nullptr;
         c.y_lo = (y_off >= 0) ? LO(y_off, y_size) : nullptr;
         c.y_f32 = nullptr;
+        c.status = p->status;
+        c.prof = p->profiler;
         for (int i = 0; i < 5; ++i) c.images[i] = nullptr;
         if (epi == BINHIP_EPI_FINAL) {
             c.y_f32 = out;
@@ -115,7 +117,7 @@ int binhip_rdn_forward(const BinRdnPlan* p, const float* const* inputs, float* o
             const int L = 2 + 5 * d;
             if ((rc = binhip_rdb_tail_fwd(N, h, ww, nt, HI(b), LO(b, w.s_blk), p->w_hi[L + 3], p->w_lo[L + 3], p->bias[L + 3],
                                           p->w_hi[L + 4], p->w_lo[L + 4], p->bias[L + 4], HI(b + 14 * P),
-                                          LO(b + 14 * P, w.s_blk), (p->reserved & BINHIP_PLAN_KEEP_ACTS) ? 1 : 0, stream)))
+                                          LO(b + 14 * P, w.s_blk), (p->reserved & BINHIP_PLAN_KEEP_ACTS) ? 1 : 0, p->status, stream)))
                 return rc;
         } else if ((rc = conv(2 + 5 * d + 4, 1, 14, 96, 96, P_, 0, h, ww, b, w.s_blk, 0, 0, b + 14 * P, w.s_blk, b, w.s_blk)))
             return rc;
@@ -245,6 +247,7 @@ int binhip_rdn_backward(const BinRdnBwdPlan* p, const void* saved, size_t saved_
         BinConvDesc d;
         d.N = N; d.H = Hc; d.W = Wc; d.ksize = ks; d.cin_chunks = cin_chunks; d.cout = cout; d.cout_pad = 0;
         d.nterms = nt; d.epilogue = 0; d.relu = 0; d.x_cpg = cpg; d.x_group_stride = gstride; d.n_images = 0; d.reserved = 0;
+        d.status = p->status;
         return binhip_conv2d_bwd_weight(&d, SH(x_off), SL(x_off, x_size), GH(g_off), GL(g_off, g_size), inv, wgws,
                                         b.wg_bytes, p->dw[layer], p->db[layer], cin, shuffle, accumulate, stream);
     };
@@ -255,7 +258,7 @@ int binhip_rdn_backward(const BinRdnBwdPlan* p, const void* saved, size_t saved_
         BhConvCall c;
         c.d.N = N; c.d.H = Hc; c.d.W = Wc; c.d.ksize = ks; c.d.cin_chunks = gin_chunks; c.d.cout = gout_ch;
         c.d.cout_pad = binhip_dgrad_rows_pad(ks, gout_ch); c.d.nterms = nt; c.d.epilogue = BINHIP_EPI_PLANES; c.d.relu = 0;
-        c.d.x_cpg = 0; c.d.x_group_stride = 0; c.d.n_images = 0; c.d.reserved = 0;
+        c.d.x_cpg = 0; c.d.x_group_stride = 0; c.d.n_images = 0; c.d.reserved = 0; c.d.status = p->status;
         c.x_hi = GH(g_off); c.x_lo = GL(g_off, g_size);
         c.w_hi = p->wt_hi[layer]; c.w_lo = p->wt_lo[layer]; c.bias = p->zero_bias;
         c.r_hi = (r_off >= 0) ? GH(r_off) : nullptr; c.r_lo = (r_off >= 0) ? GL(r_off, r_size) : nullptr;
@@ -265,6 +268,7 @@ int binhip_rdn_backward(const BinRdnBwdPlan* p, const void* saved, size_t saved_
         c.m_hi = (m_off >= 0) ? SH(m_off) : nullptr; c.mask_from = mask_from;
         c.y_cpg = y_cpg; c.y_group_stride = y_gstride;
         c.y_f32 = nullptr;
+        c.status = p->status;
         for (int i = 0; i < 5; ++i) c.images[i] = nullptr;
         return bh_launch_conv(c, s);
     };

@@ -646,13 +646,8 @@ WgGeom wg_geom(int ksize, int N, int H, int W, int cin_chunks, int cout, int cus
 template <int KS, int TR, int NT>
 int launch_wg(const WgradKArgs& a, const WgGeom& g, hipStream_t s) {
     using C = WgCfg<KS, TR, NT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<KS, TR, NT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> lds_set{0};
+    if (int rc = bh_set_max_lds(&wgrad_mfma_kernel<KS, TR, NT>, C::LDS_BYTES, lds_set)) return rc;
     dim3 grid((unsigned)g.PB, (unsigned)g.ncp, (unsigned)(g.ncot * g.ndyg));
     wgrad_mfma_kernel<KS, TR, NT><<<grid, dim3(256), C::LDS_BYTES, s>>>(a);
     BH_CHECK_LAUNCH();
@@ -663,34 +658,33 @@ template <int KS, int TR, int NT>
 int launch_wg_sb(const WgradKArgs& a, const WgGeom& g, hipStream_t s) {
     using C = WgCfg<KS, TR, NT>;
     constexpr int LDS = C::BUF_BYTES > 16384 ? C::BUF_BYTES : 16384;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_sb_kernel<KS, TR, NT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> lds_set{0};
+    if (int rc = bh_set_max_lds(&wgrad_mfma_sb_kernel<KS, TR, NT>, LDS, lds_set)) return rc;
     dim3 grid((unsigned)g.PB, (unsigned)g.ncp, (unsigned)(g.ncot * g.ndyg));
     wgrad_mfma_sb_kernel<KS, TR, NT><<<grid, dim3(256), LDS, s>>>(a);
     BH_CHECK_LAUNCH();
     return 0;
 }
 
-int g_wg_dbg = 0;
-int g_cus = 0;
+#if BINHIP_TUNING
+int g_wg_dbg = 0;      // side builds only: ablation switches (1 skip DMA, 2 skip MFMA, 4 skip reduce/store, 16 double-buffered 3x3)
+#define WG_DBG g_wg_dbg
+#else
+#define WG_DBG 0
+#endif
+// CU count of the current device (sizes the pixel-block split); looked up per call — no cached global
 int cus() {
-    if (g_cus == 0) {
-        int n = binhip_device_cus();
-        g_cus = n > 0 ? n : 256;
-    }
-    return g_cus;
+    const int n = binhip_device_cus();
+    return n > 0 ? n : 256;
 }
 
 }  // namespace
 
 extern "C" {
 
+#if BINHIP_TUNING
 int binhip_wgrad_set_debug(int flags) { g_wg_dbg = flags; return 0; }
+#endif
 
 size_t binhip_wgrad_workspace_bytes(int ksize, int N, int H, int W, int cin_chunks, int cout) {
     if (N <= 0 || H <= 0 || W <= 0 || cin_chunks <= 0 || cout <= 0) return 0;
@@ -722,24 +716,24 @@ int binhip_conv2d_bwd_weight(const BinConvDesc* d, const void* x_hi, const void*
     a.cin_chunks = d->cin_chunks; a.cout_chunks = (d->cout + 15) / 16;
     a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.ntiles = g.ntiles;
     a.PB = g.PB; a.ncp = g.ncp; a.ncot = g.ncot;
-    a.dbg = g_wg_dbg & 15;
+    a.dbg = WG_DBG & 15;
     hipStream_t s = (hipStream_t)stream;
     int rc = BINHIP_E_SHAPE;
     if (use_w1(d->ksize, d->cout)) {
         const int cgroups = (g.ncp + W1_NCPB - 1) / W1_NCPB;
         dim3 grid((unsigned)g.PB, (unsigned)cgroups);
         if (d->nterms == 1) {
-            static bool set1 = false;
-            if (!set1) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad1x1_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, W1Cfg<1>::LDS_BYTES); set1 = true; }
+            static std::atomic<unsigned long long> set1{0};
+            if (int rc1 = bh_set_max_lds(&wgrad1x1_kernel<1>, W1Cfg<1>::LDS_BYTES, set1)) return rc1;
             wgrad1x1_kernel<1><<<grid, dim3(256), W1Cfg<1>::LDS_BYTES, s>>>(a);
         } else {
-            static bool set3 = false;
-            if (!set3) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad1x1_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, W1Cfg<3>::LDS_BYTES); set3 = true; }
+            static std::atomic<unsigned long long> set3{0};
+            if (int rc3 = bh_set_max_lds(&wgrad1x1_kernel<3>, W1Cfg<3>::LDS_BYTES, set3)) return rc3;
             wgrad1x1_kernel<3><<<grid, dim3(256), W1Cfg<3>::LDS_BYTES, s>>>(a);
         }
         BH_CHECK_LAUNCH();
         rc = 0;
-    } else if (d->ksize == 3 && !(g_wg_dbg & 16)) {   // default: lean 2-workgroup/CU kernel; flag 16 = the double-buffered one
+    } else if (d->ksize == 3 && !(WG_DBG & 16)) {   // default: lean 2-workgroup/CU kernel; flag 16 = the double-buffered one
         rc = (d->nterms == 1) ? launch_wg_sb<3, 3, 1>(a, g, s) : launch_wg_sb<3, 3, 3>(a, g, s);
     } else if (d->nterms == 1) {
         if (d->ksize == 3) rc = launch_wg<3, 3, 1>(a, g, s);

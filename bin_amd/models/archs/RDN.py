@@ -32,6 +32,14 @@ def default_precision():
     return p
 
 
+class _nullctx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 class ConvLSTMCell(nn.Module):
     """reference RDN.py:9-95.  (input_size, hidden_size) = (3, 3) on the live path."""
 
@@ -46,6 +54,10 @@ class ConvLSTMCell(nn.Module):
         self.Gates.bias.data.zero_()
 
     def forward(self, input_, prev_state):
+        with torch.cuda.device(input_.device) if input_.is_cuda else _nullctx():
+            return self._forward(input_, prev_state)
+
+    def _forward(self, input_, prev_state):
         if torch.is_grad_enabled() and (input_.requires_grad or self.Gates.weight.requires_grad):
             from ...autograd import convlstm_apply
             return convlstm_apply(input_, prev_state, self.Gates.weight, self.Gates.bias, self._forget_bias)
@@ -110,12 +122,15 @@ class _RDNBase(nn.Module):
     def _run(self, *frames):
         if len(frames) != self.N_INPUTS:
             raise TypeError(f"{type(self).__name__}.forward takes {self.N_INPUTS} frames")
-        if torch.is_grad_enabled() and (any(f.requires_grad for f in frames) or
-                                         any(p.requires_grad for p in self.parameters())):
-            from ...autograd import rdn_apply        # training path (HIP backward)
-            return rdn_apply(self, frames)
-        nterms = PRECISIONS[self.precision or default_precision()]
-        return rdn_forward(self.kernel_weights(nterms), list(frames))
+        if not all(f.is_cuda for f in frames):
+            raise RuntimeError("bin_amd: RDN sub-networks run on a HIP device only (no CPU fallback; see oracle/)")
+        with torch.cuda.device(frames[0].device):      # kernels launch on the CURRENT device: make it the tensors' one
+            if torch.is_grad_enabled() and (any(f.requires_grad for f in frames) or
+                                             any(p.requires_grad for p in self.parameters())):
+                from ...autograd import rdn_apply        # training path (HIP backward)
+                return rdn_apply(self, frames)
+            nterms = PRECISIONS[self.precision or default_precision()]
+            return rdn_forward(self.kernel_weights(nterms), list(frames))
 
 
 class RDN_residual_interp_2_input(_RDNBase):
@@ -237,6 +252,10 @@ class RDN_residual_interp_5_input_ConvLSTM_L(nn.Module):
             if not t.is_cuda:
                 raise RuntimeError("bin_amd: bin_stage4 runs on a HIP device only (no CPU fallback; "
                                    "see oracle/ for the test-only CPU restatement)")
+        with torch.cuda.device(B1.device):             # kernels launch on the CURRENT device: make it the frames' one
+            return self._forward(B1, B3, B5, B7, B9, B11, stage1_cache, input_events)
+
+    def _forward(self, B1, B3, B5, B7, B9, B11, stage1_cache=None, input_events=None):
         if self.n_streams > 1 and self.reuse_schedule and self.modelType == "lstm" and not (
                 torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
             if self.batched:

@@ -10,8 +10,48 @@ import torch
 from . import _lib as L
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(device=None):
+    """The caller's current stream ON `device` (default: the current device).  Library calls launch on the current
+    HIP device, so entry points that take tensors run under `on_device(t)`."""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def on_device(t):
+    """Context that makes `t`'s device current (a no-op when it already is): kernels launch on the CURRENT device and
+    on its stream, so a tensor living on another GPU of the same process must switch first."""
+    return torch.cuda.device(t.device)
+
+
+_status = {}
+
+
+def status_word(device):
+    """Per-device uint32 status word the kernels OR into (include/binhip.h BINHIP_STATUS_*)."""
+    device = torch.device(device)
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    w = _status.get(key)
+    if w is None:
+        w = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", key))
+        _status[key] = w
+    return w
+
+
+def check_status(device=None, reset=True):
+    """Raise if any kernel since the last check stored a value outside the fp16 range (or a NaN).  Reads the device
+    word, i.e. synchronises: call it where the host syncs anyway (after a step, before images leave the device)."""
+    keys = list(_status) if device is None else [torch.device(device).index]
+    for k in keys:
+        w = _status.get(k)
+        if w is None:
+            continue
+        v = int(w.item())
+        if v and reset:
+            w.zero_()
+        if v & L.STATUS_SATURATED:
+            raise RuntimeError(
+                "bin_amd: fp16 range exceeded on cuda:%d — an activation / gradient left +-65504 (or was NaN) and was "
+                "saturated; results since the last check are not those of the fp32 reference (include/binhip.h, "
+                "'Dynamic range')" % k)
 
 
 def _ptr(t):
@@ -114,6 +154,7 @@ def conv2d(x, cw, relu=False, residual=None, out=None, epilogue=L.EPI_PLANES, im
     d.x_cpg, d.x_group_stride = x_cpg, x_group_stride
     d.n_images = len(images) if images else 0
     dev = x.hi.device
+    d.status = status_word(dev).data_ptr()
     y_f32, arr = None, None
     if epilogue == L.EPI_PLANES:
         if out is None:
@@ -207,6 +248,7 @@ def conv2d_bwd_data(gy, dw, res=None, res_chunks=0, acc=None, mask=None, mask_fr
     d.N, d.H, d.W, d.ksize = n, h, w, dw.ks
     d.cin_chunks, d.cout, d.cout_pad, d.nterms = dw.cin_chunks, dw.cout, dw.cout_pad, dw.nterms
     d.epilogue, d.relu, d.x_cpg, d.x_group_stride, d.n_images = L.EPI_PLANES, 0, 0, 0, 0
+    d.status = status_word(gy.hi.device).data_ptr()
     if out is None:
         out = CP.empty(chunks(dw.cout), n, h, w, dw.nterms, gy.hi.device, dw.cout)
     z = C.c_void_p(0)

@@ -5,7 +5,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
-from .ops import ConvWeights, _ptr, _stream, _need_cuda
+from .ops import ConvWeights, _ptr, _stream, _need_cuda, on_device, status_word
 
 D_BLOCKS, C_CONVS = 12, 4
 
@@ -123,9 +123,18 @@ def workspace(nbytes, device, key="fwd"):
 PLAN_FLAGS = 0          # module-level default (tests flip BINHIP_PLAN_NO_FUSE through this)
 
 
-def rdn_forward(weights, inputs, out=None, ws=None, flags=None):
-    """inputs: list of fp32 [N,3,H,W] device tensors -> fp32 [N,3,H,W]."""
+def rdn_forward(weights, inputs, out=None, ws=None, flags=None, profiler=None):
+    """inputs: list of fp32 [N,3,H,W] device tensors -> fp32 [N,3,H,W].  `profiler`: optional BinhipProfiler handle
+    (bench.py's roofline leg)."""
     _need_cuda(*inputs)
+    with on_device(inputs[0]):
+        return _rdn_forward(weights, inputs, out, ws, flags, profiler)
+
+
+PROFILER = None         # module-level handle bench.py sets for its roofline leg (host-side timing only)
+
+
+def _rdn_forward(weights, inputs, out, ws, flags, profiler):
     inputs = [t.contiguous().float() for t in inputs]
     n, c, h, w = inputs[0].shape
     assert c == 3 and len(inputs) == weights.n_inputs
@@ -133,6 +142,9 @@ def rdn_forward(weights, inputs, out=None, ws=None, flags=None):
     plan = L.BinRdnPlan()
     plan.N, plan.H, plan.W, plan.n_inputs, plan.nterms = n, h, w, weights.n_inputs, weights.nterms
     plan.reserved = PLAN_FLAGS if flags is None else flags
+    plan.status = status_word(inputs[0].device).data_ptr()
+    prof = profiler if profiler is not None else PROFILER
+    plan.profiler = prof if prof else None
     weights.fill_plan(plan)
     nbytes = lib.binhip_rdn_workspace_bytes(n, h, w, weights.n_inputs, weights.nterms)
     if nbytes == 0:

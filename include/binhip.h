@@ -18,6 +18,19 @@
  *     (nterms == 3), a `lo` plane set with x ~= hi + lo to ~22 mantissa bits.
  *   - nterms: 1 = fp16-input MFMA, fp32 accumulate (whole-net max-abs error ~3e-4 vs fp32);
  *             3 = fp16 hi/lo split, three MFMA products (error ~1e-6, fp32 class).
+ *   - Dynamic range.  The reference computes in fp32 (RDN.py:141, no AMP); here every value stored
+ *     between layers must fit the fp16 hi plane: |v| <= 65504.  Kernels SATURATE hi to +-65504
+ *     (never inf/NaN from overflow; lo keeps what it can of the excess) and OR BINHIP_STATUS_SATURATED
+ *     into the caller's device status word (`status`, may be NULL = not reported), so results that
+ *     left the range are detectable instead of silently wrong; a NaN input raises the same bit.
+ *     Small magnitudes: nterms = 3 represents |v| >= 2^-24 * 2^-11 relative steps down to the fp16
+ *     subnormal floor 6e-8 (absolute error <= 3e-8 per stored value); nterms = 1 flushes nothing but
+ *     rounds to 11 bits, absolute error <= 3e-8 below 6.1e-5.  Backward gradient planes carry a
+ *     per-call power-of-two scale (binhip_grad_scale) chosen from amax(gout) so that the largest
+ *     upstream gradient maps to 16; the status word covers their overflow as well.
+ *   - The library holds NO mutable process-global state: every switch is an argument, the only
+ *     caches are per-device "attribute already set" bits.  Entry points are re-entrant; calls for
+ *     different devices / streams may run concurrently from different host threads.
  */
 #ifndef BINHIP_H
 #define BINHIP_H
@@ -32,6 +45,8 @@ extern "C" {
 #define BINHIP_E_ARG      (-1)   /* null pointer / bad enum */
 #define BINHIP_E_SHAPE    (-2)   /* unsupported shape */
 #define BINHIP_E_WORKSPACE (-3)  /* workspace too small */
+
+#define BINHIP_STATUS_SATURATED 1u   /* bit 0 of a status word: a stored value was clamped to +-65504 (or was NaN) */
 
 #define BINHIP_EPI_PLANES  0     /* y = [relu](conv + b [+ residual]) -> chunk planes            */
 #define BINHIP_EPI_SHUFFLE 1     /* conv + b -> PixelShuffle(2) -> chunk planes at 2H x 2W       */
@@ -60,6 +75,7 @@ typedef struct BinConvDesc {
                               /*   (elements). x_cpg <= 0: one group.                             */
     int32_t n_images;         /* FINAL: number of fp32 NCHW images averaged into the output      */
     int32_t reserved;
+    void*   status;           /* device uint32 status word (BINHIP_STATUS_*), OR-ed into; or NULL */
 } BinConvDesc;
 
 /* Rows per weight block for a (ksize, cout_pad, nterms) configuration (relayout needs it). */
@@ -159,8 +175,7 @@ int binhip_charbonnier_bwd(const float* x, const float* y, int64_t numel, float 
 int binhip_rdb_tail_fwd(int N, int H, int W, int nterms, const void* blk_hi, const void* blk_lo,
                         const void* wc_hi, const void* wc_lo, const float* bias_c,
                         const void* wl_hi, const void* wl_lo, const float* bias_l,
-                        void* y_hi, void* y_lo, int store_o3, void* stream);
-int binhip_set_tail_depth(int depth);   /* tuning knob: LDS ring depth 2/3/4 of the fused kernel (f16) */
+                        void* y_hi, void* y_lo, int store_o3, void* status, void* stream);
 
 /* ---- one whole RDN sub-network (RDN.py:210-222 / 268-280 / 322-334) ---------------------------
  * 66 convolutions launched back-to-back on `stream` from C (no Python between layers).           */
@@ -174,6 +189,8 @@ typedef struct BinRdnPlan {
     const void* w_hi[BINHIP_RDN_LAYERS];   /* relayouted weights per layer                       */
     const void* w_lo[BINHIP_RDN_LAYERS];   /* NULL when nterms == 1                              */
     const float* bias[BINHIP_RDN_LAYERS];
+    void* status;                          /* device uint32 status word (BINHIP_STATUS_*) or NULL */
+    struct BinhipProfiler* profiler;       /* optional live kernel timing (below) or NULL         */
 } BinRdnPlan;
 
 size_t binhip_rdn_workspace_bytes(int N, int H, int W, int n_inputs, int nterms);
@@ -187,7 +204,6 @@ int binhip_rdn_forward(const BinRdnPlan* plan, const float* const* inputs /* hos
  * (N,H,W, ksize, cin_chunks, cout, nterms, x_cpg/x_group_stride).  The result is multiplied by
  * inv_scale[0] (device scalar, may be NULL) and written (or added, accumulate != 0) to OIHW fp32.
  * shuffle_perm != 0: gY's channels are in UPNet.0's PixelShuffle-permuted order.                      */
-int binhip_wgrad_set_debug(int flags);   /* ablation switches for timing experiments (results invalid when != 0) */
 size_t binhip_wgrad_workspace_bytes(int ksize, int N, int H, int W, int cin_chunks, int cout);
 int binhip_conv2d_bwd_weight(const BinConvDesc* d, const void* x_hi, const void* x_lo,
                              const void* gy_hi, const void* gy_lo, const float* inv_scale,
@@ -237,21 +253,22 @@ typedef struct BinRdnBwdPlan {
     float* dw[BINHIP_RDN_LAYERS];
     float* db[BINHIP_RDN_LAYERS];
     float* gin[5];
+    void* status;                           /* device uint32 status word (BINHIP_STATUS_*) or NULL     */
 } BinRdnBwdPlan;
 size_t binhip_rdn_backward_workspace_bytes(int N, int H, int W, int n_inputs, int nterms);
 int binhip_rdn_backward(const BinRdnBwdPlan* plan, const void* saved, size_t saved_bytes,
                         const float* gout, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- live kernel timing (bench.py roofline leg) --------------------------------------------------
- * Between begin/end every conv launch whose (ksize, cout_pad, epilogue) matches is bracketed by a
- * hipEvent pair recorded on the launch stream; end() synchronises on them and returns the summed
- * kernel time.  Host-side only; at most `max_launches` (<= 16384) launches are recorded.           */
-int binhip_profile_begin(int ksize, int cout_pad, int epilogue, int max_launches);
-/* tuning knob: pick kernel-configuration `variant` for a layer class (0 RDB conv, 1 1x1->96, 2 3x3->96,
- * 3 UPNet.0, 4 final, 5 5x5); layer_class -1 toggles the XCD-aware tile order.  Results are identical
- * for every variant (same arithmetic order per output); process-global.                               */
-int binhip_set_variant(int layer_class, int variant);
-int binhip_profile_end(double* total_ms, int* launches);
+ * An explicit host-side handle: every conv launch of a plan that carries it and whose (ksize,
+ * cout_pad, epilogue) matches is bracketed by a hipEvent pair recorded on the launch stream (at most
+ * `max_launches` <= 16384 pairs); read() synchronises on the recorded pairs, returns their summed
+ * kernel time and the launch count, and rewinds the handle.  Not thread-safe per handle (use one per
+ * host thread); the library itself keeps no global timing state.                                   */
+typedef struct BinhipProfiler BinhipProfiler;
+int binhip_profiler_create(int ksize, int cout_pad, int epilogue, int max_launches, BinhipProfiler** out);
+int binhip_profiler_read(BinhipProfiler* p, double* total_ms, int* launches);
+void binhip_profiler_destroy(BinhipProfiler* p);
 
 #ifdef __cplusplus
 }

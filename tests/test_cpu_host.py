@@ -69,7 +69,10 @@ def test_abi_error_codes_without_a_gpu():
     assert lib.binhip_rdn_forward(ctypes.byref(plan), arr, one, one, 1 << 20, null) in (E_SHAPE, E_ARG)      # odd height
     assert lib.binhip_rdn_backward_workspace_bytes(1, 64, 64, 4, 1) == 0
     assert lib.binhip_wgrad_workspace_bytes(3, 0, 8, 8, 2, 32) == 0
-    assert lib.binhip_profile_begin(3, 32, 0, 0) == E_ARG
+    h = ctypes.c_void_p(0)
+    assert lib.binhip_profiler_create(3, 32, 0, 0, ctypes.byref(h)) == E_ARG and not h.value     # max_launches <= 0
+    assert lib.binhip_profiler_create(3, 32, 0, 4, None) == E_ARG
+    assert lib.binhip_profiler_read(None, None, None) == E_ARG
     assert E_WS == -3
 
 

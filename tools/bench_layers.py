@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Per-layer microbenchmark at the 720p working size (half-res 384x672): times each distinct layer class of the
-RDN forward for every kernel variant (binhip_set_variant) with events on the launch stream, checks that all
-variants produce identical results, and prints us / actual fp16 GB/s / TFLOP/s."""
+RDN forward with events on the launch stream and prints us / actual fp16 GB/s / TFLOP/s.  With the BINHIP_TUNING
+side build (`python -m bin_amd.build --tuning`, then BIN_AMD_LIB=tools/_abl/libbinhip_tuning.so) it also sweeps the
+kernel variants (binhip_set_variant) and reports the largest difference to the default variant's result."""
 import argparse
 import os
 import sys
@@ -35,6 +36,7 @@ def main():
     args = ap.parse_args()
     nt, n, h, w = args.nterms, args.n, args.h, args.w
     lib = L.lib()
+    tuning = hasattr(lib, "binhip_set_variant")
     dev = torch.device("cuda")
     g = torch.Generator(device="cpu").manual_seed(0)
     px = n * h * w
@@ -53,39 +55,39 @@ def main():
     for cin in (96, 192):
         cw = wts(32, cin, 3)
         out = ops.CP.empty(2, n, h, w, nt, dev)
-        cases.append((0, f"RDB conv3x3 {cin}->32 +ReLU", [0, -1, 12, 3] if nt == 1 else [-1, 3, 4],
+        cases.append((0, f"RDB conv3x3 {cin}->32 +ReLU", [-1, 0, 12] if nt == 1 else [-1, 1],
                       (lambda cw=cw, cin=cin, out=out: ops.conv2d(x224, cw, relu=True, out=out, cin_chunks=cin // 16)),
                       2 * 9 * cin * 32 * px, (cin + 32) * bpe * px, out))
     cw = wts(96, 224, 1)
     out96 = ops.CP.empty(6, n, h, w, nt, dev)
-    cases.append((1, "LFF 1x1 224->96 +res", [1, -1] if nt == 1 else [-1, 2, 3],
+    cases.append((1, "LFF 1x1 224->96 +res", [-1],
                   (lambda cw=cw: ops.conv2d(x224, cw, residual=res96, out=out96)), 2 * 224 * 96 * px,
                   (224 + 96 + 96) * bpe * px, out96))
     x1152 = mk(1152)
     cwg = wts(96, 1152, 1)
     outg = ops.CP.empty(6, n, h, w, nt, dev)
-    cases.append((1, "GFF.0 1x1 1152->96", [1, -1] if nt == 1 else [-1, 2, 3],
+    cases.append((1, "GFF.0 1x1 1152->96", [-1],
                   (lambda: ops.conv2d(x1152, cwg, out=outg)), 2 * 1152 * 96 * px, (1152 + 96) * bpe * px, outg))
     cw3 = wts(96, 96, 3)
     out3 = ops.CP.empty(6, n, h, w, nt, dev)
-    cases.append((2, "3x3 96->96 +res", [-1] if nt == 1 else [-1, 2],
+    cases.append((2, "3x3 96->96 +res", [-1],
                   (lambda: ops.conv2d(res96, cw3, residual=x224, out=out3)), 2 * 9 * 96 * 96 * px,
                   (96 + 96 + 96) * bpe * px, out3))
     cwu = wts(256, 96, 3, shuffle=True)
     outu = ops.CP.empty(4, n, 2 * h, 2 * w, nt, dev)
-    cases.append((3, "UPNet.0 3x3 96->256 +shuffle", [0, -1] if nt == 1 else [0],
+    cases.append((3, "UPNet.0 3x3 96->256 +shuffle", [-1],
                   (lambda: ops.conv2d(res96, cwu, out=outu, epilogue=L.EPI_SHUFFLE)), 2 * 9 * 96 * 256 * px,
                   (96 + 256) * bpe * px, outu))
     xu = mk(64, 2 * h, 2 * w)
     cwf = wts(3, 64, 3)
     imgs = [torch.rand(n, 3, 2 * h, 2 * w, generator=g).to(dev) for _ in range(2)]
-    cases.append((4, "UPNet.2 3x3 64->3 +mean (final)", [0, -1] if nt == 1 else [-1, 1],
+    cases.append((4, "UPNet.2 3x3 64->3 +mean (final)", [-1] if nt == 1 else [-1, 1],
                   (lambda: ops.conv2d(xu, cwf, epilogue=L.EPI_FINAL, images=imgs)), 2 * 9 * 64 * 3 * 4 * px,
                   (64 * bpe + 3 * 4 * 3) * 4 * px, None))
     x48 = mk(48)
     cw5 = wts(96, 36, 5)
     out5 = ops.CP.empty(6, n, h, w, nt, dev)
-    cases.append((5, "SFENet1 5x5 36->96", [0, -1] if nt == 1 else [-1, 1], (lambda: ops.conv2d(x48, cw5, out=out5, cin_chunks=3)),
+    cases.append((5, "SFENet1 5x5 36->96", [-1], (lambda: ops.conv2d(x48, cw5, out=out5, cin_chunks=3)),
                   2 * 25 * 36 * 96 * px, (48 + 96) * bpe * px, out5))
 
     # fused conv#3 + LFF vs the two separate kernels
@@ -101,23 +103,20 @@ def main():
                                         cw3b.bias.data_ptr(), cwlb.w_hi.data_ptr(),
                                         cwlb.w_lo.data_ptr() if cwlb.w_lo is not None else None, cwlb.bias.data_ptr(),
                                         ynext.hi.data_ptr(), ynext.lo.data_ptr() if ynext.lo is not None else None, store,
-                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)), "tail")
+                                        None, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "tail")
 
     def unfused():
         ops.conv2d(blk, cw3b, relu=True, out=blk.sub(12, 2), cin_chunks=12)
         ops.conv2d(blk, cwlb, residual=blk.sub(0, 6), out=ynext)
 
     fl = (2 * 9 * 192 * 32 + 2 * 224 * 96) * px
-    for d in ((2, 3, 4) if nt == 1 else (2,)):
-        lib.binhip_set_tail_depth(d)
-        us = time_fn(fused)
-        print(f"fused conv3+LFF depth {d}: {us:8.1f} us  {(192 + 96) * bpe * px / us / 1e3:7.0f} GB/s(actual)  {fl / us / 1e6:7.0f} TF/s")
+    us = time_fn(fused)
+    print(f"fused conv3+LFF:              {us:8.1f} us  {(192 + 96) * bpe * px / us / 1e3:7.0f} GB/s(actual)  {fl / us / 1e6:7.0f} TF/s")
     us = time_fn(lambda: fused(1))
     print(f"fused conv3+LFF (+store o3):  {us:8.1f} us")
-    lib.binhip_set_tail_depth(0)
     us = time_fn(unfused)
     print(f"unfused conv3 ; LFF:          {us:8.1f} us")
-    if os.environ.get("WGRAD"):
+    if os.environ.get("WGRAD") and tuning:
         # weight-gradient kernels at the training working size (8 x 128 x 128 half-res pixels)
         nn_, hh_, ww_ = 8, 128, 128
         gg = torch.Generator().manual_seed(1)
@@ -130,60 +129,29 @@ def main():
                 us = time_fn(f, iters=10, warm=2)
                 print(f"wgrad k{ks} {cin}->{cout} nt={nt} {nm:16s}: {us:8.1f} us   {2*ks*ks*cin*cout*nn_*hh_*ww_*(3 if nt==3 else 1)/us/1e6:7.0f} TF-eq/s")
             lib.binhip_wgrad_set_debug(0)
-    if os.environ.get("ABLATE"):
-        for cin in (96, 192):
-            cw = wts(32, cin, 3)
-            out = ops.CP.empty(2, n, h, w, nt, dev)
-            f = (lambda cw=cw, cin=cin, out=out: ops.conv2d(x224, cw, relu=True, out=out, cin_chunks=cin // 16))
-            for v in (-1,):
-                lib.binhip_set_variant(0, v)
-                for dbg, nm in ((0, "full"), (1, "no weight DMA"), (2, "no patch DMA"), (3, "no DMA at all"), (4, "no MFMA"),
-                                (7, "nothing (launch+epilogue)"), (8, "no epilogue"), (12, "DMA+barriers only"),
-                                (15, "empty stages, no epilogue"), (16, "empty kernel")):
-                    lib.binhip_set_variant(-2, dbg)
-                    wall = time_fn(f)
-                    # per-launch hipEvent pairs on the launch stream (independent of the Python launch rate)
-                    import ctypes as C
-                    L.check(lib.binhip_profile_begin(3, 32, 0, 64), "profile_begin")
-                    for _ in range(64):
-                        f()
-                    torch.cuda.synchronize()
-                    ms, cnt = C.c_double(0), C.c_int(0)
-                    L.check(lib.binhip_profile_end(C.byref(ms), C.byref(cnt)), "profile_end")
-                    print(f"ablate RDB conv {cin}->32 variant {v:2d} {nm:28s}: wall {wall:7.1f} us/launch, "
-                          f"event pair {ms.value / max(cnt.value, 1) * 1e3:7.1f} us")
-        lib.binhip_set_variant(-2, 0)
-        lib.binhip_set_variant(0, -1)
-    if os.environ.get("WT"):
-        for cin in (96, 192):
-            cw = wts(32, cin, 3)
-            out = ops.CP.empty(2, n, h, w, nt, dev)
-            f = (lambda cw=cw, cin=cin, out=out: ops.conv2d(x224, cw, relu=True, out=out, cin_chunks=cin // 16))
-            for wt in (0, 1, 0, 1):
-                lib.binhip_set_variant(-3, wt)
-                print(f"RDB conv {cin}->32 write-through={wt}: {time_fn(f):7.1f} us")
-        lib.binhip_set_variant(-3, 1)
     want = {int(c) for c in args.classes.split(",")}
     print(f"nterms={nt} N={n} {h}x{w}")
-    for xcd in (1,):
-        lib.binhip_set_variant(-1, xcd)
-        for cls, name, variants, fn, flops, nbytes, outbuf in cases:
-            if cls not in want:
-                continue
-            ref = None
-            for v in variants:
+    for cls, name, variants, fn, flops, nbytes, outbuf in cases:
+        if cls not in want:
+            continue
+        ref = None
+        for v in (variants if tuning else [-1]):
+            if tuning:
                 lib.binhip_set_variant(cls, v)
-                r = fn()
-                torch.cuda.synchronize()
-                cur = (outbuf.hi.clone() if outbuf is not None else r.clone())
-                if ref is None:
-                    ref = cur
-                same = bool(torch.equal(ref, cur))
-                us = time_fn(fn)
-                print(f"xcd={xcd} {name:34s} v{v}: {us:8.1f} us  {nbytes / us / 1e3:7.0f} GB/s(actual)  "
-                      f"{flops / us / 1e6:7.0f} TF/s  same={same}")
-            lib.binhip_set_variant(cls, 0)
-    lib.binhip_set_variant(-1, 0)
+            r = fn()
+            torch.cuda.synchronize()
+            if outbuf is not None:
+                cur = outbuf.hi.float() + (outbuf.lo.float() if outbuf.lo is not None else 0)
+            else:
+                cur = r.clone()
+            if ref is None:
+                ref = cur
+            diff = float((ref - cur).abs().max()) / max(float(ref.abs().max()), 1e-30)
+            us = time_fn(fn)
+            print(f"{name:34s} v{v}: {us:8.1f} us  {nbytes / us / 1e3:7.0f} GB/s(actual)  "
+                  f"{flops / us / 1e6:7.0f} TF/s  rel.diff to default {diff:.2e}")
+        if tuning:
+            lib.binhip_set_variant(cls, -1)
 
 
 if __name__ == "__main__":
