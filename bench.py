@@ -266,6 +266,12 @@ def main():
                     help="precision of --mode train (default f16x3: fp32-class gradients)")
     ap.add_argument("--pipeline", action="store_true",
                     help="let consecutive steps overlap (side streams wait on the resident frames, not on the previous join)")
+    ap.add_argument("--zero-data", action="store_true",
+                    help="diagnostic (invalid as a result): all-zero frames and weights — same instruction stream, minimal "
+                         "datapath toggling; a large speed-up means the real run is power/clock-limited, not issue-limited")
+    ap.add_argument("--variant", action="append", default=[],
+                    help="tools/ A/B only (needs BIN_AMD_LIB=tools/_abl/libbinhip_tuning.so): class=variant for "
+                         "binhip_set_variant, or tail=depth for binhip_set_tail_depth")
     ap.add_argument("--reference-schedule", action="store_true",
                     help="run the reference's literal 20 RDN calls + 12 cells instead of the exact 17 + 6")
     args = ap.parse_args()
@@ -290,6 +296,12 @@ def main():
         return train_bench(args, rank, world, dev)
 
     from bin_amd import _lib as L
+    for v in args.variant:                   # side-build switches (never present in the product library)
+        k, val = v.split("=")
+        if k == "tail":
+            L.lib().binhip_set_tail_depth(int(val))
+        else:
+            L.lib().binhip_set_variant(int(k), int(val))
     from bin_amd.models.archs.RDN import bin_stage4_lstm
     from bin_amd.utils import util
     from bin_amd.weights import reference_state_dict, synthetic_frames
@@ -305,6 +317,11 @@ def main():
 
     pads = util.pad_sizes(H, W)
     frames = [util.replicate_pad(f, pads).to(dev) for f in synthetic_frames(1234 + rank, 1, H, W, 6)]
+    if args.zero_data:
+        frames = [torch.zeros_like(f) for f in frames]
+        with torch.no_grad():
+            for prm in net.parameters():
+                prm.zero_()
     hp, wp = frames[0].shape[2], frames[0].shape[3]
 
     def sync_all():
@@ -328,7 +345,7 @@ def main():
         # overlap — the next window's stage-1 calls start on idle streams while the previous window's lone stage-4 call
         # still runs.  Measured +0.4 % (31.43 vs 31.30 frames/s): every kernel already fills both workgroup slots of
         # every CU, so another stream's kernels only slip into the ramp/drain.  Off by default.
-        kw_in = {"input_events": []} if (net.n_streams > 1 and not net.batched and args.pipeline) else {}
+        kw_in = {"input_events": []} if (net.resolved_streams() > 1 and not net.batched and args.pipeline) else {}
         t0 = time.perf_counter()
         for _ in range(args.steps):
             out = net(*frames, **kw_in)
@@ -363,7 +380,7 @@ def main():
         # ---- streaming leg (reported beside `value`, never instead of it): consecutive windows of
         # one clip, sliding by one frame, with the exact stage-1 reuse -> 13 instead of 17 RDN calls per window
         stream_fps = None
-        if extras and net.n_streams > 1 and net.reuse_schedule and not net.batched:
+        if extras and net.reuse_schedule and not net.batched:
             clip_frames = frames + [f.clone() for f in frames[:4]]      # 10 resident padded frames -> 5 windows
             cache = {}
             net(*clip_frames[0:6], stage1_cache=cache)
@@ -456,8 +473,8 @@ def main():
                                    "(6-frame window padded to 768x1344 by the test.py rule), window-sharded",
                        "schedule": "17 RDN calls + 6 ConvLSTM cells (exact reuse)" if net.reuse_schedule
                                    else "20 RDN calls + 12 ConvLSTM cells (reference literal)",
-                       "precision": prec, "streams": net.n_streams, "pipelined_steps": bool(kw_in),
-                       "batched_stages": bool(net.batched and net.n_streams > 1),
+                       "precision": prec, "streams": net.resolved_streams(), "pipelined_steps": bool(kw_in),
+                       "batched_stages": bool(net.batched and net.resolved_streams() > 1),
                        "parity": "max-abs <= 2e-5 (f16x3) vs the fp32 reference (tests/)" if prec == "f16x3"
                                  else "max-abs <= 1e-3 (f16) vs the fp32 reference (tests/)"},
             "roofline": roof,

@@ -9,7 +9,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["binhip_conv.hip", "binhip_conv_x3.hip", "binhip_fused.hip", "binhip_wgrad.hip", "binhip_misc.hip", "binhip_plan.hip"]
+SOURCES = ["binhip_conv.hip", "binhip_conv_x3.hip", "binhip_fused.hip", "binhip_fused_x3.hip", "binhip_wgrad.hip", "binhip_misc.hip", "binhip_plan.hip"]
 LIB_PATH = os.path.join(CSRC, "libbinhip.so")
 
 

@@ -14,6 +14,10 @@
 // 2 workgroups / CU = 4 waves / SIMD.  One workgroup's prologue / epilogue / barrier waits are covered by the other's
 // MFMAs (they drift apart on their own: the matrix pipe arbitrates by age), and tails of a launch are filled by the
 // next stream's workgroups.
+// Measured on MI355X, whole 720p forward, same box (profiles/r02_layer_variants.md): 81.5 ms with the generic kernel,
+// 74.9 ms with this one.  A 16-wave / 32x32-tile variant (one workgroup per CU whose halves share one weight slab, 3-deep
+// patch ring with counted vmcnt = prefetch distance of two sub-stages) was built and measured at 76.4 ms: the DMA
+// prefetch distance is not what limits the loop, and a 1024-thread workgroup loses the phase drift.  Not kept.
 #include "binhip_conv_common.h"
 
 template <int KS, int R, int WN>

@@ -11,16 +11,7 @@
 // LDS-DMA ring with counted vmcnt (see binhip_conv.hip for the layout / swizzle conventions, which are shared).
 #include "binhip_conv_common.h"
 
-struct TailKArgs {
-    const _Float16 *x_hi, *x_lo;       // dense block buffer, chunk 0
-    const _Float16 *wc_hi, *wc_lo;     // conv #3 weights  [12][9][32][16]
-    const _Float16 *wl_hi, *wl_lo;     // LFF weights      [14][1][96][16]
-    const float *bc, *bl;              // biases (32 / 96 floats)
-    _Float16 *y_hi, *y_lo;             // output planes (6 chunks)
-    _Float16 *o3_hi, *o3_lo;           // optional: where to keep o3 (2 chunks) for the backward pass
-    unsigned* flags;                   // device status word (BINHIP_STATUS_*), may be null
-    int N, H, W, tiles_x, tiles_y, xcd_remap, wt;
-};
+#include "binhip_fused.h"
 
 template <int NT, int NBUF>
 struct TailCfg {
@@ -394,7 +385,10 @@ int binhip_rdb_tail_fwd(int N, int H, int W, int nterms, const void* blk_hi, con
 #endif
         return launch_tail<1, 2>(a, s);     // ring depth 2: measured best on MI355X (56.7 vs 63 us at 384x672)
     }
-    return launch_tail<3, 2>(a, s);
+#if BINHIP_TUNING
+    if (g_tail_depth == 1) return launch_tail<3, 2>(a, s);      // round-1 kernel: both planes per stage, 1 workgroup/CU
+#endif
+    return bh_launch_tail_x3(a, s);                              // plane-split stages, half-CU footprint (binhip_fused_x3.hip)
 }
 
 #if BINHIP_TUNING

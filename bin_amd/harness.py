@@ -56,7 +56,7 @@ def interpolate_clip(netG, clip, rank=0, world=1, reuse_stage1=True, batch=1):
     out = {}
     inner = netG.module if hasattr(netG, "module") else netG
     batch = max(1, int(batch))
-    stage1_cache = {} if (reuse_stage1 and batch == 1 and getattr(inner, "n_streams", 1) > 1) else None
+    stage1_cache = {} if (reuse_stage1 and batch == 1 and getattr(inner, "reuse_schedule", False)) else None
     for first in range(begin, end, batch):
         idx = list(range(first, min(first + batch, end)))
         ids = [window_frame_ids(i, T) for i in idx]
@@ -93,11 +93,12 @@ class GraphedNet:
         self.multi_stream = multi_stream
         self.static_in = [f.detach().clone().contiguous().float() for f in example_frames]
         self.inner = inner = netG.module if hasattr(netG, "module") else netG
-        saved_streams = getattr(inner, "n_streams", 1)
+        saved_streams = getattr(inner, "n_streams", None)
         if not multi_stream:
             inner.n_streams = 1
-        elif saved_streams < 2:
+        elif inner.resolved_streams() < 2:
             raise RuntimeError("GraphedNet(multi_stream=True) needs the multi-stream inference schedule (n_streams > 1)")
+        self._ns = inner.resolved_streams()
         try:
             self._capture(netG, warmup)
         finally:
@@ -134,11 +135,14 @@ class GraphedNet:
             self.graph.replay()
             return self.static_out
         inner = self.inner
+        saved = inner.n_streams
+        inner.n_streams = self._ns                       # the stream assignment the per-call graphs were captured with
         inner._graph_mode, inner._call_graphs = "replay", self.call_graphs
         try:
             return netG_call(self.net, self.static_in)
         finally:
             inner._graph_mode, inner._call_graphs = None, None
+            inner.n_streams = saved
 
 
 def netG_call(netG, frames):

@@ -108,15 +108,24 @@ class _RDNBase(nn.Module):
                                    nn.Conv2d(64, 3, kSize, padding=1, stride=1))
         self.precision = None          # None -> inherit default_precision()
         self._wcache = None            # (key, RdnWeights)
+        self._wgen = 0                 # bumped by invalidate_kernel_weights()
+
+    def _weights_key(self, nterms):
+        params = list(self.parameters())
+        return (nterms, str(params[0].device), self._wgen, tuple((p.data_ptr(), p._version) for p in params))
+
+    def invalidate_kernel_weights(self):
+        """Force a relayout on the next forward.  The cache key holds every parameter's (data_ptr, _version); a write
+        through `.data` (p.data.copy_(), EMA / clipping code, dist.broadcast(p.data)) does NOT bump _version, so code
+        that mutates parameters that way must call this (load_network and the DP parameter broadcast do)."""
+        self._wgen += 1
 
     def kernel_weights(self, nterms):
         """Relayout the 66 convolutions into kernel layout, cached on the parameters' version counters."""
-        params = dict(self.named_parameters())
-        key = (nterms, str(next(iter(params.values())).device),
-               tuple((p.data_ptr(), p._version) for p in params.values()))
+        key = self._weights_key(nterms)
         if self._wcache is None or self._wcache[0] != key:
             with torch.no_grad():
-                self._wcache = (key, RdnWeights(params, self.N_INPUTS, nterms))
+                self._wcache = (key, RdnWeights(dict(self.named_parameters()), self.N_INPUTS, nterms))
         return self._wcache[1]
 
     def _run(self, *frames):
@@ -225,7 +234,10 @@ class RDN_residual_interp_5_input_ConvLSTM_L(nn.Module):
         self.hidden_state = None
         self.reuse_schedule = True
         self.precision = None
-        self.n_streams = int(os.environ.get("BIN_AMD_STREAMS", "3"))   # concurrent RDN calls in inference
+        # concurrent RDN calls in inference; None = by precision (f16: 3 streams fill each other's launch tails;
+        # f16x3: 1 — the chip is power-capped there and one call's 231 MB block buffer stays Infinity-Cache
+        # resident only when nothing else streams beside it: 74.1 vs 76.4 ms per 720p window, same box)
+        self.n_streams = int(os.environ["BIN_AMD_STREAMS"]) if os.environ.get("BIN_AMD_STREAMS") else None
         self.batched = os.environ.get("BIN_AMD_BATCHED", "0") != "0"   # batch the shared-weight calls of a stage
         self._streams = None
 
@@ -255,14 +267,20 @@ class RDN_residual_interp_5_input_ConvLSTM_L(nn.Module):
         with torch.cuda.device(B1.device):             # kernels launch on the CURRENT device: make it the frames' one
             return self._forward(B1, B3, B5, B7, B9, B11, stage1_cache, input_events)
 
+    def resolved_streams(self):
+        if self.n_streams is not None:
+            return max(1, int(self.n_streams))
+        return 1 if (self.precision or default_precision()) == "f16x3" else 3
+
     def _forward(self, B1, B3, B5, B7, B9, B11, stage1_cache=None, input_events=None):
-        if self.n_streams > 1 and self.reuse_schedule and self.modelType == "lstm" and not (
-                torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
-            if self.batched:
+        if self.reuse_schedule and self.modelType == "lstm" and not (
+                torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or
+                                             any(t.requires_grad for t in (B1, B3, B5, B7, B9, B11)))):
+            if self.batched and self.resolved_streams() > 1:
                 return self._forward_batched((B1, B3, B5, B7, B9, B11), stage1_cache)
             return self._forward_streams((B1, B3, B5, B7, B9, B11), stage1_cache, input_events)
         if stage1_cache is not None or input_events is not None:
-            raise RuntimeError("bin_amd: stage1_cache / input_events need the inference schedule (n_streams > 1, no grad)")
+            raise RuntimeError("bin_amd: stage1_cache / input_events need the inference schedule (reuse_schedule, no grad)")
         cells = (self.clstm_4_prime, self.clstm_6_prime, self.clstm_8_prime, self.clstm_5_prime_prime,
                  self.clstm_7_prime_prime, self.clstm_6_prime_prime_prime)
         picks = (1, 2, 3, 5, 6, 8)
@@ -299,12 +317,18 @@ def _forward_streams(self, B, stage1_cache=None, input_events=None):
     from ... import _lib as L
     dev = B[0].device
     main = torch.cuda.current_stream(dev)
-    if self._streams is None or len(self._streams) != self.n_streams:
-        self._streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_streams)]
-    streams = self._streams
+    ns = self.resolved_streams()
+    if ns == 1:
+        streams = [main]                  # serial: everything on the caller's stream, no cross-stream events at all
+    else:
+        if self._streams is None or len(self._streams) != ns or self._streams[0].device != dev:
+            self._streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
+        streams = self._streams
     m = self.model
     mods = {1: m.model1_1, 2: m.model2_1, 3: m.model3_1, 4: m.model4_1}
     nterms = {k: PRECISIONS[v.precision or default_precision()] for k, v in mods.items()}
+    stale = [v._wcache is None or v._wcache[0] != v._weights_key(nterms[k]) for k, v in mods.items()]
+    relayout_pending = any(stale)
     kw = {k: v.kernel_weights(nterms[k]) for k, v in mods.items()}       # relayouts (if any) on the main stream
     lib = L.lib()
     n, _, h, w = B[0].shape
@@ -315,6 +339,8 @@ def _forward_streams(self, B, stage1_cache=None, input_events=None):
     counter = [0]
 
     def launch(si, fn, ins):
+        if ns == 1 and mode is None:      # serial on the caller's stream: program order is the dependency order
+            return fn()
         # a consumer waits on the event recorded right after the producing CALL (exact dependency, eager events)
         s = streams[si % len(streams)]
         for t in ins:
@@ -345,16 +371,21 @@ def _forward_streams(self, B, stage1_cache=None, input_events=None):
         return out
 
     def rdn(si, k, *ins):
-        ins = [t.contiguous().float() for t in ins]
         nb = lib.binhip_rdn_workspace_bytes(n, h, w, len(ins), nterms[k])
 
         def fn():
+            # layout / dtype conversions (no-ops for the usual contiguous fp32 frames) run on the call's own stream,
+            # after its waits on the producers — not on the caller's stream, where nothing would order them
             ws = workspace(nb, dev, key=f"fwd-stream{si % len(streams)}")
-            return rdn_forward(kw[k], ins, ws=ws)
+            return rdn_forward(kw[k], [t.contiguous().float() for t in ins], ws=ws)
         return launch(si, fn, ins)
 
     for s in streams:
-        if input_events is None:
+        if s is main:
+            continue
+        # the side streams always wait for what the caller's stream has queued so far: besides the frames that is the
+        # weight relayouts kernel_weights() may just have issued there (first call / after an optimizer step)
+        if input_events is None or relayout_pending:
             s.wait_stream(main)
         else:                            # pipelined: only the frames' own events, not everything queued on `main`
             for ev in input_events:
@@ -398,9 +429,10 @@ def _forward_streams(self, B, stage1_cache=None, input_events=None):
     J4pp = rdn(0, 3, h5, B5, J3, J5, B7); J6pp = rdn(1, 3, h7, B7, J5, J7, B9)
     J5ppp = rdn(0, 4, h6pp, I6, J4pp, J6pp, I8)
     for s in streams:
-        main.wait_stream(s)
+        if s is not main:
+            main.wait_stream(s)
     outs = (I2, I4, I6, I8, I3, I5, I7, I4pp, I6pp, I5ppp, I8b, J7, J6pp, J5ppp)
-    if mode is None and not torch.cuda.is_current_stream_capturing():
+    if ns > 1 and mode is None and not torch.cuda.is_current_stream_capturing():
         # caching-allocator bookkeeping for tensors that crossed streams (graph outputs live in the graphs' private pools)
         for t in outs + (h4, h6, h8, h5, h7, h6pp, J3, J5, J4pp):
             for s in streams:

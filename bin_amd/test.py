@@ -133,7 +133,7 @@ def main(argv=None):
     netG.eval()
     dev = next(netG.parameters()).device
     inner = netG.module if hasattr(netG, "module") else netG
-    reuse = (not args.no_reuse) and getattr(inner, "n_streams", 1) > 1
+    reuse = (not args.no_reuse) and getattr(inner, "reuse_schedule", False)
     log.info("In Data: %s | model: %s | parameters: %d | ranks: %d | stage-1 reuse: %s", args.input_path,
              opt["path"]["pretrain_model_G"], sum(p.numel() for p in netG.parameters() if p.requires_grad), world, reuse)
 

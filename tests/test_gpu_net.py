@@ -140,6 +140,44 @@ def test_full_720p_properties():
         assert torch.equal(x, z)
 
 
+@pytest.mark.parametrize("prec", ["f16x3", "f16"])
+def test_full_720p_vs_reference_fixture(prec):
+    """BASELINE config 1 at FULL size (test.py:348-379: a 1280x720 window padded to 768x1344) against the REFERENCE
+    network's own outputs, committed as tests/golden/g8_720p.npz (tests/golden/make_golden_720p.py imported
+    /root/reference in the build container: strided samples of all 14 outputs + whole-tensor statistics + the PSNR of
+    the three images test.py writes).  Bars: f16x3 max-abs 2e-5, f16 max-abs 1e-3, both |dPSNR| <= 0.01 dB."""
+    from bin_amd import ops
+    from bin_amd.utils import util
+    from bin_amd.weights import synthetic_frames
+    g = load_golden("g8_720p")
+    stride = int(g["stride"])
+    H, W = 720, 1280
+    frames = synthetic_frames(int(g["seed_frames"]), 1, H, W, 6)
+    pads = tuple(int(v) for v in g["pads"])
+    assert pads == tuple(util.pad_sizes(H, W))
+    padded = [util.replicate_pad(f, pads).cuda() for f in frames]
+    with torch.no_grad():
+        out = _net(prec)(*padded)
+    torch.cuda.synchronize()
+    ops.check_status()
+    worst = 0.0
+    for k, o in enumerate(out):
+        o = o.cpu()
+        smp = o[0, :, (k % stride)::stride, ((5 * k) % stride)::stride]
+        worst = max(worst, float((smp - torch.from_numpy(g[f"s{k}"])).abs().max()))
+        a = o.abs().double()
+        mx, mean, _ = g["stats"][k]
+        assert abs(float(a.max()) - mx) <= TOL[prec] and abs(float(a.mean()) - mean) <= TOL[prec], (k, float(a.max()), mx)
+    assert worst <= TOL[prec], worst
+    l, r, t, b = pads
+    target = util.tensor2img(frames[3][0])
+    for j, idx in enumerate((13, 8, 12)):
+        img = util.tensor2img(out[idx][0])[t:t + H, l:l + W]
+        assert abs(util.calculate_psnr(img, target) - float(g["psnr"][j])) <= 0.01
+        d = np.abs(img[::8, ::8].astype(np.int16) - g[f"u8_{idx}"].astype(np.int16))
+        assert int(d.max()) <= 1                      # uint8 images agree to one rounding step at most
+
+
 def test_cpu_tensor_raises():
     from bin_amd.weights import synthetic_frames
     net = _net("f16")
