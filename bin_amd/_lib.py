@@ -46,13 +46,13 @@ _SIGNATURES = {
     "binhip_conv2d_fwd": (C.c_int, [C.POINTER(BinConvDesc)] + [C.c_void_p] * 10 +
                           [C.POINTER(C.c_void_p), C.c_void_p]),
     "binhip_nchw_to_planes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
-                                        C.c_void_p]),
+                                        C.c_void_p, C.c_void_p]),
     "binhip_planes_to_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                         C.c_void_p]),
     "binhip_pixel_unshuffle_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                              C.c_void_p]),
     "binhip_pack_inputs": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
-                                     C.c_void_p, C.c_void_p]),
+                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "binhip_u8_to_frame": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                      C.c_void_p]),
     "binhip_frame_to_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
@@ -77,7 +77,7 @@ _SIGNATURES = {
                                            C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "binhip_grad_scale": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "binhip_nchw_to_planes_scaled": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
-                                               C.c_void_p, C.c_void_p, C.c_void_p]),
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "binhip_unshuffle_planes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                           C.c_void_p, C.c_void_p]),
     "binhip_unpack_input_grads": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

@@ -57,6 +57,10 @@ class _RdnFn(torch.autograd.Function):
         ctx.dims = (n, h, w)
         ctx.param_meta = [(tuple(a.shape), a.device) for a in args[n_frames:]]
         ctx.params = args[n_frames:]
+        # backward calls still owed to this weight set in the current step (the pyramid shares model1 / model2 / model3
+        # between 4-5 / 3 / 2 calls): when the count returns to zero the set's gradients are complete and a data-parallel
+        # reducer may start their all-reduce while the rest of the backward is still running (bin_model.FlatGradAllReduce)
+        module._bwd_pending = getattr(module, "_bwd_pending", 0) + 1
         return out
 
     @staticmethod
@@ -106,6 +110,11 @@ class _RdnFn(torch.autograd.Function):
             L.check(lib.binhip_rdn_backward(C.byref(plan), _ptr(ctx.saved_ws), ctx.saved_ws.numel(), _ptr(gout),
                                             _ptr(ws), ws.numel(), _stream()), "rdn_backward")
         ctx.saved_ws = None
+        module._bwd_pending = getattr(module, "_bwd_pending", 1) - 1
+        if module._bwd_pending == 0 and direct:
+            cb = getattr(module, "_grads_ready_cb", None)
+            if cb is not None:
+                cb()
         if direct:
             if not have:
                 for p, g in zip(params, grads):

@@ -47,20 +47,6 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// fp16 storage range.  The reference computes in fp32 (RDN.py:141, no AMP), so a value beyond +-65504 is legal there;
-// here it cannot be stored in an fp16 hi plane.  Rather than let hi = inf, lo = -inf poison every later layer with NaN,
-// the epilogue saturates hi to +-65504 (lo then carries what it can of the rest) and raises bit 0 of the status word,
-// which the host checks (bin_amd/ops.py: RuntimeError "fp16 range exceeded").  Documented in include/binhip.h.
-#define BINHIP_F16_MAX 65504.0f
-#define BINHIP_FLAG_SATURATED 1u
-
-// returns hi; sat |= (v left the range or is NaN: c != v holds for NaN too)
-__device__ __forceinline__ _Float16 split_hi(float v, bool& sat) {
-    const float c = fminf(fmaxf(v, -BINHIP_F16_MAX), BINHIP_F16_MAX);
-    sat = sat || (c != v);
-    return (_Float16)c;
-}
-
 // 16-byte plane store.  wt != 0: write-through (sc1) so the XCD's L2 holds no dirty output lines at the end of the
 // kernel: the kernel-boundary release then has nothing to write back (MI355X: 8 XCDs with private, mutually
 // non-coherent L2s => every boundary flushes dirty lines; 16.5 MB of output costs ~2.8 us there).
@@ -184,7 +170,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, floatx16 (&acc
                         for (int j = 0; j < 4; ++j) {
                             const _Float16 hj = split_hi(v[j], sat);
                             hv[ge].h[j] = hj;
-                            lv[ge].h[j] = (_Float16)(v[j] - (float)hj);
+                            lv[ge].h[j] = split_lo(v[j], hj);
                         }
                     }
                     // vdst = even group, src = odd group: upper half of vdst <-> lower half of src

@@ -234,7 +234,7 @@ rdb_tail_kernel(const TailKArgs a) {
                 for (int j = 0; j < 4; ++j) {
                     const _Float16 hj = split_hi(v[j], sat);
                     hv[ge].h[j] = hj;
-                    lv[ge].h[j] = (_Float16)(v[j] - (float)hj);
+                    lv[ge].h[j] = split_lo(v[j], hj);
                 }
                 const int off = ((gp * C::R + r) * 32 + n) * 32 + ((ge ^ ((n >> 3) & 1)) << 4) + kg * 8;
                 *reinterpret_cast<half4*>(o3 + off) = hv[ge].h;
@@ -315,7 +315,7 @@ rdb_tail_kernel(const TailKArgs a) {
                     for (int j = 0; j < 4; ++j) {
                         const _Float16 hj = split_hi(v[j], sat);
                         hv[ge].h[j] = hj;
-                        lv[ge].h[j] = (_Float16)(v[j] - (float)hj);
+                        lv[ge].h[j] = split_lo(v[j], hj);
                     }
                 }
 #pragma unroll

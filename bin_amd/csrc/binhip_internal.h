@@ -25,6 +25,25 @@ __device__ static inline int bh_chunks_dev(int C) { return (C + 15) / 16; }
         if (e__ != hipSuccess) return (int)e__;             \
     } while (0)
 
+// fp16 storage range.  The reference computes in fp32 (RDN.py:141, no AMP), so a value beyond +-65504 is legal there;
+// here it cannot be stored in an fp16 hi plane.  Rather than let hi = inf, lo = -inf poison every later layer with NaN,
+// the epilogue saturates hi to +-65504 (lo then carries what it can of the rest) and raises bit 0 of the status word,
+// which the host checks (bin_amd/ops.py: RuntimeError "fp16 range exceeded").  Documented in include/binhip.h.
+#define BINHIP_F16_MAX 65504.0f
+#define BINHIP_FLAG_SATURATED 1u
+
+// returns hi; sat |= (v left the range or is NaN: c != v holds for NaN too)
+__device__ __forceinline__ _Float16 split_hi(float v, bool& sat) {
+    const float c = fminf(fmaxf(v, -BINHIP_F16_MAX), BINHIP_F16_MAX);
+    sat = sat || (c != v);
+    return (_Float16)c;
+}
+// lo = v - hi, itself kept inside the fp16 range: in range it is |lo| <= ulp(hi)/2 and the clamp is the identity; after
+// a saturated hi the excess can be anything (or NaN), and an unclamped conversion would store inf / NaN after all
+__device__ __forceinline__ _Float16 split_lo(float v, _Float16 hi) {
+    return (_Float16)fminf(fmaxf(v - (float)hi, -BINHIP_F16_MAX), BINHIP_F16_MAX);
+}
+
 // internal launcher used by both the per-op ABI and the RDN plan
 struct BhConvCall {
     BinConvDesc d;

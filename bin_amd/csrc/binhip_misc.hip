@@ -11,7 +11,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 // one thread = one 16-byte slot (8 channels of one pixel)
 __global__ void nchw_to_planes_kernel(const float* __restrict__ x, int N, int C, int H, int W,
                                       _Float16* __restrict__ y_hi, _Float16* __restrict__ y_lo,
-                                      const float* __restrict__ scale) {
+                                      const float* __restrict__ scale, unsigned* __restrict__ flags) {
     const float sc = scale ? scale[0] : 1.f;
     const long long HW = (long long)H * W;
     const long long total = (long long)bh_chunks_dev(C) * N * HW * 2;
@@ -23,15 +23,17 @@ __global__ void nchw_to_planes_kernel(const float* __restrict__ x, int N, int C,
     const int n = (int)(u % N);
     const int ch = (int)(u / N);
     half8 hv, lv;
+    bool sat = false;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int c = ch * 16 + s * 8 + e;
         const float v = (c < C) ? x[((long long)n * C + c) * HW + pix] * sc : 0.f;
-        hv[e] = (_Float16)v;
-        lv[e] = (_Float16)(v - (float)hv[e]);
+        hv[e] = split_hi(v, sat);
+        lv[e] = split_lo(v, hv[e]);
     }
     *reinterpret_cast<half8*>(y_hi + t * 8) = hv;
     if (y_lo) *reinterpret_cast<half8*>(y_lo + t * 8) = lv;
+    if (sat && flags) atomicOr(flags, BINHIP_FLAG_SATURATED);
 }
 
 // one thread = one (n, c, pixel) output element; reads are 2-byte gathers (test/boundary glue only)
@@ -70,7 +72,8 @@ struct PackArgs {
     const float* img[5];
     int nimg, N, H, W;   // full-res H, W
 };
-__global__ void pack_inputs_kernel(PackArgs a, _Float16* __restrict__ y_hi, _Float16* __restrict__ y_lo) {
+__global__ void pack_inputs_kernel(PackArgs a, _Float16* __restrict__ y_hi, _Float16* __restrict__ y_lo,
+                                   unsigned* __restrict__ flags) {
     const int h = a.H / 2, w = a.W / 2;
     const long long hw = (long long)h * w;
     const int C = 12 * a.nimg;
@@ -85,6 +88,7 @@ __global__ void pack_inputs_kernel(PackArgs a, _Float16* __restrict__ y_hi, _Flo
     const int ch = (int)(u / a.N);
     const int y = (int)(pix / w), x = (int)(pix % w);
     half8 hv, lv;
+    bool sat = false;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int c = ch * 16 + s * 8 + e;     // = 4*cc + 2*i + j   (RDN.py:128-132)
@@ -94,11 +98,12 @@ __global__ void pack_inputs_kernel(PackArgs a, _Float16* __restrict__ y_hi, _Flo
             const int im = cc / 3, rgb = cc - im * 3;
             v = a.img[im][(((long long)n * 3 + rgb) * a.H + (2 * y + i)) * a.W + (2 * x + j)];
         }
-        hv[e] = (_Float16)v;
-        lv[e] = (_Float16)(v - (float)hv[e]);
+        hv[e] = split_hi(v, sat);
+        lv[e] = split_lo(v, hv[e]);
     }
     *reinterpret_cast<half8*>(y_hi + t * 8) = hv;
     if (y_lo) *reinterpret_cast<half8*>(y_lo + t * 8) = lv;
+    if (sat && flags) atomicOr(flags, BINHIP_FLAG_SATURATED);
 }
 
 // ---- harness glue: the per-frame host work of test.py moved onto the device -----------------
@@ -450,23 +455,23 @@ int binhip_device_cus(void) {
     return n;
 }
 
-int binhip_nchw_to_planes(const float* x, int N, int C, int H, int W, void* y_hi, void* y_lo, void* stream) {
+int binhip_nchw_to_planes(const float* x, int N, int C, int H, int W, void* y_hi, void* y_lo, void* status, void* stream) {
     if (!x || !y_hi) return BINHIP_E_ARG;
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return BINHIP_E_SHAPE;
     const long long total = (long long)bh_chunks(C) * N * H * W * 2;
     hipLaunchKernelGGL(nchw_to_planes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       x, N, C, H, W, (_Float16*)y_hi, (_Float16*)y_lo, (const float*)nullptr);
+                       x, N, C, H, W, (_Float16*)y_hi, (_Float16*)y_lo, (const float*)nullptr, (unsigned*)status);
     BH_CHECK_LAUNCH();
     return 0;
 }
 
 int binhip_nchw_to_planes_scaled(const float* x, int N, int C, int H, int W, const float* scale, void* y_hi,
-                                 void* y_lo, void* stream) {
+                                 void* y_lo, void* status, void* stream) {
     if (!x || !y_hi || !scale) return BINHIP_E_ARG;
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return BINHIP_E_SHAPE;
     const long long total = (long long)bh_chunks(C) * N * H * W * 2;
     hipLaunchKernelGGL(nchw_to_planes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       x, N, C, H, W, (_Float16*)y_hi, (_Float16*)y_lo, scale);
+                       x, N, C, H, W, (_Float16*)y_hi, (_Float16*)y_lo, scale, (unsigned*)status);
     BH_CHECK_LAUNCH();
     return 0;
 }
@@ -492,7 +497,7 @@ int binhip_pixel_unshuffle_f32(const float* x, int N, int C, int H, int W, int r
 }
 
 int binhip_pack_inputs(const float* const* images, int n_images, int N, int H, int W, void* y_hi, void* y_lo,
-                       void* stream) {
+                       void* status, void* stream) {
     if (!images || !y_hi) return BINHIP_E_ARG;
     if (n_images < 1 || n_images > 5 || N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return BINHIP_E_SHAPE;
     PackArgs a;
@@ -501,7 +506,7 @@ int binhip_pack_inputs(const float* const* images, int n_images, int N, int H, i
     a.nimg = n_images; a.N = N; a.H = H; a.W = W;
     const long long total = (long long)bh_chunks(12 * n_images) * N * (H / 2) * (W / 2) * 2;
     hipLaunchKernelGGL(pack_inputs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       a, (_Float16*)y_hi, (_Float16*)y_lo);
+                       a, (_Float16*)y_hi, (_Float16*)y_lo, (unsigned*)status);
     BH_CHECK_LAUNCH();
     return 0;
 }

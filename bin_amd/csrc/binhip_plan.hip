@@ -72,7 +72,7 @@ int binhip_rdn_forward(const BinRdnPlan* p, const float* const* inputs, float* o
     auto HI = [&](int64_t off) { return (void*)(base + off); };
     auto LO = [&](int64_t off, int64_t size) { return nt == 3 ? (void*)(base + off + size) : (void*)nullptr; };
 
-    int rc = binhip_pack_inputs(inputs, nin, N, H, W, HI(w.x0), LO(w.x0, w.s_x0), stream);
+    int rc = binhip_pack_inputs(inputs, nin, N, H, W, HI(w.x0), LO(w.x0, w.s_x0), p->status, stream);
     if (rc) return rc;
 
     auto conv = [&](int layer, int ks, int cin_chunks, int cout, int cout_pad, int epi, int relu, int Hc, int Wc,
@@ -239,7 +239,7 @@ int binhip_rdn_backward(const BinRdnBwdPlan* p, const void* saved, size_t saved_
     const int accumulate = (p->reserved & BINHIP_BWD_ACCUMULATE) ? 1 : 0;   // dw/db += instead of =
     int rc;
     if ((rc = binhip_grad_scale(gout, (int64_t)N * 3 * H * W, 16.f, amax_part, sc, stream))) return rc;
-    if ((rc = binhip_nchw_to_planes_scaled(gout, N, 3, H, W, sc, GH(b.gout), GL(b.gout, b.s_gout), stream))) return rc;
+    if ((rc = binhip_nchw_to_planes_scaled(gout, N, 3, H, W, sc, GH(b.gout), GL(b.gout, b.s_gout), p->status, stream))) return rc;
 
     // weight gradient of forward layer `layer`: X = saved activations, gY = gradient planes
     auto wgrad = [&](int layer, int ks, int Hc, int Wc, int cin_chunks, int cin, int cout, int64_t x_off, int64_t x_size,

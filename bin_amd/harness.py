@@ -72,6 +72,7 @@ def interpolate_clip(netG, clip, rank=0, world=1, reuse_stage1=True, batch=1):
             Ft_p = netG(*inputs)
         for j, i in enumerate(idx):
             out[i] = tuple(ops.frame_to_u8(Ft_p[k][j:j + 1], t, l, h, w).cpu().numpy() for k in (13, 8, 12))
+        ops.check_status(dev)             # the .cpu() above synchronised: a saturated fp16 plane is an error, not an image
     return out
 
 

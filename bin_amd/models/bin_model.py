@@ -47,15 +47,58 @@ class SingleProcessParallel(nn.Module):
 
 
 class FlatGradAllReduce:
-    """Data-parallel gradient averaging with ONE collective per step (C1 in SURVEY.md §2c): every parameter's .grad is
-    a view into one flat fp32 buffer (11.44 M floats = 45.77 MB for bin_stage4), so autograd accumulates straight into
-    it and the all-reduce (RCCL over xGMI under "nccl", gloo in the CPU tests) runs on the buffer in place — no
-    per-parameter gather/scatter copies (540 tensors each way)."""
+    """Data-parallel gradient averaging over ONE flat buffer (C1 in SURVEY.md §2c): every parameter's .grad is a view
+    into one flat fp32 buffer (11.44 M floats = 45.77 MB for bin_stage4), so autograd / the backward kernels accumulate
+    straight into it and the all-reduce (RCCL over xGMI under "nccl", gloo in the CPU tests) runs on the buffer in
+    place — no per-parameter gather/scatter copies (540 tensors each way).
+
+    Overlap (SURVEY §8e "launched during backward in >= 2 chunks"): `watch(net)` registers the four RDN weight sets.
+    The backward of the pyramid finishes them in the order model4, model3, model2, model1 (each set's gradient is
+    complete when the LAST call that shares it has run its backward — bin_amd.autograd counts them); at that moment
+    the set's contiguous slice of the flat buffer is all-reduced on a SIDE stream, behind an event recorded on the
+    compute stream, while the remaining backward kernels keep running.  `__call__` (after backward) reduces whatever
+    is left (ConvLSTM cells; everything, if nothing was watched), joins the side stream and divides by the world size.
+    On CPU tensors (gloo tests) there are no streams: the same slices are reduced synchronously."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
         self.flat = None
+        self.force_collective = False      # run the collectives even at world size 1 (tests of the RCCL path)
+        self._buckets = []                 # (module, start, end) slices whose completion is signalled during backward
+        self._reduced = []                 # slices already all-reduced in this step
+        self._stream = None
+
+    def _offsets(self):
+        o = 0
+        for p in self.params:
+            yield o
+            o += p.numel()
+
+    def watch(self, net):
+        """Register every shared RDN weight set of `net` whose parameters form one contiguous slice of the buffer."""
+        from .archs.RDN import _RDNBase
+        off = {id(p): o for p, o in zip(self.params, self._offsets())}
+        self._buckets = []
+        seen = set()
+        for mod in net.modules():
+            if not isinstance(mod, _RDNBase) or id(mod) in seen:
+                continue
+            seen.add(id(mod))
+            ps = [p for p in mod.parameters() if p.requires_grad]
+            if not ps or any(id(p) not in off for p in ps):
+                continue
+            start = off[id(ps[0])]
+            end = start
+            ok = True
+            for p in ps:
+                ok = ok and off[id(p)] == end
+                end += p.numel()
+            if ok:
+                idx = len(self._buckets)
+                self._buckets.append((mod, start, end))
+                mod._grads_ready_cb = (lambda i=idx: self._bucket_ready(i))
+        return self
 
     def attach(self):
         """Zero the flat buffer and (re)point every .grad at its slice; call after optimizer.zero_grad()."""
@@ -68,23 +111,61 @@ class FlatGradAllReduce:
         for p in self.params:
             p.grad = self.flat[o:o + p.numel()].view_as(p)
             o += p.numel()
+        self._reduced = []
+        for mod, _, _ in self._buckets:
+            mod._bwd_pending = 0
+
+    def _active(self):
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.force_collective)
+
+    def _views_intact(self):
+        return self.flat is not None and all(p.grad is not None and p.grad.data_ptr() == self.flat.data_ptr() + 4 * o
+                                             for p, o in zip(self.params, self._offsets()))
+
+    def _reduce_slice(self, start, end, overlap):
+        import torch.distributed as dist
+        piece = self.flat[start:end]
+        if overlap and piece.is_cuda:
+            main = torch.cuda.current_stream(piece.device)
+            if self._stream is None or self._stream.device != piece.device:
+                self._stream = torch.cuda.Stream(device=piece.device)
+            ev = torch.cuda.Event()
+            ev.record(main)                          # everything that wrote this slice is queued before this point
+            self._stream.wait_event(ev)
+            with torch.cuda.stream(self._stream):
+                dist.all_reduce(piece, op=dist.ReduceOp.SUM)
+        else:
+            dist.all_reduce(piece, op=dist.ReduceOp.SUM)
+        self._reduced.append((start, end))
+
+    def _bucket_ready(self, idx):
+        """Called from the backward pass when weight set `idx` has received its last contribution."""
+        if not self._active() or not self._views_intact():
+            return
+        _, start, end = self._buckets[idx]
+        if (start, end) not in self._reduced:
+            self._reduce_slice(start, end, overlap=True)
 
     def __call__(self):
         import torch.distributed as dist
-        world = dist.get_world_size()
-        if world == 1:
+        if not self._active():
             return
-        if self.flat is None or any(p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * o
-                                    for p, o in zip(self.params, self._offsets())):
+        world = dist.get_world_size()
+        if not self._views_intact():
             self._gather()                       # somebody replaced a .grad (or attach() was skipped): copy in
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        self.flat.div_(world)
-
-    def _offsets(self):
-        o = 0
-        for p in self.params:
-            yield o
-            o += p.numel()
+            self._reduced = []
+        # the remainder: maximal runs of the buffer not covered by an early bucket
+        pos = 0
+        for start, end in sorted(self._reduced) + [(self.numel, self.numel)]:
+            if start > pos:
+                self._reduce_slice(pos, start, overlap=False)
+            pos = max(pos, end)
+        if self._stream is not None and self.flat.is_cuda:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self._stream)
+        self._reduced = []
+        if world > 1:
+            self.flat.div_(world)
 
     def _gather(self):
         dev = self.params[0].device
@@ -116,9 +197,9 @@ class bin_model(BaseModel):
 
         self.netG = (netG if netG is not None else networks.define_G(opt)).to(self.device)
         self.netG = SingleProcessParallel(self.netG)
-        self.grad_sync = FlatGradAllReduce(self.netG.parameters()) if opt["dist"] else None
+        self.grad_sync = FlatGradAllReduce(self.netG.parameters()).watch(self.netG) if opt["dist"] else None
         if opt["dist"]:
-            self._broadcast_parameters()
+            self.broadcast_parameters()
 
         self.print_network()
         self.load()
@@ -171,11 +252,26 @@ class bin_model(BaseModel):
             self.inst_log_dict = OrderedDict()
 
     # ------------------------------------------------------------------ distributed helpers
-    def _broadcast_parameters(self):
+    def broadcast_parameters(self, force=False):
+        """Rank 0's parameters to every rank as ONE bucketed broadcast (a flat copy of the 11.44 M floats) instead of
+        540 small collectives; the relayouted kernel weights are invalidated explicitly because writing through
+        `.data`-style views does not bump the parameters' version counters."""
         import torch.distributed as dist
-        if dist.get_world_size() > 1:
-            for p in self.netG.parameters():
-                dist.broadcast(p.data, src=0)
+        if dist.get_world_size() == 1 and not force:
+            return
+        params = list(self.netG.parameters())
+        with torch.no_grad():
+            flat = torch.cat([p.detach().reshape(-1) for p in params])
+            dist.broadcast(flat, src=0)
+            o = 0
+            for p in params:
+                p.copy_(flat[o:o + p.numel()].view_as(p))
+                o += p.numel()
+        for mod in self.netG.modules():
+            if hasattr(mod, "invalidate_kernel_weights"):
+                mod.invalidate_kernel_weights()
+
+    _broadcast_parameters = broadcast_parameters
 
     # ------------------------------------------------------------------ training step (bin_model.py:130-141)
     def optimize_parameters(self, step):
@@ -303,6 +399,11 @@ class bin_model(BaseModel):
         self.train_loss_total = [AverageMeter() for _ in range(self.get_info() + 1)]
 
     def train_AverageMeter_update(self):
+        # the .item() reads below synchronise anyway: also surface a saturated fp16 plane (include/binhip.h, "Dynamic
+        # range") as an error here instead of training on silently clamped activations / gradients
+        from .. import ops
+        if self.loss.is_cuda:
+            ops.check_status(self.loss.device)
         num = len(self.loss_list)
         for i in range(num):
             self.train_loss_total[i].update(self.loss_list[i].item(), 1)
@@ -316,6 +417,9 @@ class bin_model(BaseModel):
         self.val_loss_total = [AverageMeter() for _ in range(self.get_info() + 1)]
 
     def val_loss_AverageMeter_update(self, loss_list, avg_loss):
+        from .. import ops
+        if avg_loss.is_cuda:
+            ops.check_status(avg_loss.device)
         num = len(loss_list)
         for i in range(num):
             self.val_loss_total[i].update(loss_list[i].item(), 1)

@@ -94,7 +94,8 @@ def nchw_to_planes(x, nterms=1):
     x = x.contiguous().float()
     n, c, h, w = x.shape
     y = CP.empty(chunks(c), n, h, w, nterms, x.device, c)
-    L.check(L.lib().binhip_nchw_to_planes(_ptr(x), n, c, h, w, _ptr(y.hi), _ptr(y.lo), _stream()), "nchw_to_planes")
+    L.check(L.lib().binhip_nchw_to_planes(_ptr(x), n, c, h, w, _ptr(y.hi), _ptr(y.lo), _ptr(status_word(x.device)),
+                                          _stream()), "nchw_to_planes")
     return y
 
 
@@ -115,7 +116,8 @@ def pack_inputs(images, nterms=1):
     k = len(images)
     y = CP.empty(chunks(12 * k), n, h // 2, w // 2, nterms, images[0].device, 12 * k)
     arr = (C.c_void_p * k)(*[im.data_ptr() for im in images])
-    L.check(L.lib().binhip_pack_inputs(arr, k, n, h, w, _ptr(y.hi), _ptr(y.lo), _stream()), "pack_inputs")
+    L.check(L.lib().binhip_pack_inputs(arr, k, n, h, w, _ptr(y.hi), _ptr(y.lo), _ptr(status_word(images[0].device)),
+                                       _stream()), "pack_inputs")
     return y
 
 
@@ -239,6 +241,45 @@ class DgradWeights:
         L.check(lib.binhip_weights_relayout_dgrad(_ptr(w), cout, cin, ks, self.cout_pad, self.cin_chunks, cb,
                                                   1 if shuffle else 0, _ptr(self.w_hi), _ptr(self.w_lo),
                                                   _ptr(self.bias), _stream()), "weights_relayout_dgrad")
+
+
+class RdbGatherWeights:
+    """Backward-data weights of ONE concat group of a residual dense block in gather form
+    (binhip_weights_relayout_rdb_gather, include/binhip.h): group g = 0 produces the gradient of the block's 96 input
+    channels, g = 1..3 that of conv g-1's 32 outputs, each as one forward-shaped 3x3 conv over the stacked output
+    gradients of convs g..3.  `weights4`: the block's four OIHW fp32 conv weights."""
+
+    def __init__(self, weights4, group, nterms=1):
+        _need_cuda(*weights4)
+        lib = L.lib()
+        self.ks, self.nterms = 3, nterms
+        self.cout = 96 if group == 0 else 32
+        self.cout_pad = self.cout
+        self.cin_chunks = 2 * (4 - group)
+        cb = lib.binhip_conv_cout_block(3, self.cout_pad, nterms)
+        nbytes = lib.binhip_weights_bytes(self.cout_pad, self.cin_chunks, 3)
+        dev = weights4[0].device
+        self.w_hi = torch.empty(nbytes // 2, dtype=torch.float16, device=dev)
+        self.w_lo = torch.empty(nbytes // 2, dtype=torch.float16, device=dev) if nterms == 3 else None
+        self.bias = torch.empty(self.cout_pad, dtype=torch.float32, device=dev)
+        self._src = [w.detach().contiguous().float() for w in weights4]
+        arr = (C.c_void_p * 4)(*[w.data_ptr() for w in self._src])
+        L.check(lib.binhip_weights_relayout_rdb_gather(arr, group, cb, _ptr(self.w_hi), _ptr(self.w_lo), _ptr(self.bias),
+                                                       _stream()), "weights_relayout_rdb_gather")
+
+
+def rdb_tail(blk, cw3, cwl, out=None, store_o3=False):
+    """Fused tail of a residual dense block (binhip_rdb_tail_fwd): o3 = relu(conv3x3(blk[0:192])), y = LFF(cat(blk[0:192],
+    o3)) + blk[0:96].  blk: 14-chunk CP (planes 12, 13 receive o3 when store_o3); returns the 6-chunk output CP."""
+    _, n, h, w, _ = blk.hi.shape
+    nt = cw3.nterms
+    if out is None:
+        out = CP.empty(6, n, h, w, nt, blk.hi.device, 96)
+    L.check(L.lib().binhip_rdb_tail_fwd(n, h, w, nt, _ptr(blk.hi), _ptr(blk.lo), _ptr(cw3.w_hi), _ptr(cw3.w_lo),
+                                        _ptr(cw3.bias), _ptr(cwl.w_hi), _ptr(cwl.w_lo), _ptr(cwl.bias), _ptr(out.hi),
+                                        _ptr(out.lo), 1 if store_o3 else 0, _ptr(status_word(blk.hi.device)), _stream()),
+            "rdb_tail_fwd")
+    return out
 
 
 def conv2d_bwd_data(gy, dw, res=None, res_chunks=0, acc=None, mask=None, mask_from=0, out=None):

@@ -111,8 +111,10 @@ _workspaces = {}
 
 
 def workspace(nbytes, device, key="fwd"):
-    """One cached workspace per (device, purpose), grown on demand."""
-    key = (device.type, device.index, key)
+    """One cached workspace per (device, CURRENT STREAM, purpose), grown on demand.  The stream is part of the key
+    because a workspace is only ordered against its own stream's work: two host threads (or two networks) driving
+    different streams of one device must never share one."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream, key)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)

@@ -214,10 +214,14 @@ def main(argv=None):
                 os.makedirs(os.path.join(result_root, clip), exist_ok=True)
             names = output_names(frames, index)
             clip_dir = os.path.join(result_root, clip)
-            # who writes what is settled here, in window order, as in the serial reference loop: <num+12> belongs to
-            # the first window that reaches it (its Ft_p[12]), the next window's Ft_p[8] of the same name is dropped
-            owned = [n is not None and (clip, n) not in claimed and not os.path.exists(os.path.join(clip_dir, n))
-                     for n in names]
+            # who writes what follows from the GLOBAL window index alone, as in the serial reference loop: <num+12>
+            # belongs to the window that reaches it first (its Ft_p[12]); the next window's Ft_p[8] has the same name
+            # and is dropped — so a window writes its first deblurred frame only when it opens the clip.  Decided
+            # without looking at the file system, two ranks on either side of a shard boundary can never both write
+            # one file (the existence check below only skips work a previous run already finished).
+            owned = [True, index == 0, names[2] is not None]
+            owned = [mine and (clip, n) not in claimed and not os.path.exists(os.path.join(clip_dir, n))
+                     for n, mine in zip(names, owned)]
             claimed.update((clip, n) for n, mine in zip(names, owned) if mine)
             if not any(owned) and not args.gt_path:
                 continue
@@ -245,6 +249,7 @@ def main(argv=None):
         for job, _ in pending:
             job.result()
     torch.cuda.synchronize()
+    ops.check_status(dev)                 # a frame that left the fp16 storage range is an error, not a result
     wall = time.time() - t_all
     pool.shutdown()
 

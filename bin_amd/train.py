@@ -56,8 +56,9 @@ def validate(model, loader, step, opt, log, max_batches=None):
     return loss_avg
 
 
-def main(argv=None, model_factory=None):
-    """`model_factory(opt)` replaces create_model (the CPU host-logic tests inject the oracle-backed wrapper)."""
+def main(argv=None, model_factory=None, probe=None):
+    """`model_factory(opt)` replaces create_model (the CPU host-logic tests inject the oracle-backed wrapper).
+    `probe`: optional dict that receives this rank's window order and first-epoch sampler share (tests)."""
     ap = argparse.ArgumentParser()
     ap.add_argument("-opt", "--opt", type=str, required=True, help="Path to option YAML file.")
     ap.add_argument("--launcher", choices=["none", "pytorch"], default="none")
@@ -92,7 +93,16 @@ def main(argv=None, model_factory=None):
     seed = opt["train"]["manual_seed"]
     if seed is None:
         seed = int(time.time()) % 10000
-    util.set_random_seed(seed + max(rank, 0))
+        if opt["dist"]:                     # a time-based seed must still be ONE seed: rank 0's
+            import torch.distributed as dist
+            box = [seed]
+            dist.broadcast_object_list(box, src=0)
+            seed = int(box[0])
+    # The dataset shuffles its window list with the global RNG (BIN_dataset.list_windows, as the reference does), and
+    # DistIterSampler hands every rank a disjoint share of ONE index permutation — which only partitions the data if all
+    # ranks map index -> window identically.  So the datasets are built under the rank-INDEPENDENT seed; the ranks'
+    # streams diverge (seed + rank: augmentation draws, worker seeds) only after that.
+    util.set_random_seed(seed)
 
     # ---- data
     train_loader = val_loader = sampler = None
@@ -118,6 +128,11 @@ def main(argv=None, model_factory=None):
             except (FileNotFoundError, NotADirectoryError):
                 log.warning("validation set [%s] not found; validation is skipped", ds_opt["dataroot_LQ"])
     assert train_loader is not None, "the option file has no `train` dataset"
+    if probe is not None:
+        probe["windows"] = [w[3] for w in train_set.all_paths]
+        probe["share"] = list(iter(sampler)) if sampler is not None else list(range(len(train_set)))
+        probe["ratio"] = int(opt["datasets"]["train"]["dist_ratio"] or 100)
+    util.set_random_seed(seed + max(rank, 0))
 
     # ---- model
     model = (model_factory or create_model)(opt)

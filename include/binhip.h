@@ -132,7 +132,7 @@ int binhip_conv2d_bwd_data(const BinConvDesc* d, const void* gy_hi, const void* 
 /* ---- layout glue ------------------------------------------------------------------------------ */
 /* fp32 NCHW [N,C,H,W] -> chunk planes (C padded with zeros to 16).                              */
 int binhip_nchw_to_planes(const float* x, int N, int C, int H, int W, void* y_hi, void* y_lo,
-                          void* stream);
+                          void* status, void* stream);
 /* chunk planes -> fp32 NCHW (hi + lo when lo != NULL).                                           */
 int binhip_planes_to_nchw(const void* x_hi, const void* x_lo, int N, int C, int H, int W, float* y,
                           void* stream);
@@ -141,7 +141,7 @@ int binhip_pixel_unshuffle_f32(const float* x, int N, int C, int H, int W, int r
 /* K1: pixel_reshuffle(cat(images), 2) (RDN.py:107-132, 211/269/323) fused into the CP writer:
  * `n_images` fp32 [N,3,H,W] -> CP [N, H/2, W/2, pad16(12*n_images)].                            */
 int binhip_pack_inputs(const float* const* images, int n_images, int N, int H, int W,
-                       void* y_hi, void* y_lo, void* stream);
+                       void* y_hi, void* y_lo, void* status, void* stream);
 
 /* ---- harness glue: test.py's per-frame host work on the device --------------------
  * u8_to_frame: HWC BGR uint8 -> fp32 CHW RGB /255 (read_image, test.py:44-56) + ReplicationPad2d
@@ -216,7 +216,7 @@ int binhip_conv2d_bwd_weight(const BinConvDesc* d, const void* x_hi, const void*
 int binhip_grad_scale(const float* g, int64_t numel, float target, float* partials, float* scale_out,
                       void* stream);
 int binhip_nchw_to_planes_scaled(const float* x, int N, int C, int H, int W, const float* scale,
-                                 void* y_hi, void* y_lo, void* stream);
+                                 void* y_hi, void* y_lo, void* status, void* stream);
 /* inverse PixelShuffle(2) on planes: nchunks planes at 2H x 2W -> 4*nchunks planes at H x W           */
 int binhip_unshuffle_planes(const void* x_hi, const void* x_lo, int N, int H, int W, int nchunks,
                             void* y_hi, void* y_lo, void* stream);

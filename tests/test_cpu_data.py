@@ -292,8 +292,9 @@ def _dist_worker(rank, world, port, yml, q):
         captured["m"] = T._tiny_factory(opt)
         return captured["m"]
 
-    rc = train.main(["-opt", yml, "--launcher", "pytorch", "--max_iter", "3"], model_factory=factory)
-    q.put((rank, rc, [p.detach().double().sum().item() for p in captured["m"].netG.parameters()]))
+    probe = {}
+    rc = train.main(["-opt", yml, "--launcher", "pytorch", "--max_iter", "3"], model_factory=factory, probe=probe)
+    q.put((rank, rc, [p.detach().double().sum().item() for p in captured["m"].netG.parameters()], probe))
     torch.distributed.destroy_process_group()
 
 
@@ -312,6 +313,17 @@ def test_train_loop_world2_gloo(tmp_path, adobe):
         assert p.exitcode == 0
     assert got[0][1] == 0 and got[1][1] == 0
     assert got[0][2] == got[1][2]                            # ranks hold identical parameters after 3 DP steps
+    # the ranks seed differently for augmentation (seed + rank) but must build the SAME shuffled window list, or the
+    # sampler's disjoint index shares would overlap / skip windows: union of the shares == ratio x dataset
+    pa, pb = got[0][3], got[1][3]
+    assert pa["windows"] == pb["windows"] and len(pa["windows"]) > 0
+    n, ratio = len(pa["windows"]), pa["ratio"]
+    union = sorted(pa["share"] + pb["share"])
+    want = sorted(list(range(n)) * ratio)
+    assert len(union) >= len(want) and len(union) - len(want) < 2           # rounded up to a multiple of the world size
+    from collections import Counter
+    cu, cw = Counter(union), Counter(want)
+    assert all(cu[i] >= cw[i] for i in range(n)) and sum((cu - cw).values()) == len(union) - len(want)
 
 
 def test_train_loop_reduce_lr_on_plateau(tmp_path, adobe, monkeypatch):

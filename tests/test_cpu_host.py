@@ -25,7 +25,13 @@ def test_library_exports_every_header_symbol():
     for sym in sorted(declared):
         assert hasattr(lib, sym), f"libbinhip.so does not export {sym}"
     assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
-    assert _lib.lib().binhip_version() >= 100
+    assert _lib.lib().binhip_version() >= 200
+    # the product library has no process-global switches (SURVEY §8b "no globals except immutable tables"): the
+    # tuning / ablation setters exist only in BINHIP_TUNING side builds and are not declared in the public header
+    for sym in _lib._TUNING_SIGNATURES:
+        assert not hasattr(lib, sym), f"product libbinhip.so must not export {sym}"
+        assert sym not in declared
+    assert "binhip_profile_begin" not in declared and "set_variant" not in hdr
 
 
 def test_library_host_queries():

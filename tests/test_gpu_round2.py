@@ -1,0 +1,348 @@
+"""-m gpu: checks added in round 2:
+  * one residual dense block driven through the per-op C ABI — forward + the gather-form backward — against the
+    REFERENCE's own block outputs / gradients (g2_rdb),
+  * BASELINE config 3 at its per-GPU size (8 x 256x256 crops): batch-8 gradients == mean of the eight batch-1
+    gradients, determinism, and a batch-1 256x256 step against torch autograd of the oracle,
+  * the wrappers' inference entry points (test_set_input / test_forward / test, VideoBaseModel.test / test_stitch)
+    on the real HIP network,
+  * fp16 storage range: saturation is detected (status word -> RuntimeError), tiny magnitudes stay accurate,
+  * the nccl (= RCCL) process group at world size 1, concurrent host threads, no process-global switches.
+"""
+import os
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def _train_opt(tmp_path, lr=1e-4, precision=None, dist=False):
+    return {"model": "bin", "gpu_ids": [0], "is_train": True, "dist": dist,
+            "network_G": {"which_model_G": "bin_stage4", "nframes": 6, "version": 2, "precision": precision},
+            "path": {"pretrain_model_G": None, "strict_load": True, "models": str(tmp_path), "training_state": str(tmp_path)},
+            "train": {"pixel_criterion": "cb", "pixel_weight": 1.0, "weight_decay_G": 0, "ft_tsa_only": None,
+                      "lr_G": lr, "beta1": 0.9, "beta2": 0.99, "lr_scheme": "MultiStepLR", "lr_steps": [100000],
+                      "restarts": None, "restart_weights": None, "lr_gamma": 0.5, "clear_state": False}}
+
+
+def _batch(B, S, seed):
+    g = torch.Generator().manual_seed(seed)
+    return {"LQs": torch.rand(B, 6, 3, S, S, generator=g), "GTenh": torch.rand(B, 6, 3, S, S, generator=g),
+            "GTinp": torch.rand(B, 5, 3, S, S, generator=g)}
+
+
+# ------------------------------------------------------------------------------------------------ dense block, per-op ABI
+@pytest.mark.parametrize("nterms,tol_y,tol_g", [(3, 2e-6, 3e-5), (1, 2e-3, 2.5e-1)])
+def test_rdb_block_forward_and_gather_backward_golden(nterms, tol_y, tol_g, canon_gpu):
+    """RDB(96, 32, 4) of model1 on the reference's own fixture (g2_rdb: x, y, gy -> gx and all ten parameter
+    gradients from the reference module's autograd).  Forward = three plane-concat convs + the fused tail; backward =
+    the launch sequence of binhip_plan.hip's dense-block section issued op by op through the C ABI: LFF wgrad/dgrad,
+    then per conv its wgrad and the GATHER-form backward-data (every concat group written once).
+    nterms = 1 (single fp16 product, the inference mode): ~1e-3 operand rounding in the forward flips ~0.3 % of the ReLU
+    masks, which on this white-noise upstream gradient costs up to ~20 % on individual weight-gradient tensors (same
+    bar as tests/test_gpu_backward.py::test_rdn_backward_vs_oracle_autograd[f16]); training defaults to nterms = 3."""
+    from bin_amd import ops
+    g = load_golden("g2_rdb")
+    pre = "model1.RDBs.0."
+    x = torch.from_numpy(g["x"]).cuda()
+    gy = torch.from_numpy(g["gy"]).cuda()
+    n, _, h, w = x.shape
+    W = [canon_gpu[f"{pre}convs.{c}.conv.0.weight"] for c in range(4)]
+    Bc = [canon_gpu[f"{pre}convs.{c}.conv.0.bias"] for c in range(4)]
+    WL, BL = canon_gpu[pre + "LFF.weight"], canon_gpu[pre + "LFF.bias"]
+    cw = [ops.ConvWeights(W[c], Bc[c], nterms=nterms) for c in range(4)]
+    cwl = ops.ConvWeights(WL, BL, nterms=nterms)
+    # ---- forward (RDN.py:135-165): blk planes 0-5 = x, conv c writes planes 6+2c, 7+2c, the tail keeps o3 in 12, 13
+    blk = ops.CP.empty(14, n, h, w, nterms, x.device)
+    xin = ops.nchw_to_planes(x, nterms)
+    blk.hi[0:6].copy_(xin.hi)
+    if nterms == 3:
+        blk.lo[0:6].copy_(xin.lo)
+    for c in range(3):
+        ops.conv2d(blk, cw[c], relu=True, out=blk.sub(6 + 2 * c, 2), cin_chunks=6 + 2 * c)
+    y = ops.planes_to_nchw(ops.rdb_tail(blk, cw[3], cwl, store_o3=True), 96)
+    ref_y = torch.from_numpy(g["y"]).cuda()
+    assert _rel(y, ref_y) <= tol_y
+    # ---- backward (autograd of the same lines), gather form
+    gyp = ops.nchw_to_planes(gy, nterms)
+    dWL, dbL = ops.conv2d_bwd_weight(blk, gyp, 96, 224, 1, nterms)
+    gcat = ops.conv2d_bwd_data(gyp, ops.DgradWeights(WL, nterms), res=gyp, res_chunks=6, mask=blk, mask_from=12)
+    assert gcat.hi.shape[0] == 14
+    grads = {}
+    gx = None
+    for c in (3, 2, 1, 0):
+        gyc = gcat.sub(6 + 2 * c, 2 * (4 - c))                     # stacked output gradients of convs c..3
+        grads[c] = ops.conv2d_bwd_weight(blk, gyc, 32, 96 + 32 * c, 3, nterms)
+        gw = ops.RdbGatherWeights(W, c, nterms)
+        if c > 0:
+            slot = gcat.sub(4 + 2 * c, 2)                          # conv c-1's output slot: G_{c-1} = relu'(L_c + sum dgrads)
+            ops.conv2d_bwd_data(gyc, gw, res=slot, mask=blk.sub(4 + 2 * c, 2), mask_from=0, out=slot)
+        else:
+            gx = ops.planes_to_nchw(ops.conv2d_bwd_data(gyc, gw, res=gcat.sub(0, 6)), 96)
+    torch.cuda.synchronize()
+    ops.check_status()
+    assert _rel(gx, torch.from_numpy(g["gx"]).cuda()) <= tol_g, "block input gradient"
+    assert _rel(dWL, torch.from_numpy(g["g.LFF.weight"]).cuda()) <= tol_g
+    assert _rel(dbL, torch.from_numpy(g["g.LFF.bias"]).cuda()) <= tol_g
+    for c in range(4):
+        assert _rel(grads[c][0], torch.from_numpy(g[f"g.convs.{c}.conv.0.weight"]).cuda()) <= tol_g, c
+        assert _rel(grads[c][1], torch.from_numpy(g[f"g.convs.{c}.conv.0.bias"]).cuda()) <= tol_g, c
+
+
+# ------------------------------------------------------------------------------------------------ config 3 at size
+def _grads(m):
+    return {n: p.grad.detach().clone() for n, p in m.netG.module.named_parameters()}
+
+
+def test_config3_step_8x256_batch_linearity_and_determinism(tmp_path):
+    """BASELINE config 3 per GPU: `optimize_parameters()` on 8 crops of 256x256 (bin_model.py:130-141 with
+    data/__init__.py:13-14: batch_size // world_size = 8).  Size-independent properties: the loss is a mean over the
+    batch, so the batch-8 gradient is the mean of the eight batch-1 gradients; the step is deterministic; nothing
+    leaves the fp16 storage range.  lr = 0 keeps the weights fixed across the nine steps."""
+    from bin_amd import ops
+    from bin_amd.models import create_model
+    from bin_amd.weights import reference_state_dict
+    m = create_model(_train_opt(tmp_path, lr=0.0))
+    m.netG.module.load_state_dict(reference_state_dict(0), strict=True)
+    data = _batch(8, 256, 7)
+    m.feed_data(data)
+    m.optimize_parameters(1)
+    loss8, g8 = float(m.loss), _grads(m)
+    assert np.isfinite(loss8) and 0.05 < loss8 < 1.0
+    m.optimize_parameters(2)
+    assert float(m.loss) == loss8
+    g8b = _grads(m)
+    for k in g8:
+        assert torch.equal(g8[k], g8b[k]), k                      # deterministic: every gradient bit
+    acc, losses = None, []
+    for i in range(8):
+        m.feed_data({k: v[i:i + 1] for k, v in data.items()})
+        m.optimize_parameters(3 + i)
+        losses.append(float(m.loss))
+        gi = _grads(m)
+        acc = gi if acc is None else {k: acc[k] + gi[k] for k in acc}
+    torch.cuda.synchronize()
+    ops.check_status()
+    assert abs(sum(losses) / 8 - loss8) <= 2e-6
+    worst = 0.0
+    for k in g8:
+        worst = max(worst, _rel(acc[k] / 8, g8[k]))
+    assert worst <= 2e-4, worst                                   # fp32-class kernels, different summation splits
+
+
+def test_config3_batch1_256_step_vs_oracle_autograd(tmp_path, canon_cpu):
+    """One 256x256 sample: loss, the 14 loss terms and all 540 parameter-gradient norms of the HIP step vs torch
+    autograd of the oracle (the reference restatement) on the host CPU (~30 s)."""
+    from bin_amd.models import create_model
+    from bin_amd.weights import reference_state_dict
+    from oracle import rdn_oracle as O
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    data = _batch(1, 256, 11)
+    Wc = {k: v.clone().requires_grad_(True) for k, v in canon_cpu.items()}
+    Ft = O.bin_stage4_forward([data["LQs"][:, i] for i in range(6)], Wc)
+    I = {1 + 2 * i: data["GTenh"][:, i] for i in range(6)}
+    I.update({2 + 2 * i: data["GTinp"][:, i] for i in range(5)})
+    loss, ll = O.bin_loss(Ft, I)
+    loss.backward()
+    m = create_model(_train_opt(tmp_path, lr=0.0))
+    m.netG.module.load_state_dict(reference_state_dict(0), strict=True)
+    m.feed_data(data)
+    m.optimize_parameters(1)
+    assert abs(float(m.loss) - float(loss)) <= 2e-6
+    assert float((torch.stack([l.detach() for l in m.loss_list]).cpu() - torch.stack([l.detach() for l in ll])).abs().max()) <= 5e-6
+    got = O.canon_from_state_dict({k: p.grad for k, p in m.netG.module.named_parameters()})
+    worst = 0.0
+    for k, g in got.items():
+        r = _rel(g.cpu(), Wc[k].grad)
+        worst = max(worst, r)
+        assert r <= 2e-3, (k, r)
+    print(f"256x256 step vs oracle autograd: worst relative parameter-gradient error {worst:.2e}")
+
+
+# ------------------------------------------------------------------------------------------------ wrapper entry points
+def test_wrapper_inference_entry_points_on_the_hip_net(tmp_path):
+    """bin_model.test_set_input / test_forward / test (bin_model.py:204-298, 361-380: what test.py:378-379 calls) and
+    VideoBaseModel.feed_data / test / test_stitch (Video_base_model.py:124-280) with the real HIP generator: same
+    tensors as calling the network directly; the stitcher reproduces the untiled result where the halo covers the
+    receptive field (constant frames) and keeps the tile interiors in place."""
+    from bin_amd.models import create_model
+    from bin_amd.models.Video_base_model import VideoBaseModel
+    from bin_amd.weights import reference_state_dict, synthetic_frames
+    opt = _train_opt(tmp_path)
+    m = create_model(opt)
+    m.netG.module.load_state_dict(reference_state_dict(0), strict=True)
+    frames = synthetic_frames(21, 1, 64, 96, 6)
+    with torch.no_grad():
+        direct = m.netG.module.eval()(*[f.cuda() for f in frames])
+        m.netG.train()
+    m.test_set_input((*frames, 3))
+    assert (m.batch, m.channel, m.height, m.width) == (1, 3, 64, 96) and m.B7.is_cuda
+    out = m.test()
+    assert len(out) == 14 and m.Ft_p is out
+    for a, b in zip(out, direct):
+        assert torch.equal(a, b)
+    with torch.no_grad():
+        m.netG.eval()
+        m.test_forward()                                           # the reference calls it inside its own no_grad/eval
+        m.netG.train()
+    for a, b in zip(m.Ft_p, direct):
+        assert torch.equal(a, b)
+    # ---- VideoBaseModel over the same generator
+    v = VideoBaseModel(opt, netG=m.netG.module)
+    lq = torch.stack(frames, dim=1)                                # [B, 6, C, H, W]
+    v.feed_data({"LQs": lq}, need_GT=False)
+    v.test()
+    assert tuple(v.fake_H.shape) == (1, 14, 3, 64, 96)
+    for k in range(14):
+        assert torch.equal(v.fake_H[:, k], direct[k])
+    # test_stitch geometry, checked exactly: every tile's interior is the network run on that tile's replicate-padded
+    # (tile + halo) crop.  One tile covering the frame, then 2 x 2 tiles of 32 x 48.
+    import torch.nn.functional as F
+    net = m.netG.module.eval()
+    flat = F.pad(lq.reshape(6, 3, 64, 96), (16, 16, 16, 16), mode="replicate").cuda()
+    with torch.no_grad():
+        whole = net(*[flat[i:i + 1] for i in range(6)])
+        v.test_stitch(tile_hw=(64, 96), halo=16)
+        assert tuple(v.fake_H.shape) == (1, 14, 3, 64, 96)
+        for k in range(14):
+            assert torch.equal(v.fake_H[:, k], whole[k][..., 16:80, 16:112])
+        v.test_stitch(tile_hw=(32, 48), halo=16)
+        assert tuple(v.fake_H.shape) == (1, 14, 3, 64, 96) and torch.isfinite(v.fake_H).all()
+        j, i = 1, 1                                                # bottom-right tile: rows 32..63, columns 48..95
+        crop = flat[..., j * 32:(j + 1) * 32 + 32, i * 48:(i + 1) * 48 + 32].contiguous()
+        tile = net(*[crop[q:q + 1] for q in range(6)])
+        for k in range(14):
+            assert torch.equal(v.fake_H[:, k, :, 32:64, 48:96], tile[k][..., 16:48, 16:64])
+    m.netG.train()
+
+
+# ------------------------------------------------------------------------------------------------ fp16 storage range
+@pytest.mark.parametrize("prec", ["f16x3", "f16"])
+def test_fp16_saturation_is_detected_not_silent(prec):
+    """The reference computes in fp32; here values between layers are fp16 hi(+lo) planes (|v| <= 65504).  Frames x64
+    and weights x8 drive activations past that: the kernels must saturate (no inf/NaN poisoning), raise the status
+    word, and the host check must turn it into a RuntimeError — never a silently wrong image.  A moderate scale-up
+    that stays in range must still match the oracle."""
+    from bin_amd import ops
+    from bin_amd.models.archs.RDN import bin_stage4_lstm
+    from bin_amd.weights import reference_state_dict, synthetic_frames
+    ops.check_status()                                             # clear anything left by earlier tests
+    net = bin_stage4_lstm()
+    sd = reference_state_dict(0)
+    net.load_state_dict({k: (v * 8 if k.endswith("weight") and "clstm" not in k else v) for k, v in sd.items()}, strict=True)
+    net = net.cuda().eval().set_precision(prec)
+    frames = [f.cuda() * 64 for f in synthetic_frames(5, 1, 32, 32, 6)]
+    with torch.no_grad():
+        out = net(*frames)
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(o).all() for o in out), "saturation must not produce inf/NaN"
+    with pytest.raises(RuntimeError, match="fp16 range exceeded"):
+        ops.check_status()
+    ops.check_status()                                             # the word was reset by the failing check
+
+
+@pytest.mark.parametrize("prec,tol", [("f16x3", 2e-5), ("f16", 1e-3)])
+def test_large_and_tiny_magnitudes_inside_the_range(prec, tol, canon_cpu):
+    """In-range stress: frames in [0, 8] (64x the usual energy through the 5x5 input conv) and frames of magnitude 1e-3
+    (activations deep in the fp16 subnormal range for single-plane storage): relative error vs the oracle stays at the
+    mode's usual level, and the status word stays clear."""
+    from bin_amd import ops
+    from bin_amd.models.archs.RDN import bin_stage4_lstm
+    from bin_amd.weights import reference_state_dict, synthetic_frames
+    from oracle import rdn_oracle as O
+    ops.check_status()
+    net = bin_stage4_lstm()
+    net.load_state_dict(reference_state_dict(0), strict=True)
+    net = net.cuda().eval().set_precision(prec)
+    for scale in (8.0, 1e-3):
+        frames = [f * scale for f in synthetic_frames(9, 1, 32, 32, 6)]
+        with torch.no_grad():
+            ref = O.bin_stage4_forward(frames, canon_cpu)
+            out = net(*[f.cuda() for f in frames])
+        torch.cuda.synchronize()
+        ops.check_status()
+        mag = max(float(r.abs().max()) for r in ref)
+        err = max(float((o.cpu() - r).abs().max()) for o, r in zip(out, ref))
+        assert err <= tol * max(mag, 1.0), (scale, err, mag)
+
+
+# ------------------------------------------------------------------------------------------------ RCCL / threads / ABI
+def test_nccl_world1_flat_allreduce_broadcast_and_barrier(tmp_path):
+    """The RCCL path (backend "nccl") has otherwise only run under gloo: initialise a world-size-1 nccl group on the
+    GPU, build the model with dist=True (bucketed parameter broadcast + flat gradient buffer), run one training step
+    with the gradient all-reduce on its side stream, then barrier.  Results must equal the non-distributed step."""
+    import torch.distributed as dist
+    from bin_amd.models import create_model
+    from bin_amd.weights import reference_state_dict
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29617")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        data = _batch(1, 64, 3)
+        ref = create_model(_train_opt(tmp_path, lr=1e-4))
+        ref.netG.module.load_state_dict(reference_state_dict(0), strict=True)
+        ref.feed_data(data)
+        ref.optimize_parameters(1)
+        m = create_model(_train_opt(tmp_path, lr=1e-4, dist=True))
+        m.netG.module.load_state_dict(reference_state_dict(0), strict=True)
+        m.grad_sync.force_collective = True                        # world size 1: still issue every collective
+        m.broadcast_parameters(force=True)
+        assert len(m.grad_sync._buckets) == 4                      # model1..model4 reduce during backward
+        t = torch.ones(8, device="cuda")
+        dist.all_reduce(t)                                         # RCCL really runs a collective on this GPU
+        assert float(t.sum()) == 8.0
+        m.feed_data(data)
+        m.optimize_parameters(1)
+        dist.barrier()
+        torch.cuda.synchronize()
+        assert float(m.loss) == float(ref.loss)
+        for (k, a), (_, b) in zip(m.netG.module.named_parameters(), ref.netG.module.named_parameters()):
+            assert torch.equal(a, b), k
+    finally:
+        dist.destroy_process_group()
+
+
+def test_concurrent_host_threads_share_the_library():
+    """include/binhip.h: the library holds no mutable process-global state, entry points are re-entrant.  Two host
+    threads run forwards of two independent networks on their own streams at the same time; each result equals the
+    serial one bit for bit."""
+    from bin_amd.models.archs.RDN import bin_stage4_lstm
+    from bin_amd.weights import reference_state_dict, synthetic_frames
+    nets, frames, serial = [], [], []
+    for i, prec in enumerate(("f16x3", "f16")):
+        net = bin_stage4_lstm()
+        net.load_state_dict(reference_state_dict(0), strict=True)
+        nets.append(net.cuda().eval().set_precision(prec))
+        frames.append([f.cuda() for f in synthetic_frames(40 + i, 1, 64, 64, 6)])
+    with torch.no_grad():
+        for net, fr in zip(nets, frames):
+            serial.append([o.clone() for o in net(*fr)])
+    torch.cuda.synchronize()
+    results, errors = [None, None], []
+
+    def work(i):
+        try:
+            s = torch.cuda.Stream()
+            with torch.no_grad(), torch.cuda.stream(s):
+                for _ in range(3):
+                    out = nets[i](*frames[i])
+                s.synchronize()
+            results[i] = out
+        except Exception as e:       # surfaced below
+            errors.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors
+    for i in range(2):
+        for a, b in zip(results[i], serial[i]):
+            assert torch.equal(a, b)
