@@ -292,16 +292,17 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    for v in args.variant:                   # side-build switches (never present in the product library)
+        from bin_amd import _lib as _L
+        k, val = v.rsplit("=", 1)
+        if k == "tail":
+            _L.lib().binhip_set_tail_depth(int(val))
+        else:
+            _L.lib().binhip_set_variant(int(k), int(val))
     if args.mode == "train":
         return train_bench(args, rank, world, dev)
 
     from bin_amd import _lib as L
-    for v in args.variant:                   # side-build switches (never present in the product library)
-        k, val = v.split("=")
-        if k == "tail":
-            L.lib().binhip_set_tail_depth(int(val))
-        else:
-            L.lib().binhip_set_variant(int(k), int(val))
     from bin_amd.models.archs.RDN import bin_stage4_lstm
     from bin_amd.utils import util
     from bin_amd.weights import reference_state_dict, synthetic_frames

@@ -317,8 +317,16 @@ struct BinhipProfiler {
 };
 namespace { constexpr size_t PROF_MAX_PAIRS = 16384; }
 
+#if BINHIP_TUNING
+static int g_x3_wide = 1;     // side builds: 0 = round-1 routing of the wide nterms = 3 3x3 layers (generic kernel, 64/96-row blocks)
+#define BH_X3_WIDE g_x3_wide
+#else
+#define BH_X3_WIDE 1
+#endif
+
 int bh_conv_cout_block(int ksize, int cout_pad, int nterms) {
     if (cout_pad <= 0 || cout_pad % 32) return -1;
+    if (ksize == 3 && nterms == 3 && BH_X3_WIDE) return 32;  // every fp32-class 3x3 conv: plane-split kernel, 32-row columns
     if (cout_pad == 256) return nterms == 3 ? 64 : 128;     // UPNet.0 (PixelShuffle epilogue)
     if (ksize == 5) return 32;
     if (ksize == 1 && cout_pad == 224) return 224;            // LFF backward-data: all 224 rows in one workgroup column
@@ -441,10 +449,10 @@ static int bh_dispatch_conv(const ConvKArgs& a0, int k, int cp, int nt, int e, h
         }
         if (e == P && k == 5 && cb == 32)  return launch_cfg<5, 1, 1, 2, 8, 1, 1, 2, P>(a, cp, s);   // 8 waves, 16x32 tile
     } else {
-        if ((e == F && k == 3 && cp == 32) || (e == P && k == 3 && cb == 32)) {
+        if (k == 3 && cb == 32) {
 #if BINHIP_TUNING
             // the generic both-planes-per-stage kernel (117 KB LDS, 157 VGPRs, 1 workgroup/CU): round-1 default
-            if (BH_VARIANT(e == F ? CLS_FINAL : CLS_K3C32) == 1)
+            if (BH_VARIANT(e == F ? CLS_FINAL : CLS_K3C32) == 1 && e != S)
                 return e == F ? launch_cfg<3, 1, 1, 2, 8, 1, 3, 2, F>(a, cp, s) : launch_cfg<3, 1, 1, 2, 8, 1, 3, 2, P>(a, cp, s);
 #endif
             return bh_launch_conv_x3(a, cp, e, s);      // plane-split stages, 2 workgroups/CU (binhip_conv_x3.hip)
@@ -641,6 +649,7 @@ int binhip_set_variant(int layer_class, int variant) {
     if (layer_class == -1) { g_xcd_remap = variant; return 0; }
     if (layer_class == -2) { g_dbg = variant; return 0; }
     if (layer_class == -3) { g_wt = variant; return 0; }
+    if (layer_class == -4) { g_x3_wide = variant; return 0; }     // takes effect for weights relayouted afterwards
     if (layer_class < 0 || layer_class >= 8) return BINHIP_E_ARG;
     g_variant[layer_class] = variant;
     return 0;

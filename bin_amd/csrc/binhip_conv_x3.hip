@@ -199,9 +199,12 @@ static int launch_x3(const ConvKArgs& ka, int cout_pad, hipStream_t s) {
     return 0;
 }
 
-// entry for the dispatcher in binhip_conv.hip: 3x3, 32-row output blocks, nterms = 3
+// entry for the dispatcher in binhip_conv.hip: every 3x3 convolution of the nterms = 3 path, in 32-row output blocks
+// (wider layers — 96 -> 96, UPNet.0's 96 -> 256, the 96-row backward-data convs — run as cout_pad / 32 workgroup
+// columns over the same tiles: the input patch is re-read per column, from L2)
 int bh_launch_conv_x3(const ConvKArgs& a, int cout_pad, int epilogue, hipStream_t s) {
     if (epilogue == BINHIP_EPI_PLANES) return launch_x3<3, 2, 8, BINHIP_EPI_PLANES>(a, cout_pad, s);
+    if (epilogue == BINHIP_EPI_SHUFFLE) return launch_x3<3, 2, 8, BINHIP_EPI_SHUFFLE>(a, cout_pad, s);
     if (epilogue == BINHIP_EPI_FINAL) return launch_x3<3, 2, 8, BINHIP_EPI_FINAL>(a, cout_pad, s);
     return BINHIP_E_SHAPE;
 }

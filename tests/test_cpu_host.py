@@ -38,7 +38,8 @@ def test_library_host_queries():
     from bin_amd import _lib
     lib = _lib.lib()
     assert lib.binhip_conv_cout_block(3, 32, 1) == 32
-    assert lib.binhip_conv_cout_block(3, 256, 1) == 128 and lib.binhip_conv_cout_block(3, 256, 3) == 64
+    assert lib.binhip_conv_cout_block(3, 256, 1) == 128 and lib.binhip_conv_cout_block(3, 256, 3) == 32
+    assert lib.binhip_conv_cout_block(3, 96, 3) == 32 and lib.binhip_conv_cout_block(3, 96, 1) == 96
     assert lib.binhip_weights_bytes(32, 6, 3) == 32 * 6 * 9 * 32
     assert lib.binhip_rdn_workspace_bytes(1, 33, 32, 2, 1) == 0          # odd height rejected
     assert lib.binhip_rdn_workspace_bytes(1, 64, 64, 4, 1) == 0          # 4 inputs do not exist
