@@ -114,7 +114,9 @@ __device__ __forceinline__ void x3_compute(const char* pb, const char* wb, int a
     }
 }
 
-template <int KS, int R, int WN, int EPI>
+// WIDE only names the instantiation: 0 = one 32-row output block (the dense-block convs, UPNet.2), 1 = several workgroup
+// columns — same code, separate symbols, so per-kernel profiles keep the dominant dense-block conv apart from the wide layers
+template <int KS, int R, int WN, int EPI, int WIDE>
 __global__ void __launch_bounds__(64 * WN) __attribute__((amdgpu_waves_per_eu(4, 4)))
 conv_x3_kernel(const ConvKArgs a) {
     using C = X3Cfg<KS, R, WN>;
@@ -185,16 +187,16 @@ conv_x3_kernel(const ConvKArgs a) {
     conv_epilogue<1, R, 3, EPI>(a, acc, img, ty0 + wave * R, tx0, z * 32, z == 0, n, kg, plane_elems);
 }
 
-template <int KS, int R, int WN, int EPI>
+template <int KS, int R, int WN, int EPI, int WIDE>
 static int launch_x3(const ConvKArgs& ka, int cout_pad, hipStream_t s) {
     using C = X3Cfg<KS, R, WN>;
     static std::atomic<unsigned long long> lds_set{0};
-    if (int rc = bh_set_max_lds(&conv_x3_kernel<KS, R, WN, EPI>, C::LDS_BYTES, lds_set)) return rc;
+    if (int rc = bh_set_max_lds(&conv_x3_kernel<KS, R, WN, EPI, WIDE>, C::LDS_BYTES, lds_set)) return rc;
     ConvKArgs a = ka;
     a.tiles_x = (a.W + 31) / 32;
     a.tiles_y = (a.H + C::TH - 1) / C::TH;
     dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N), (unsigned)(cout_pad / 32));
-    conv_x3_kernel<KS, R, WN, EPI><<<grid, dim3(64 * C::NW), C::LDS_BYTES, s>>>(a);
+    conv_x3_kernel<KS, R, WN, EPI, WIDE><<<grid, dim3(64 * C::NW), C::LDS_BYTES, s>>>(a);
     BH_CHECK_LAUNCH();
     return 0;
 }
@@ -203,8 +205,10 @@ static int launch_x3(const ConvKArgs& ka, int cout_pad, hipStream_t s) {
 // (wider layers — 96 -> 96, UPNet.0's 96 -> 256, the 96-row backward-data convs — run as cout_pad / 32 workgroup
 // columns over the same tiles: the input patch is re-read per column, from L2)
 int bh_launch_conv_x3(const ConvKArgs& a, int cout_pad, int epilogue, hipStream_t s) {
-    if (epilogue == BINHIP_EPI_PLANES) return launch_x3<3, 2, 8, BINHIP_EPI_PLANES>(a, cout_pad, s);
-    if (epilogue == BINHIP_EPI_SHUFFLE) return launch_x3<3, 2, 8, BINHIP_EPI_SHUFFLE>(a, cout_pad, s);
-    if (epilogue == BINHIP_EPI_FINAL) return launch_x3<3, 2, 8, BINHIP_EPI_FINAL>(a, cout_pad, s);
+    if (epilogue == BINHIP_EPI_PLANES)
+        return cout_pad == 32 ? launch_x3<3, 2, 8, BINHIP_EPI_PLANES, 0>(a, cout_pad, s)
+                              : launch_x3<3, 2, 8, BINHIP_EPI_PLANES, 1>(a, cout_pad, s);
+    if (epilogue == BINHIP_EPI_SHUFFLE) return launch_x3<3, 2, 8, BINHIP_EPI_SHUFFLE, 1>(a, cout_pad, s);
+    if (epilogue == BINHIP_EPI_FINAL) return launch_x3<3, 2, 8, BINHIP_EPI_FINAL, 0>(a, cout_pad, s);
     return BINHIP_E_SHAPE;
 }
