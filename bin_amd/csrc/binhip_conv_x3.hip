@@ -18,6 +18,8 @@
 // 74.9 ms with this one.  A 16-wave / 32x32-tile variant (one workgroup per CU whose halves share one weight slab, 3-deep
 // patch ring with counted vmcnt = prefetch distance of two sub-stages) was built and measured at 76.4 ms: the DMA
 // prefetch distance is not what limits the loop, and a 1024-thread workgroup loses the phase drift.  Not kept.
+// Neither was a 4-wave / 8x32-tile variant for grids that give each CU only one 16x32 workgroup (training crops,
+// 8 x 128x128 = 256 tiles): training step 176.0 vs 173.1 ms, 720p window 76.0 vs 72.2 ms (twice the weight DMA per pixel).
 #include "binhip_conv_common.h"
 
 template <int KS, int R, int WN>
