@@ -33,7 +33,7 @@ class BinRdnBwdPlan(C.Structure):
                 ("wt_hi", C.c_void_p * RDN_LAYERS), ("wt_lo", C.c_void_p * RDN_LAYERS),
                 ("zero_bias", C.c_void_p),
                 ("dw", C.c_void_p * RDN_LAYERS), ("db", C.c_void_p * RDN_LAYERS), ("gin", C.c_void_p * 5),
-                ("status", C.c_void_p)]
+                ("status", C.c_void_p), ("aux_stream", C.c_void_p)]
 
 
 _SIGNATURES = {

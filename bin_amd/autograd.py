@@ -27,6 +27,20 @@ from .rdn_plan import layer_names, rdn_forward, workspace
 # only through the regular path.
 DIRECT_PARAM_GRADS = False
 
+# Weight gradients on a side stream, overlapping the backward-data chain (BinRdnBwdPlan.aux_stream; one side stream per
+# device, the library orders and joins it with events inside each call).  BIN_AMD_WGRAD_STREAM=0 turns it off.
+WGRAD_SIDE_STREAM = os.environ.get("BIN_AMD_WGRAD_STREAM", "1") != "0"
+_aux_streams = {}
+
+
+def _aux_stream(device):
+    s = _aux_streams.get(device.index)
+    if s is None:
+        s = torch.cuda.Stream(device=device)
+        _aux_streams[device.index] = s
+    return s
+
+
 # "f16": with an f16x3 (fp32-class) forward, run the RDN backward single-product on the hi planes of the saved
 # activations (BINHIP_BWD_SAVED_X3) — loss and ReLU masks stay exact, gradients carry ~1e-3 relative rounding noise,
 # the step is ~1.4x faster.  Set from network_G.backward_precision / BIN_AMD_BACKWARD_PRECISION; None = same as forward.
@@ -78,6 +92,8 @@ class _RdnFn(torch.autograd.Function):
             plan.reserved = L.BWD_SAVED_X3
         dgw.fill_plan(plan)
         plan.status = status_word(dev).data_ptr()
+        plan.aux_stream = (_aux_stream(dev).cuda_stream
+                           if WGRAD_SIDE_STREAM and not torch.cuda.is_current_stream_capturing() else None)
         params = ctx.params
         direct = DIRECT_PARAM_GRADS and all(ctx.needs_input_grad[3 + k:])
         have = False

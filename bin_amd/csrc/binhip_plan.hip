@@ -147,7 +147,7 @@ namespace {
 struct Bws {
     int64_t P, PF;
     int kc0, gx0_chunks;
-    int64_t gout, gu, guu, gg1, gg0, gf1, gy, gcat, gx0, total_halfs;
+    int64_t gout, gu, guu, gg1, gg0, gf1, gy, gcat, gcat2, gx0, total_halfs;
     int64_t s_gout, s_gu, s_guu, s_g, s_gy, s_gcat, s_gx0;
     size_t wg_bytes, sc_off_bytes, wg_off_bytes, total_bytes;
 };
@@ -171,6 +171,8 @@ Bws make_bws(int N, int H, int W, int nin, int nt) {
     b.gf1 = o; o += mul * b.s_g;
     b.gy = o; o += mul * b.s_gy;
     b.gcat = o; o += mul * b.s_gcat;
+    b.gcat2 = o; o += mul * b.s_gcat;      // dense blocks alternate between the two: block d's weight gradients (side
+                                           // stream) still read one while block d-1's backward-data fills the other
     b.gx0 = o; o += mul * b.s_gx0;
     b.total_halfs = o;
     // weight-gradient partial workspace: max over the layer shapes
@@ -220,6 +222,25 @@ int binhip_rdn_backward(const BinRdnBwdPlan* p, const void* saved, size_t saved_
         if (!p->wt_hi[i] || (nt == 3 && !p->wt_lo[i]) || !p->dw[i] || !p->db[i]) return BINHIP_E_ARG;
 
     hipStream_t s = (hipStream_t)stream;
+    // Optional second stream (plan->aux_stream): the weight-gradient kernels of a layer depend only on that layer's
+    // output gradient and the saved activations, not on the backward-data chain that continues behind it, so they run
+    // on the side stream and overlap the chain (both kernel families are latency-bound at training sizes and fit a CU
+    // together).  Ordering is by events created, recorded, waited on and destroyed inside this call (no state is kept):
+    //   fork  — side stream waits for everything the main stream has queued so far (the gradient a wgrad reads);
+    //   b_done[d] — main stream waits, before it overwrites a gradient-concat buffer, for the side-stream weight
+    //   gradients of the block that read it two blocks earlier; the main stream joins the side stream before returning.
+    hipStream_t sb = p->aux_stream ? (hipStream_t)p->aux_stream : s;
+    const bool two = (sb != s);
+    auto order = [&](hipStream_t from, hipStream_t to) -> int {      // `to` waits for `from`'s queue up to here
+        if (!two) return 0;
+        hipEvent_t e;
+        hipError_t r = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        if (r != hipSuccess) return (int)r;
+        r = hipEventRecord(e, from);
+        if (r == hipSuccess) r = hipStreamWaitEvent(to, e, 0);
+        (void)hipEventDestroy(e);                                    // released once the recorded work completes
+        return r == hipSuccess ? 0 : (int)r;
+    };
     const Ws w = make_ws(N, H, W, nin, nt_saved);
     const int h = H / 2, ww = W / 2;
     const int64_t P = w.P;
@@ -248,8 +269,9 @@ int binhip_rdn_backward(const BinRdnBwdPlan* p, const void* saved, size_t saved_
         d.N = N; d.H = Hc; d.W = Wc; d.ksize = ks; d.cin_chunks = cin_chunks; d.cout = cout; d.cout_pad = 0;
         d.nterms = nt; d.epilogue = 0; d.relu = 0; d.x_cpg = cpg; d.x_group_stride = gstride; d.n_images = 0; d.reserved = 0;
         d.status = p->status;
+        if (int rf = order(s, sb)) return rf;                        // its gY (and the scale) are queued on the main stream
         return binhip_conv2d_bwd_weight(&d, SH(x_off), SL(x_off, x_size), GH(g_off), GL(g_off, g_size), inv, wgws,
-                                        b.wg_bytes, p->dw[layer], p->db[layer], cin, shuffle, accumulate, stream);
+                                        b.wg_bytes, p->dw[layer], p->db[layer], cin, shuffle, accumulate, (void*)sb);
     };
     // data gradient through forward layer `layer`: conv with the transposed/flipped weights
     auto dgrad = [&](int layer, int ks, int Hc, int Wc, int gin_chunks, int gout_ch, int64_t g_off, int64_t g_size,
@@ -287,30 +309,49 @@ int binhip_rdn_backward(const BinRdnBwdPlan* p, const void* saved, size_t saved_
     if ((rc = wgrad(62, 1, h, ww, 72, 1152, 96, w.blk + 14 * P, w.s_blk, 6, 14 * P, b.gg0, b.s_g, 0))) return rc;
     if ((rc = dgrad(62, 1, h, ww, 6, 1152, b.gg0, b.s_g, b.gy + 6 * P, b.s_gy, -1, 0, 0, false, -1, 0, 6, 6 * P))) return rc;
     // ---- the 12 residual dense blocks, last to first
+    hipEvent_t b_done[12] = {};
     for (int d = 11; d >= 0; --d) {
         const int64_t blk = w.blk + (int64_t)d * 14 * P;      // saved forward buffer of RDB d
         const int64_t gy = b.gy + (int64_t)(d + 1) * 6 * P;   // grad of RDB d's output
+        const int64_t gcat = (d & 1) ? b.gcat2 : b.gcat;      // this block's gradient-concat buffer
         const int L = 2 + 5 * d;
         // LFF 1x1 224 -> 96 (+x): gcat = W'^T gy (+ gy on the first 6 chunks); ReLU mask of conv 3's output
         if ((rc = wgrad(L + 4, 1, h, ww, 14, 224, 96, blk, w.s_blk, 0, 0, gy, b.s_gy, 0))) return rc;
-        if ((rc = dgrad(L + 4, 1, h, ww, 6, 224, gy, b.s_gy, b.gcat, b.s_gcat, gy, b.s_gy, 6, false, blk, 12, 0, 0))) return rc;
+        // block d+2 used this gcat buffer: its weight gradients (side stream) must have read it before it is refilled.
+        // Everything queued on the side stream up to here is older than block d+1's wgrads, so a plain join suffices
+        // only every other block would over-serialise; the side stream is in order, so "block d+2 done" = an event
+        // recorded there right after block d+2's last wgrad.
+        if (two && d + 2 <= 11 && b_done[d + 2]) {
+            hipError_t r = hipStreamWaitEvent(s, b_done[d + 2], 0);
+            (void)hipEventDestroy(b_done[d + 2]);
+            b_done[d + 2] = nullptr;
+            if (r != hipSuccess) return (int)r;
+        }
+        if ((rc = dgrad(L + 4, 1, h, ww, 6, 224, gy, b.s_gy, gcat, b.s_gcat, gy, b.s_gy, 6, false, blk, 12, 0, 0))) return rc;
         // The four 3x3 convs in gather form (binhip_weights_relayout_rdb_gather): every group of gcat is produced
         // ONCE as L_g + conv(stacked G_c of the later convs) instead of being read-modified-written by each of them.
         for (int c = 3; c >= 0; --c) {
-            const int64_t gyc = b.gcat + (int64_t)(6 + 2 * c) * P;       // G_c .. G_3, contiguous chunks
+            const int64_t gyc = gcat + (int64_t)(6 + 2 * c) * P;       // G_c .. G_3, contiguous chunks
             if ((rc = wgrad(L + c, 3, h, ww, 6 + 2 * c, 96 + 32 * c, 32, blk, w.s_blk, 0, 0, gyc, b.s_gcat, 0))) return rc;
             if (c > 0) {
                 // group c = conv c-1's output slot (chunks 4+2c, 5+2c): G_{c-1} = relu'( L_c + sum_{c' >= c} dgrad_c' )
-                const int64_t slot = b.gcat + (int64_t)(4 + 2 * c) * P;
+                const int64_t slot = gcat + (int64_t)(4 + 2 * c) * P;
                 if ((rc = dgrad(L + c, 3, h, ww, 2 * (4 - c), 32, gyc, b.s_gcat, slot, b.s_gcat, slot, b.s_gcat, 0, false,
                                 blk + (int64_t)(4 + 2 * c) * P, 0, 0, 0))) return rc;
             } else {
                 // group 0: L_0 + all four convs -> grad of the block input = GY[d] (already holds GFF.0's share when d >= 1)
-                if ((rc = dgrad(L, 3, h, ww, 8, 96, gyc, b.s_gcat, b.gy + (int64_t)d * 6 * P, b.s_gy, b.gcat, b.s_gcat, 0,
+                if ((rc = dgrad(L, 3, h, ww, 8, 96, gyc, b.s_gcat, b.gy + (int64_t)d * 6 * P, b.s_gy, gcat, b.s_gcat, 0,
                                 d >= 1, -1, 0, 0, 0))) return rc;
             }
         }
+        if (two) {
+            hipError_t r = hipEventCreateWithFlags(&b_done[d], hipEventDisableTiming);
+            if (r == hipSuccess) r = hipEventRecord(b_done[d], sb);
+            if (r != hipSuccess) return (int)r;
+        }
     }
+    for (int d = 0; d < 12; ++d)
+        if (b_done[d]) { (void)hipEventDestroy(b_done[d]); b_done[d] = nullptr; }
     // ---- SFENet2: X = F1; gF1 = dgrad + gG1 (the `x += f__1` skip)
     if ((rc = wgrad(1, 3, h, ww, 6, 96, 96, w.f1, w.s_f1, 0, 0, b.gy, b.s_gy, 0))) return rc;
     if ((rc = dgrad(1, 3, h, ww, 6, 96, b.gy, b.s_gy, b.gf1, b.s_g, b.gg1, b.s_g, 0, false, -1, 0, 0, 0))) return rc;
@@ -322,7 +363,8 @@ int binhip_rdn_backward(const BinRdnBwdPlan* p, const void* saved, size_t saved_
         if ((rc = dgrad(0, 5, h, ww, 6, 12 * nin, b.gf1, b.s_g, b.gx0, b.s_gx0, -1, 0, 0, false, -1, 0, 0, 0))) return rc;
         if ((rc = binhip_unpack_input_grads(GH(b.gx0), GL(b.gx0, b.s_gx0), gout, sc, nin, N, H, W, p->gin, stream))) return rc;
     }
-    return 0;
+    // the caller reuses `workspace` / frees `saved` in main-stream order: join the side stream before returning
+    return order(sb, s);
 }
 
 }  // extern "C"

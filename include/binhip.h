@@ -254,6 +254,9 @@ typedef struct BinRdnBwdPlan {
     float* db[BINHIP_RDN_LAYERS];
     float* gin[5];
     void* status;                           /* device uint32 status word (BINHIP_STATUS_*) or NULL     */
+    void* aux_stream;                       /* optional second hipStream_t: the weight-gradient kernels run on it,  */
+                                            /* overlapping the backward-data chain (event-ordered inside the call;  */
+                                            /* joined into `stream` before return).  NULL: everything on `stream`   */
 } BinRdnBwdPlan;
 size_t binhip_rdn_backward_workspace_bytes(int N, int H, int W, int n_inputs, int nterms);
 int binhip_rdn_backward(const BinRdnBwdPlan* plan, const void* saved, size_t saved_bytes,
