@@ -63,6 +63,21 @@ struct BhConvCall {
     BinhipProfiler* prof = nullptr;                  // optional live-timing handle (binhip_profiler_create)
 };
 int bh_launch_conv(const BhConvCall& c, hipStream_t s);
+
+// weight gradients in two phases, so a plan can reduce several layers' partials with one launch
+#define BH_WGRAD_BATCH 8
+struct BhWgradReduce {
+    const float* partial;
+    const float* partial_b;
+    float* dw;
+    float* db;
+    long long nrows;
+    int PB, ncp, ncot, ks, tr, cout, cin, shuffle;
+};
+int bh_wgrad_partials(const BinConvDesc* d, const void* x_hi, const void* x_lo, const void* gy_hi, const void* gy_lo,
+                      void* workspace, size_t workspace_bytes, float* dw_oihw, float* dbias, int cin, int shuffle_perm,
+                      BhWgradReduce* out, void* stream);
+int bh_wgrad_reduce_batch(const BhWgradReduce* items, int n, const float* inv_scale, int accumulate, void* stream);
 int bh_conv_cout_block(int ksize, int cout_pad, int nterms);
 
 // per-device one-time hipFuncSetAttribute(MaxDynamicSharedMemorySize): the attribute is per device, so the cache is a

@@ -188,7 +188,7 @@ Bws make_bws(int N, int H, int W, int nin, int nt) {
     b.wg_bytes = wg;
     size_t bytes = ((size_t)b.total_halfs * 2 + 255) & ~(size_t)255;
     b.sc_off_bytes = bytes; bytes += 8192;                       // scale[2] + 1024 amax partials (+pad)
-    b.wg_off_bytes = bytes; bytes += wg;
+    b.wg_off_bytes = bytes; bytes += 5 * wg;                     // one partial region per layer of a dense block (batched reduce)
     b.total_bytes = bytes + 256;
     return b;
 }
@@ -262,16 +262,29 @@ int binhip_rdn_backward(const BinRdnBwdPlan* p, const void* saved, size_t saved_
     if ((rc = binhip_grad_scale(gout, (int64_t)N * 3 * H * W, 16.f, amax_part, sc, stream))) return rc;
     if ((rc = binhip_nchw_to_planes_scaled(gout, N, 3, H, W, sc, GH(b.gout), GL(b.gout, b.s_gout), p->status, stream))) return rc;
 
-    // weight gradient of forward layer `layer`: X = saved activations, gY = gradient planes
+    // weight gradient of forward layer `layer`: X = saved activations, gY = gradient planes.  slot < 0: reduce at once;
+    // slot 0..4: keep the partials in region `slot` and queue the reduction for flush_reduces() (one launch per dense block)
+    BhWgradReduce pending[BH_WGRAD_BATCH];
+    int npending = 0;
     auto wgrad = [&](int layer, int ks, int Hc, int Wc, int cin_chunks, int cin, int cout, int64_t x_off, int64_t x_size,
-                     int cpg, int64_t gstride, int64_t g_off, int64_t g_size, int shuffle) -> int {
+                     int cpg, int64_t gstride, int64_t g_off, int64_t g_size, int shuffle, int slot = -1) -> int {
         BinConvDesc d;
         d.N = N; d.H = Hc; d.W = Wc; d.ksize = ks; d.cin_chunks = cin_chunks; d.cout = cout; d.cout_pad = 0;
         d.nterms = nt; d.epilogue = 0; d.relu = 0; d.x_cpg = cpg; d.x_group_stride = gstride; d.n_images = 0; d.reserved = 0;
         d.status = p->status;
         if (int rf = order(s, sb)) return rf;                        // its gY (and the scale) are queued on the main stream
-        return binhip_conv2d_bwd_weight(&d, SH(x_off), SL(x_off, x_size), GH(g_off), GL(g_off, g_size), inv, wgws,
-                                        b.wg_bytes, p->dw[layer], p->db[layer], cin, shuffle, accumulate, (void*)sb);
+        BhWgradReduce r;
+        char* region = (char*)wgws + (size_t)(slot < 0 ? 0 : slot) * b.wg_bytes;
+        if (int rw = bh_wgrad_partials(&d, SH(x_off), SL(x_off, x_size), GH(g_off), GL(g_off, g_size), region, b.wg_bytes,
+                                       p->dw[layer], p->db[layer], cin, shuffle, &r, (void*)sb)) return rw;
+        if (slot < 0) return bh_wgrad_reduce_batch(&r, 1, inv, accumulate, (void*)sb);
+        pending[npending++] = r;
+        return 0;
+    };
+    auto flush_reduces = [&]() -> int {
+        const int rr = bh_wgrad_reduce_batch(pending, npending, inv, accumulate, (void*)sb);
+        npending = 0;
+        return rr;
     };
     // data gradient through forward layer `layer`: conv with the transposed/flipped weights
     auto dgrad = [&](int layer, int ks, int Hc, int Wc, int gin_chunks, int gout_ch, int64_t g_off, int64_t g_size,
@@ -316,7 +329,7 @@ int binhip_rdn_backward(const BinRdnBwdPlan* p, const void* saved, size_t saved_
         const int64_t gcat = (d & 1) ? b.gcat2 : b.gcat;      // this block's gradient-concat buffer
         const int L = 2 + 5 * d;
         // LFF 1x1 224 -> 96 (+x): gcat = W'^T gy (+ gy on the first 6 chunks); ReLU mask of conv 3's output
-        if ((rc = wgrad(L + 4, 1, h, ww, 14, 224, 96, blk, w.s_blk, 0, 0, gy, b.s_gy, 0))) return rc;
+        if ((rc = wgrad(L + 4, 1, h, ww, 14, 224, 96, blk, w.s_blk, 0, 0, gy, b.s_gy, 0, 4))) return rc;
         // block d+2 used this gcat buffer: its weight gradients (side stream) must have read it before it is refilled.
         // Everything queued on the side stream up to here is older than block d+1's wgrads, so a plain join suffices
         // only every other block would over-serialise; the side stream is in order, so "block d+2 done" = an event
@@ -332,7 +345,7 @@ int binhip_rdn_backward(const BinRdnBwdPlan* p, const void* saved, size_t saved_
         // ONCE as L_g + conv(stacked G_c of the later convs) instead of being read-modified-written by each of them.
         for (int c = 3; c >= 0; --c) {
             const int64_t gyc = gcat + (int64_t)(6 + 2 * c) * P;       // G_c .. G_3, contiguous chunks
-            if ((rc = wgrad(L + c, 3, h, ww, 6 + 2 * c, 96 + 32 * c, 32, blk, w.s_blk, 0, 0, gyc, b.s_gcat, 0))) return rc;
+            if ((rc = wgrad(L + c, 3, h, ww, 6 + 2 * c, 96 + 32 * c, 32, blk, w.s_blk, 0, 0, gyc, b.s_gcat, 0, c))) return rc;
             if (c > 0) {
                 // group c = conv c-1's output slot (chunks 4+2c, 5+2c): G_{c-1} = relu'( L_c + sum_{c' >= c} dgrad_c' )
                 const int64_t slot = gcat + (int64_t)(4 + 2 * c) * P;
@@ -344,6 +357,7 @@ int binhip_rdn_backward(const BinRdnBwdPlan* p, const void* saved, size_t saved_
                                 d >= 1, -1, 0, 0, 0))) return rc;
             }
         }
+        if ((rc = flush_reduces())) return rc;                       // the block's five layers in one reduce launch
         if (two) {
             hipError_t r = hipEventCreateWithFlags(&b_done[d], hipEventDisableTiming);
             if (r == hipSuccess) r = hipEventRecord(b_done[d], sb);

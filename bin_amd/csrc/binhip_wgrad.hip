@@ -554,18 +554,34 @@ wgrad1x1_kernel(const WgradKArgs a) {
     }
 }
 
-// final deterministic reduction over the PB partials + un-scale + scatter to OIHW.
-// One 256-thread block per (z, cp, tap, m) row of 32 outputs: thread (nn, ps) sums every 8th partial (coalesced 128-B
-// reads), the 8 slices are combined through LDS in a fixed order.  Rows >= nrows handle the bias (one per co tile).
+// final deterministic reduction over the PB partials + un-scale + scatter to OIHW, for a BATCH of layers in one launch
+// (the backward plan reduces the five layers of a dense block together: 1 122 -> 306 reduce launches per training step).
+// One 256-thread block per (z, cp, tap, m) row of 32 outputs of a layer: thread (nn, ps) sums every 8th partial
+// (coalesced 128-B reads), the 8 slices are combined through LDS in a fixed order.  Rows >= nrows of a layer handle
+// its bias (one per co tile).  Summation order per output is independent of the batching.
+struct ReduceBatch {
+    BhWgradReduce it[BH_WGRAD_BATCH];
+    long long row_start[BH_WGRAD_BATCH + 1];
+    int n;
+};
+
 __global__ void __launch_bounds__(256)
-wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ partial_b, int PB, int ncp, int ncot,
-                    int ks, int tr, int cout, int cin, const float* __restrict__ inv_scale, float* __restrict__ dw,
-                    float* __restrict__ db, int accumulate, int shuffle, long long nrows) {
+wgrad_reduce_kernel(const ReduceBatch rb, const float* __restrict__ inv_scale, int accumulate) {
     __shared__ float sm[8][32];
+    long long row = blockIdx.x;
+    int li = 0;
+#pragma unroll
+    for (int i = 1; i < BH_WGRAD_BATCH; ++i)
+        if (i < rb.n && row >= rb.row_start[i]) li = i;
+    const BhWgradReduce& L = rb.it[li];
+    row -= rb.row_start[li];
+    const float* __restrict__ partial = L.partial;
+    const float* __restrict__ partial_b = L.partial_b;
+    const int PB = L.PB, ncp = L.ncp, ncot = L.ncot, ks = L.ks, tr = L.tr, cout = L.cout, cin = L.cin;
+    const long long nrows = L.nrows;
     const int ntap_blk = tr * ks;
     const int nn = threadIdx.x & 31, ps = threadIdx.x >> 5;
     const float is = inv_scale ? inv_scale[0] : 1.f;
-    const long long row = blockIdx.x;
     float s = 0.f;
     int co, ci = 0, dy = 0, dx = 0;
     bool is_bias = row >= nrows;
@@ -591,13 +607,13 @@ wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__
     const float tot = ((sm[0][nn] + sm[1][nn]) + (sm[2][nn] + sm[3][nn])) + ((sm[4][nn] + sm[5][nn]) + (sm[6][nn] + sm[7][nn]));
     if (co >= cout) return;
     int cr = co;
-    if (shuffle) { const int cq = cout / 4; cr = (co % cq) * 4 + co / cq; }
+    if (L.shuffle) { const int cq = cout / 4; cr = (co % cq) * 4 + co / cq; }
     if (is_bias) {
-        if (db) db[cr] = accumulate ? db[cr] + tot * is : tot * is;
+        if (L.db) L.db[cr] = accumulate ? L.db[cr] + tot * is : tot * is;
         return;
     }
     if (ci >= cin) return;
-    float* o = dw + (((long long)cr * cin + ci) * ks + dy) * ks + dx;
+    float* o = L.dw + (((long long)cr * cin + ci) * ks + dy) * ks + dx;
     *o = accumulate ? *o + tot * is : tot * is;
 }
 
@@ -692,9 +708,13 @@ size_t binhip_wgrad_workspace_bytes(int ksize, int N, int H, int W, int cin_chun
     return (g.partial_floats + g.bias_floats) * sizeof(float) + 256;
 }
 
-int binhip_conv2d_bwd_weight(const BinConvDesc* d, const void* x_hi, const void* x_lo, const void* gy_hi,
-                             const void* gy_lo, const float* inv_scale, void* workspace, size_t workspace_bytes,
-                             float* dw_oihw, float* dbias, int cin, int shuffle_perm, int accumulate, void* stream) {
+}  // extern "C"
+
+// main kernel of one layer's weight gradient: writes the per-block partials into `workspace` and fills `out` for the
+// (batched) reduction
+int bh_wgrad_partials(const BinConvDesc* d, const void* x_hi, const void* x_lo, const void* gy_hi, const void* gy_lo,
+                      void* workspace, size_t workspace_bytes, float* dw_oihw, float* dbias, int cin, int shuffle_perm,
+                      BhWgradReduce* out, void* stream) {
     if (!d || !x_hi || !gy_hi || !workspace || !dw_oihw) return BINHIP_E_ARG;
     if (d->nterms != 1 && d->nterms != 3) return BINHIP_E_ARG;
     if (d->nterms == 3 && (!x_lo || !gy_lo)) return BINHIP_E_ARG;
@@ -745,12 +765,41 @@ int binhip_conv2d_bwd_weight(const BinConvDesc* d, const void* x_hi, const void*
         else rc = launch_wg<5, 1, 3>(a, g, s);
     }
     if (rc) return rc;
-    const long long nrows = (long long)g.ndyg * g.ncot * g.ncp * g.ntap * 32;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(nrows + g.ncot)), dim3(256), 0, s, a.partial,
-                       a.partial_b, g.PB, g.ncp, g.ncot, d->ksize, g.tr, d->cout, cin, inv_scale, dw_oihw, dbias,
-                       accumulate, shuffle_perm, nrows);
+    out->partial = a.partial; out->partial_b = a.partial_b;
+    out->PB = g.PB; out->ncp = g.ncp; out->ncot = g.ncot; out->ks = d->ksize; out->tr = g.tr;
+    out->cout = d->cout; out->cin = cin; out->shuffle = shuffle_perm;
+    out->dw = dw_oihw; out->db = dbias;
+    out->nrows = (long long)g.ndyg * g.ncot * g.ncp * g.ntap * 32;
+    return 0;
+}
+
+int bh_wgrad_reduce_batch(const BhWgradReduce* items, int n, const float* inv_scale, int accumulate, void* stream) {
+    if (n <= 0) return 0;
+    if (n > BH_WGRAD_BATCH) return BINHIP_E_ARG;
+    ReduceBatch rb;
+    long long rows = 0;
+    for (int i = 0; i < n; ++i) {
+        rb.it[i] = items[i];
+        rb.row_start[i] = rows;
+        rows += items[i].nrows + items[i].ncot;
+    }
+    for (int i = n; i <= BH_WGRAD_BATCH; ++i) rb.row_start[i] = rows;
+    for (int i = n; i < BH_WGRAD_BATCH; ++i) rb.it[i] = items[0];
+    rb.n = n;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, rb, inv_scale, accumulate);
     BH_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" {
+
+int binhip_conv2d_bwd_weight(const BinConvDesc* d, const void* x_hi, const void* x_lo, const void* gy_hi,
+                             const void* gy_lo, const float* inv_scale, void* workspace, size_t workspace_bytes,
+                             float* dw_oihw, float* dbias, int cin, int shuffle_perm, int accumulate, void* stream) {
+    BhWgradReduce r;
+    if (int rc = bh_wgrad_partials(d, x_hi, x_lo, gy_hi, gy_lo, workspace, workspace_bytes, dw_oihw, dbias, cin,
+                                   shuffle_perm, &r, stream)) return rc;
+    return bh_wgrad_reduce_batch(&r, 1, inv_scale, accumulate, stream);
 }
 
 }  // extern "C"

@@ -6,8 +6,8 @@ export TMPDIR=/tmp
 cat gpurun_out/r2m_pytest.log
 run() { tag=$1; shift; ( timeout 300 python bench.py --no-cpu-baseline --no-extras "$@" 2>&1 | tail -1 ) > gpurun_out/r2m_$tag.log 2>&1; }
 for rep in 1 2; do
-BIN_AMD_WGRAD_STREAM=0 run train_serial_$rep --mode train --steps 8
-BIN_AMD_WGRAD_STREAM=1 run train_side_$rep --mode train --steps 8
+run train_batched_$rep --mode train --steps 8
+
 done
 python - <<'PY'
 import json, glob
