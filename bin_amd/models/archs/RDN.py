@@ -239,6 +239,8 @@ class RDN_residual_interp_5_input_ConvLSTM_L(nn.Module):
         # resident only when nothing else streams beside it: 74.1 vs 76.4 ms per 720p window, same box)
         self.n_streams = int(os.environ["BIN_AMD_STREAMS"]) if os.environ.get("BIN_AMD_STREAMS") else None
         self.batched = os.environ.get("BIN_AMD_BATCHED", "0") != "0"   # batch the shared-weight calls of a stage
+        # training (grad enabled): the whole pyramid as FOUR RDN calls, one per weight set (see _forward_four_calls)
+        self.four_calls = os.environ.get("BIN_AMD_FOUR_CALLS", "1") != "0"
         self._streams = None
 
     def set_precision(self, precision):
@@ -281,6 +283,8 @@ class RDN_residual_interp_5_input_ConvLSTM_L(nn.Module):
             return self._forward_streams((B1, B3, B5, B7, B9, B11), stage1_cache, input_events)
         if stage1_cache is not None or input_events is not None:
             raise RuntimeError("bin_amd: stage1_cache / input_events need the inference schedule (reuse_schedule, no grad)")
+        if self.four_calls and self.reuse_schedule and self.modelType == "lstm":
+            return self._forward_four_calls((B1, B3, B5, B7, B9, B11))
         cells = (self.clstm_4_prime, self.clstm_6_prime, self.clstm_8_prime, self.clstm_5_prime_prime,
                  self.clstm_7_prime_prime, self.clstm_6_prime_prime_prime)
         picks = (1, 2, 3, 5, 6, 8)
@@ -532,6 +536,47 @@ def _forward_batched(self, B, stage1_cache=None):
 
 
 RDN_residual_interp_5_input_ConvLSTM_L._forward_batched = _forward_batched
+
+
+def _forward_four_calls(self, B):
+    """The differentiable schedule: both windows' pyramid as FOUR RDN calls, one per weight set (reference RDN.py:342-363
+    shares model1 between 4, model2 between 3, model3 between 2 calls of a window; :435-459 runs two windows).
+    Window 2 depends on window 1 only through the ConvLSTM hand-offs, and each of those needs nothing deeper than the
+    stage it feeds: h4/h6/h8 <- stage-1 outputs, h5/h7 <- stage 2, h6'' <- stage 3.  So stage s of BOTH windows can run
+    as one batch along N once stage s-1 of both is done:
+        model1  N = 5n : (B1,B3) (B3,B5) (B5,B7) (B7,B9) (B9,B11)             -> I2 I4 I6 I8 I8b   (3 pairs are shared)
+        model2  N = 6n : window 1 (I2,I2,I4) (I4,I4,I6) (I6,I6,I8) ; window 2 (h4,I4,I6) (h6,I6,I8) (h8,I8,I8b)
+        model3  N = 4n : window 1 (I3,B3,I3,I5,B5) (I5,B5,I5,I7,B7) ; window 2 (h5,B5,J3,J5,B7) (h7,B7,J5,J7,B9)
+        model4  N = 2n : window 1 (I4,I4,I4'',I6'',I6) ; window 2 (h6'',I6,J4'',J6'',I8)
+    Per image the kernels compute exactly what the 17 separate calls compute (forward values are bit-identical); the
+    weight gradients are the same sums taken in one reduction per layer instead of up to five.  Launches per training
+    step drop from ~4 400 to ~1 100 and every launch carries 2-6x the tiles, which is what the small training crops
+    (8 x 128x128 half-resolution pixels = one workgroup per CU per launch) were missing."""
+    m = self.model
+    n = B[0].shape[0]
+    B1, B3, B5, B7, B9, B11 = B
+    cat = torch.cat
+    cells = (self.clstm_4_prime, self.clstm_6_prime, self.clstm_8_prime, self.clstm_5_prime_prime,
+             self.clstm_7_prime_prime, self.clstm_6_prime_prime_prime)
+
+    def parts(t, k):
+        return [t[i * n:(i + 1) * n] for i in range(k)]
+
+    I2, I4, I6, I8, I8b = parts(m.model1_1(cat((B1, B3, B5, B7, B9), 0), cat((B3, B5, B7, B9, B11), 0)), 5)
+    h4, h6, h8 = (cells[k](x, None)[0] for k, x in enumerate((I4, I6, I8)))
+    I3, I5, I7, J3, J5, J7 = parts(m.model2_1(cat((I2, I4, I6, h4, h6, h8), 0), cat((I2, I4, I6, I4, I6, I8), 0),
+                                              cat((I4, I6, I8, I6, I8, I8b), 0)), 6)
+    h5, h7 = cells[3](I5, None)[0], cells[4](I7, None)[0]
+    I4pp, I6pp, J4pp, J6pp = parts(m.model3_1(cat((I3, I5, h5, h7), 0), cat((B3, B5, B5, B7), 0), cat((I3, I5, J3, J5), 0),
+                                              cat((I5, I7, J5, J7), 0), cat((B5, B7, B7, B9), 0)), 4)
+    h6pp = cells[5](I6pp, None)[0]
+    I5ppp, J5ppp = parts(m.model4_1(cat((I4, h6pp), 0), cat((I4, I6), 0), cat((I4pp, J4pp), 0), cat((I6pp, J6pp), 0),
+                                    cat((I6, I8), 0)), 2)
+    self.Ft_p_1 = (I6, I8, I8b, None, J3, J5, J7, J4pp, J6pp, J5ppp)
+    return (I2, I4, I6, I8, I3, I5, I7, I4pp, I6pp, I5ppp, I8b, J7, J6pp, J5ppp)
+
+
+RDN_residual_interp_5_input_ConvLSTM_L._forward_four_calls = _forward_four_calls
 
 
 def bin_stage4_lstm():
