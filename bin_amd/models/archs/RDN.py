@@ -241,6 +241,9 @@ class RDN_residual_interp_5_input_ConvLSTM_L(nn.Module):
         self.batched = os.environ.get("BIN_AMD_BATCHED", "0") != "0"   # batch the shared-weight calls of a stage
         # training (grad enabled): the whole pyramid as FOUR RDN calls, one per weight set (see _forward_four_calls)
         self.four_calls = os.environ.get("BIN_AMD_FOUR_CALLS", "1") != "0"
+        # inference: use the four-call schedule too when a launch of the per-call schedule would not fill the chip
+        # (small frames); "1"/"0" force it on / off, default "auto" (see _use_four_calls_infer)
+        self.four_calls_infer = os.environ.get("BIN_AMD_INFER_FOUR", "auto")
         self._streams = None
 
     def set_precision(self, precision):
@@ -274,7 +277,18 @@ class RDN_residual_interp_5_input_ConvLSTM_L(nn.Module):
             return max(1, int(self.n_streams))
         return 1 if (self.precision or default_precision()) == "f16x3" else 3
 
+    def _use_four_calls_infer(self, frame):
+        if self.four_calls_infer in ("0", "1"):
+            return self.four_calls_infer == "1"
+        n, _, h, w = frame.shape
+        tiles = n * ((h // 2 + 15) // 16) * ((w // 2 + 31) // 32)      # 16x32 tiles of one dense-block conv launch
+        return tiles < 256                                             # fewer than one workgroup per CU
+
     def _forward(self, B1, B3, B5, B7, B9, B11, stage1_cache=None, input_events=None):
+        if (self.reuse_schedule and self.modelType == "lstm" and not torch.is_grad_enabled() and stage1_cache is None
+                and input_events is None and getattr(self, "_graph_mode", None) is None
+                and self._use_four_calls_infer(B1)):
+            return self._forward_four_calls((B1, B3, B5, B7, B9, B11))
         if self.reuse_schedule and self.modelType == "lstm" and not (
                 torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or
                                              any(t.requires_grad for t in (B1, B3, B5, B7, B9, B11)))):

@@ -213,7 +213,7 @@ def test_multistream_schedule_is_bit_identical(prec):
     frames = [f.cuda() for f in synthetic_frames(17, 1, 64, 96, 6)]
     net = _net(prec)
     with torch.no_grad():
-        net.n_streams = 1
+        net.n_streams, net.four_calls_infer = 1, "0"
         a = net(*frames)
         for ns, batched in ((2, False), (3, False), (4, False), (3, True)):
             net.n_streams, net.batched = ns, batched
@@ -222,6 +222,15 @@ def test_multistream_schedule_is_bit_identical(prec):
             torch.cuda.synchronize()
             for x, y, z in zip(a, b, b2):
                 assert torch.equal(x, y) and torch.equal(x, z)
+        # the four-call schedule (stage s of both windows as one batch along N; the default for small frames and for
+        # training) returns the same bits as the 17 separate calls
+        net.n_streams, net.batched, net.four_calls_infer = 1, False, "1"
+        c = net(*frames)
+        net.four_calls_infer = "auto"
+        d = net(*frames)                       # 64x96 frames: auto picks the four-call schedule
+        torch.cuda.synchronize()
+        for x, y, z in zip(a, c, d):
+            assert torch.equal(x, y) and torch.equal(x, z)
 
 
 def test_harness_glue_kernels_match_reference_helpers():
