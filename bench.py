@@ -253,8 +253,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the legs reported beside `value` (tolerance mode, streaming, training step)")
     ap.add_argument("--streams", type=int, default=None, help="concurrent RDN calls (HIP streams) in the forward")
-    ap.add_argument("--batched", action="store_true",
-                    help="batch the shared-weight RDN calls of each pyramid stage (N>1 launches) instead of multi-stream")
+    ap.add_argument("--four-calls", action="store_true",
+                    help="A/B: force the four-call schedule (stage s of both windows batched along N; the default only for "
+                         "small frames and training) for the 720p inference window")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--calib", action="store_true",
                     help="also run one 256 MiB device copy (known HBM bytes) to calibrate rocprofv3 FETCH/WRITE_SIZE")
@@ -313,8 +314,8 @@ def main():
     net.reuse_schedule = not args.reference_schedule
     if args.streams is not None:
         net.n_streams = args.streams
-    if args.batched:
-        net.batched = True
+    if args.four_calls:
+        net.four_calls_infer = "1"
 
     pads = util.pad_sizes(H, W)
     frames = [util.replicate_pad(f, pads).to(dev) for f in synthetic_frames(1234 + rank, 1, H, W, 6)]
@@ -346,7 +347,7 @@ def main():
         # overlap — the next window's stage-1 calls start on idle streams while the previous window's lone stage-4 call
         # still runs.  Measured +0.4 % (31.43 vs 31.30 frames/s): every kernel already fills both workgroup slots of
         # every CU, so another stream's kernels only slip into the ramp/drain.  Off by default.
-        kw_in = {"input_events": []} if (net.resolved_streams() > 1 and not net.batched and args.pipeline) else {}
+        kw_in = {"input_events": []} if (net.resolved_streams() > 1 and not args.four_calls and args.pipeline) else {}
         t0 = time.perf_counter()
         for _ in range(args.steps):
             out = net(*frames, **kw_in)
@@ -381,7 +382,7 @@ def main():
         # ---- streaming leg (reported beside `value`, never instead of it): consecutive windows of
         # one clip, sliding by one frame, with the exact stage-1 reuse -> 13 instead of 17 RDN calls per window
         stream_fps = None
-        if extras and net.reuse_schedule and not net.batched:
+        if extras and net.reuse_schedule:
             clip_frames = frames + [f.clone() for f in frames[:4]]      # 10 resident padded frames -> 5 windows
             cache = {}
             net(*clip_frames[0:6], stage1_cache=cache)
@@ -475,7 +476,7 @@ def main():
                        "schedule": "17 RDN calls + 6 ConvLSTM cells (exact reuse)" if net.reuse_schedule
                                    else "20 RDN calls + 12 ConvLSTM cells (reference literal)",
                        "precision": prec, "streams": net.resolved_streams(), "pipelined_steps": bool(kw_in),
-                       "batched_stages": bool(net.batched and net.resolved_streams() > 1),
+                       "four_call_schedule": bool(args.four_calls),
                        "parity": "max-abs <= 2e-5 (f16x3) vs the fp32 reference (tests/)" if prec == "f16x3"
                                  else "max-abs <= 1e-3 (f16) vs the fp32 reference (tests/)"},
             "roofline": roof,

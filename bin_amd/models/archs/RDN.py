@@ -238,7 +238,6 @@ class RDN_residual_interp_5_input_ConvLSTM_L(nn.Module):
         # f16x3: 1 — the chip is power-capped there and one call's 231 MB block buffer stays Infinity-Cache
         # resident only when nothing else streams beside it: 74.1 vs 76.4 ms per 720p window, same box)
         self.n_streams = int(os.environ["BIN_AMD_STREAMS"]) if os.environ.get("BIN_AMD_STREAMS") else None
-        self.batched = os.environ.get("BIN_AMD_BATCHED", "0") != "0"   # batch the shared-weight calls of a stage
         # training (grad enabled): the whole pyramid as FOUR RDN calls, one per weight set (see _forward_four_calls)
         self.four_calls = os.environ.get("BIN_AMD_FOUR_CALLS", "1") != "0"
         # inference: use the four-call schedule too when a launch of the per-call schedule would not fill the chip
@@ -292,8 +291,6 @@ class RDN_residual_interp_5_input_ConvLSTM_L(nn.Module):
         if self.reuse_schedule and self.modelType == "lstm" and not (
                 torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or
                                              any(t.requires_grad for t in (B1, B3, B5, B7, B9, B11)))):
-            if self.batched and self.resolved_streams() > 1:
-                return self._forward_batched((B1, B3, B5, B7, B9, B11), stage1_cache)
             return self._forward_streams((B1, B3, B5, B7, B9, B11), stage1_cache, input_events)
         if stage1_cache is not None or input_events is not None:
             raise RuntimeError("bin_amd: stage1_cache / input_events need the inference schedule (reuse_schedule, no grad)")
@@ -461,95 +458,6 @@ def _forward_streams(self, B, stage1_cache=None, input_events=None):
 
 
 RDN_residual_interp_5_input_ConvLSTM_L._forward_streams = _forward_streams      # (defined below the class for readability)
-
-
-def _forward_batched(self, B, stage1_cache=None):
-    """Inference schedule that BATCHES the calls of a pyramid stage that share weights (reference RDN.py:342-363:
-    model1_1..1_4 are one module, model2_1..2_3 one, model3_1/3_2 one): the five stage-1 calls of both windows
-    become one N=5 launch sequence, stage 2 N=3, stage 3 N=2 — 7 RDN launch sequences per forward instead of 17.
-    Each kernel then covers several images: the fixed per-launch cost (launch boundary, first-stage latency,
-    store drain) is paid 7x67 instead of 17x67 times and the later workgroup rounds overlap the earlier ones'
-    epilogues.  All inputs of a batch are contiguous slices of [frames] / earlier batched outputs, so no copies
-    beyond one cat of the 6 input frames.  Per-image arithmetic is unchanged => bit-identical outputs."""
-    from ...rdn_plan import rdn_forward, workspace
-    from ... import _lib as L
-    dev = B[0].device
-    m = self.model
-    mods = {1: m.model1_1, 2: m.model2_1, 3: m.model3_1, 4: m.model4_1}
-    nterms = {k: PRECISIONS[v.precision or default_precision()] for k, v in mods.items()}
-    kw = {k: v.kernel_weights(nterms[k]) for k, v in mods.items()}
-    n = B[0].shape[0]
-    Ball = torch.cat([t.contiguous().float() for t in B], 0)            # [6n,3,H,W]
-
-    def fr(k0, k1=None):                                                # frames k0..k1-1 as one batch
-        return Ball[k0 * n:(k0 + 1 if k1 is None else k1) * n]
-
-    def rdn(k, *ins):
-        return rdn_forward(kw[k], list(ins), ws=workspace(L.lib().binhip_rdn_workspace_bytes(
-            ins[0].shape[0], ins[0].shape[2], ins[0].shape[3], len(ins), nterms[k]), dev, key="fwd-batched"))
-
-    # ---- stage 1 of both windows: pairs (B1,B3) (B3,B5) (B5,B7) (B7,B9) (B9,B11)
-    if stage1_cache is None:
-        S1 = rdn(1, fr(0, 5), fr(1, 6))                                 # [I2, I4, I6, I8, I8b]
-    else:
-        pairs = [(B[i], B[i + 1]) for i in range(5)]
-        live = {(id(a), id(b)) for a, b in pairs}
-        for key in [key for key in stage1_cache if key not in live]:
-            del stage1_cache[key]
-        outs = []
-        for i, (a, b) in enumerate(pairs):
-            hit = stage1_cache.get((id(a), id(b)))
-            if hit is not None and hit[1] is a and hit[2] is b:
-                outs.append(hit[0])
-            else:
-                o = rdn(1, fr(i), fr(i + 1))
-                stage1_cache[(id(a), id(b))] = (o, a, b)
-                outs.append(o)
-        S1 = torch.cat(outs, 0)
-    I = [S1[i * n:(i + 1) * n] for i in range(5)]                        # I2, I4, I6, I8, I8b
-    cells = (self.clstm_4_prime, self.clstm_6_prime, self.clstm_8_prime, self.clstm_5_prime_prime,
-             self.clstm_7_prime_prime, self.clstm_6_prime_prime_prime)
-    # ---- the two windows' stages 2-4 form two dependency chains (window 2 needs window 1 only through the ConvLSTM
-    # hand-offs h4,h6,h8 <- stage 1, h5,h7 <- stage 2, h6pp <- stage 3), so they run on two streams side by side
-    main = torch.cuda.current_stream(dev)
-    if self._streams is None or len(self._streams) < 1:
-        self._streams = [torch.cuda.Stream(device=dev)]
-    side = self._streams[0]
-    ws_bytes = {k: 0 for k in (2, 3, 4)}
-
-    def rdn_on(stream_key, k, *ins):
-        return rdn_forward(kw[k], list(ins), ws=workspace(L.lib().binhip_rdn_workspace_bytes(
-            ins[0].shape[0], ins[0].shape[2], ins[0].shape[3], len(ins), nterms[k]), dev, key="fwd-batched-" + stream_key))
-
-    ev_s1 = torch.cuda.Event(); ev_s1.record(main)
-    # window 1 chain on the main stream
-    S2 = rdn_on("a", 2, S1[0:3 * n], S1[0:3 * n], S1[n:4 * n])          # [I3, I5, I7]
-    h5, h7 = cells[3](S2[n:2 * n], None)[0], cells[4](S2[2 * n:3 * n], None)[0]
-    ev_h57 = torch.cuda.Event(); ev_h57.record(main)
-    S3 = rdn_on("a", 3, S2[0:2 * n], fr(1, 3), S2[0:2 * n], S2[n:3 * n], fr(2, 4))   # [I4pp, I6pp]
-    h6pp = cells[5](S3[n:2 * n], None)[0]
-    ev_h6pp = torch.cuda.Event(); ev_h6pp.record(main)
-    I5ppp = rdn_on("a", 4, I[1], I[1], S3[0:n], S3[n:2 * n], I[2])
-    # window 2 chain on the side stream
-    side.wait_event(ev_s1)
-    with torch.cuda.stream(side):
-        h4, h6, h8 = (cells[k](I[k + 1], None)[0] for k in range(3))
-        J2 = rdn_on("b", 2, torch.cat((h4, h6, h8), 0), S1[n:4 * n], S1[2 * n:5 * n])   # [J3, J5, J7]
-        side.wait_event(ev_h57)
-        J3 = rdn_on("b", 3, torch.cat((h5, h7), 0), fr(2, 4), J2[0:2 * n], J2[n:3 * n], fr(3, 5))   # [J4pp, J6pp]
-        side.wait_event(ev_h6pp)
-        J5ppp = rdn_on("b", 4, h6pp, I[2], J3[0:n], J3[n:2 * n], I[3])
-    main.wait_stream(side)
-    for t in (S1, S2, S3, h5, h7, h6pp, Ball):
-        t.record_stream(side)
-    for t in (J2, J3, J5ppp, h4, h6, h8):
-        t.record_stream(main)
-    self.Ft_p_1 = (I[2], I[3], I[4], None, J2[0:n], J2[n:2 * n], J2[2 * n:3 * n], J3[0:n], J3[n:2 * n], J5ppp)
-    return (I[0], I[1], I[2], I[3], S2[0:n], S2[n:2 * n], S2[2 * n:3 * n], S3[0:n], S3[n:2 * n], I5ppp,
-            I[4], J2[2 * n:3 * n], J3[n:2 * n], J5ppp)
-
-
-RDN_residual_interp_5_input_ConvLSTM_L._forward_batched = _forward_batched
 
 
 def _forward_four_calls(self, B):

@@ -207,16 +207,16 @@ def test_fused_rdb_tail_equals_unfused(prec, canon_gpu):
 
 @pytest.mark.parametrize("prec", ["f16x3", "f16"])
 def test_multistream_schedule_is_bit_identical(prec):
-    """Running independent RDN calls on separate HIP streams, or batching the shared-weight calls of a stage into
-    one N>1 launch sequence, changes no output bit."""
+    """Running independent RDN calls on separate HIP streams, or batching stage s of both windows into one N>1 call
+    (four-call schedule), changes no output bit."""
     from bin_amd.weights import synthetic_frames
     frames = [f.cuda() for f in synthetic_frames(17, 1, 64, 96, 6)]
     net = _net(prec)
     with torch.no_grad():
         net.n_streams, net.four_calls_infer = 1, "0"
         a = net(*frames)
-        for ns, batched in ((2, False), (3, False), (4, False), (3, True)):
-            net.n_streams, net.batched = ns, batched
+        for ns in (2, 3, 4):
+            net.n_streams = ns
             b = net(*frames)
             b2 = net(*frames)
             torch.cuda.synchronize()
@@ -224,7 +224,7 @@ def test_multistream_schedule_is_bit_identical(prec):
                 assert torch.equal(x, y) and torch.equal(x, z)
         # the four-call schedule (stage s of both windows as one batch along N; the default for small frames and for
         # training) returns the same bits as the 17 separate calls
-        net.n_streams, net.batched, net.four_calls_infer = 1, False, "1"
+        net.n_streams, net.four_calls_infer = 1, "1"
         c = net(*frames)
         net.four_calls_infer = "auto"
         d = net(*frames)                       # 64x96 frames: auto picks the four-call schedule
