@@ -21,6 +21,9 @@
 // Neither was a 4-wave / 8x32-tile variant for grids that give each CU only one 16x32 workgroup (training crops,
 // 8 x 128x128 = 256 tiles): training step 176.0 vs 173.1 ms, 720p window 76.0 vs 72.2 ms (twice the weight DMA per pixel).
 #include "binhip_conv_common.h"
+#ifndef BINHIP_ABLATE
+#define BINHIP_ABLATE 0
+#endif
 
 template <int KS, int R, int WN>
 struct X3Cfg {
@@ -52,7 +55,7 @@ __device__ __forceinline__ void x3_issue_patch(const ConvKArgs& a, char* smem, i
 #pragma unroll
     for (int j = 0; j < C::NPJ; ++j) {
         const int i = wave + C::NW * j;
-        if ((C::PP % C::NW == 0) || (i < C::PP))
+        if (BINHIP_ABLATE != 4 && ((C::PP % C::NW == 0) || (i < C::PP)))
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(lds + i * 1024), 16, voff[j], 0, 0, 0);
     }
 }
@@ -66,7 +69,7 @@ __device__ __forceinline__ void x3_issue_weights(const ConvKArgs& a, char* smem,
 #pragma unroll
     for (int j = 0; j < C::NWJ; ++j) {
         const int i = wave + C::NW * j;                  // piece: 0..WP-1 hi taps, WP..2WP-1 lo taps
-        if (((2 * C::WP) % C::NW == 0) || (i < 2 * C::WP)) {
+        if (BINHIP_ABLATE != 4 && (((2 * C::WP) % C::NW == 0) || (i < 2 * C::WP))) {
             const bool lo = i >= C::WP;
             const int t = lo ? i - C::WP : i;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(lo ? wl : wh, (lds_void_t*)(lds + i * 1024), 16,
@@ -75,7 +78,26 @@ __device__ __forceinline__ void x3_issue_weights(const ConvKArgs& a, char* smem,
     }
 }
 
-__device__ __forceinline__ half8 x3_ld8(const char* p) { return *reinterpret_cast<const half8*>(p); }
+// BINHIP_ABLATE (side builds only, 0 in the product; results are garbage by construction): 1 = no MFMA (fragment loads kept
+// alive), 2 = no LDS fragment loads (MFMA on undefined registers), 4 = no LDS-DMA — used with tools/power_probe.py to split the
+// package power of the kernel into its matrix / LDS / DMA shares
+__device__ __forceinline__ half8 x3_ld8(const char* p) {
+#if BINHIP_ABLATE == 2
+    half8 v;
+    asm volatile("" : "=v"(v));
+    return v;
+#else
+    return *reinterpret_cast<const half8*>(p);
+#endif
+}
+__device__ __forceinline__ floatx16 x3_mfma(half8 a, half8 b, floatx16 c) {
+#if BINHIP_ABLATE == 1
+    asm volatile("" ::"v"(a), "v"(b));
+    return c;
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
+}
 
 // One sub-stage out of LDS.  HI: both weight planes against the hi patch (2 products); !HI: hi weights against the lo
 // patch.  Tap order dx-major: the R+KS-1 patch-row fragments of a tap column are fetched once and serve its KS taps;
@@ -107,11 +129,11 @@ __device__ __forceinline__ void x3_compute(const char* pb, const char* wb, int a
         if constexpr (HI) {
 #pragma unroll
             for (int r = 0; r < R; ++r)
-                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[s & 1], B[dx & 1][r + dy], acc[r], 0, 0, 0);
+                acc[r] = x3_mfma(Al[s & 1], B[dx & 1][r + dy], acc[r]);
         }
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[s & 1], B[dx & 1][r + dy], acc[r], 0, 0, 0);
+            acc[r] = x3_mfma(Ah[s & 1], B[dx & 1][r + dy], acc[r]);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
