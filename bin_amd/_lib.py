@@ -6,7 +6,7 @@ import os
 from .build import LIB_PATH
 
 RDN_LAYERS = 66
-PLAN_KEEP_ACTS, PLAN_NO_FUSE = 1, 2
+PLAN_KEEP_ACTS, PLAN_NO_FUSE, PLAN_RDB3 = 1, 2, 4
 BWD_ACCUMULATE = 1          # BinRdnBwdPlan.reserved flag (BINHIP_BWD_ACCUMULATE)
 BWD_SAVED_X3 = 2            # BINHIP_BWD_SAVED_X3
 EPI_PLANES, EPI_SHUFFLE, EPI_FINAL = 0, 1, 2

@@ -339,7 +339,9 @@ int bh_conv_cout_block(int ksize, int cout_pad, int nterms) {
 static int bh_dispatch_conv(const ConvKArgs& a, int k, int cp, int nt, int e, hipStream_t s);
 int bh_launch_conv_x3(const ConvKArgs& a, int cout_pad, int epilogue, hipStream_t s);   // binhip_conv_x3.hip
 
-int bh_launch_conv(const BhConvCall& c, hipStream_t s) {
+// validate a call and fill the kernel argument block (everything but the tile counts, which the launcher of the chosen
+// tile shape sets)
+int bh_prepare_conv(const BhConvCall& c, ConvKArgs* out) {
     const BinConvDesc& d = c.d;
     if (!c.x_hi || !c.w_hi || !c.bias) return BINHIP_E_ARG;
     if (d.nterms != 1 && d.nterms != 3) return BINHIP_E_ARG;
@@ -383,6 +385,22 @@ int bh_launch_conv(const BhConvCall& c, hipStream_t s) {
     } else {
         return BINHIP_E_ARG;
     }
+    {   // 32-bit buffer offsets: write-through stores only while the whole output tensor stays below 4 GiB
+        const int e = d.epilogue, cp = d.cout_pad;
+        const long long out_chunks = (e == BINHIP_EPI_SHUFFLE) ? (a.cout / 4 + 15) / 16 : (cp + 15) / 16;
+        const long long px = (long long)a.N * a.H * a.W * ((e == BINHIP_EPI_SHUFFLE) ? 4 : 1);
+        const long long span = (a.y_cpg > 0 ? ((out_chunks + a.y_cpg - 1) / a.y_cpg) * a.y_group_stride * 2 : out_chunks * px * 32);
+        // PLANES only: the PixelShuffle store (16 B per lane at a 64-B stride) relies on L2 to merge partial lines
+        a.wt = (e == BINHIP_EPI_PLANES && span < (1ll << 32) - 64) ? 1 : 0;
+    }
+    *out = a;
+    return 0;
+}
+
+int bh_launch_conv(const BhConvCall& c, hipStream_t s) {
+    ConvKArgs a;
+    if (int rc = bh_prepare_conv(c, &a)) return rc;
+    const BinConvDesc& d = c.d;
     const int k = d.ksize, cp = d.cout_pad, nt = d.nterms, e = d.epilogue;
     BinhipProfiler* pr = c.prof;
     if (pr && k == pr->ks && cp == pr->cout_pad && e == pr->epi && pr->used + 2 <= pr->ev.size()) {
@@ -413,19 +431,11 @@ static int bh_dispatch_conv(const ConvKArgs& a0, int k, int cp, int nt, int e, h
     const int cb = bh_conv_cout_block(k, cp, nt);
     if (cb <= 0 || cp % cb) return BINHIP_E_SHAPE;
     ConvKArgs a = a0;
-    int wt_on = 1;
 #if BINHIP_TUNING
     a.xcd_remap = g_xcd_remap;
     a.dbg = g_dbg;
-    wt_on = g_wt;
+    if (!g_wt) a.wt = 0;
 #endif
-    {   // 32-bit buffer offsets: write-through path only while the whole output tensor stays below 4 GiB
-        const long long out_chunks = (e == BINHIP_EPI_SHUFFLE) ? (a.cout / 4 + 15) / 16 : (cp + 15) / 16;
-        const long long px = (long long)a.N * a.H * a.W * ((e == BINHIP_EPI_SHUFFLE) ? 4 : 1);
-        const long long span = (a.y_cpg > 0 ? ((out_chunks + a.y_cpg - 1) / a.y_cpg) * a.y_group_stride * 2 : out_chunks * px * 32);
-        // PLANES only: the PixelShuffle store (16 B per lane at a 64-B stride) relies on L2 to merge partial lines
-        a.wt = (wt_on && e == BINHIP_EPI_PLANES && span < (1ll << 32) - 64) ? 1 : 0;
-    }
     //                                   KS MT WM R WN KC NT NBUF EPI
     if (nt == 1) {
         if (e == F && k == 3 && cp == 32) return launch_cfg<3, 1, 1, 2, 8, 1, 1, 2, F>(a, cp, s);     // 8 waves, 16x32 tile

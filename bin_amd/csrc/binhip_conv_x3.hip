@@ -138,27 +138,16 @@ __device__ __forceinline__ void x3_compute(const char* pb, const char* wb, int a
     }
 }
 
-// WIDE only names the instantiation: 0 = one 32-row output block (the dense-block convs, UPNet.2), 1 = several workgroup
-// columns — same code, separate symbols, so per-kernel profiles keep the dominant dense-block conv apart from the wide layers
-template <int KS, int R, int WN, int EPI, int WIDE>
-__global__ void __launch_bounds__(64 * WN) __attribute__((amdgpu_waves_per_eu(4, 4)))
-conv_x3_kernel(const ConvKArgs a) {
+// One output tile (TH x 32 pixels, 32 output channels of column z) from prologue DMA to epilogue stores.  Every wave of
+// the workgroup calls it with the same arguments; LDS must be free of readers on entry.
+template <int KS, int R, int WN, int EPI>
+__device__ __forceinline__ void x3_tile(const ConvKArgs& a, char* smem, int img, int ty, int tx, int z) {
     using C = X3Cfg<KS, R, WN>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31;     // pixel column (B/N index) and cout row (A/M index) of this lane
     const int kg = lane >> 5;    // which 8-channel half of the 16-channel chunk
-
-    int bid = blockIdx.x;
-    if (a.xcd_remap) bid = xcd_band(bid, gridDim.x);
-    const int tx = bid % a.tiles_x;
-    bid /= a.tiles_x;
-    const int ty = bid % a.tiles_y;
-    const int img = bid / a.tiles_y;
-    const int z = blockIdx.y;
     const int tx0 = tx * 32, ty0 = ty * C::TH;
     const int H = a.H, W = a.W;
     const long long plane_elems = (long long)a.N * H * W * 16;
@@ -211,6 +200,90 @@ conv_x3_kernel(const ConvKArgs a) {
     conv_epilogue<1, R, 3, EPI>(a, acc, img, ty0 + wave * R, tx0, z * 32, z == 0, n, kg, plane_elems);
 }
 
+// WIDE only names the instantiation: 0 = one 32-row output block (the dense-block convs, UPNet.2), 1 = several workgroup
+// columns — same code, separate symbols, so per-kernel profiles keep the dominant dense-block conv apart from the wide layers
+template <int KS, int R, int WN, int EPI, int WIDE>
+__global__ void __launch_bounds__(64 * WN) __attribute__((amdgpu_waves_per_eu(4, 4)))
+conv_x3_kernel(const ConvKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int bid = blockIdx.x;
+    if (a.xcd_remap) bid = xcd_band(bid, gridDim.x);
+    const int tx = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y;
+    const int img = bid / a.tiles_y;
+    x3_tile<KS, R, WN, EPI>(a, smem, img, ty, tx, blockIdx.y);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The three Cout = 32 convolutions of a residual dense block (RDN.py:135-147: convs 0, 1, 2 of `RDB.convs`) as phases of
+// ONE launch.  Conv p+1 of a tile needs conv p's output of the tile and of its 8 neighbours (1-pixel halo), nothing else,
+// so there is no grid-wide barrier: workgroups take (phase, tile) items from an atomic counter in phase-major raster order
+// and, before a phase >= 1 item, poll the per-tile "done" flags of the 3 x 3 neighbourhood of the previous phase.
+//   * No deadlock for ANY grid size or residency: every item an item waits for has a smaller index, so it was handed out
+//     earlier to a workgroup that is running (it executed the atomic) and that itself only waits for still smaller indices.
+//   * Visibility across CUs / XCDs (MI355X: per-XCD L2s are not coherent, a CU's L1 is never refreshed): the producer's
+//     output stores are the write-through (sc1) 16-byte plane stores the kernel uses anyway; every wave drains them
+//     (s_waitcnt vmcnt(0)), the workgroup barriers, ONE lane publishes the flag with an agent-scope (sc1) store.  The
+//     consumer polls with agent-scope loads, barriers, and only then issues its LDS-DMA: the planes it now reads (chunks
+//     6+2p, 7+2p of the block buffer) were never read in this launch before their flags were set, so no L1 / L2 holds a
+//     stale line of them (kernel boundaries invalidate both).
+//   * A bounded spin (RDB3_SPIN_LIMIT polls with s_sleep) turns a protocol error into a status bit instead of a hang.
+struct Rdb3Args {
+    ConvKArgs conv[3];
+    unsigned* counter;        // work-queue head, 0 at launch
+    unsigned* flags;          // [2][T] "phase p of tile t is visible" == epoch
+    unsigned epoch;           // value that means "done" in this launch (flags are reused by later launches)
+    int T;                    // tiles per phase = tiles_x * tiles_y * N
+};
+#define BINHIP_FLAG_SYNC_TIMEOUT 2u
+constexpr unsigned RDB3_SPIN_LIMIT = 1u << 22;
+
+template <int R, int WN>
+__global__ void __launch_bounds__(64 * WN) __attribute__((amdgpu_waves_per_eu(4, 4)))
+conv_x3_rdb3_kernel(const Rdb3Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ unsigned s_idx;
+    const int tiles_x = a.conv[0].tiles_x, tiles_y = a.conv[0].tiles_y;
+    const unsigned total = 3u * (unsigned)a.T;
+    for (;;) {
+        if (threadIdx.x == 0) s_idx = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned idx = s_idx;
+        if (idx >= total) break;
+        const int p = (int)(idx / (unsigned)a.T);
+        int t = (int)(idx - (unsigned)p * (unsigned)a.T);
+        const int tx = t % tiles_x;
+        t /= tiles_x;
+        const int ty = t % tiles_y;
+        const int img = t / tiles_y;
+        if (p > 0) {
+            if (threadIdx.x < 9) {            // one lane per neighbour of the 3 x 3 neighbourhood
+                const int ny = ty + (int)threadIdx.x / 3 - 1, nx = tx + (int)threadIdx.x % 3 - 1;
+                if (ny >= 0 && ny < tiles_y && nx >= 0 && nx < tiles_x) {
+                    const unsigned* f = a.flags + (size_t)(p - 1) * a.T + ((size_t)img * tiles_y + ny) * tiles_x + nx;
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > RDB3_SPIN_LIMIT) {
+                            if (a.conv[0].flags) atomicOr(a.conv[0].flags, BINHIP_FLAG_SYNC_TIMEOUT);
+                            break;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();                      // also: every wave has read s_idx before lane 0 overwrites it
+        x3_tile<3, R, WN, BINHIP_EPI_PLANES>(a.conv[p], smem, img, ty, tx, 0);
+        // publish: this wave's write-through stores have left (vmcnt(0)), then all waves', then the flag
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0 && p < 2)
+            __hip_atomic_store(a.flags + (size_t)p * a.T + (idx - (unsigned)p * (unsigned)a.T), a.epoch, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 template <int KS, int R, int WN, int EPI, int WIDE>
 static int launch_x3(const ConvKArgs& ka, int cout_pad, hipStream_t s) {
     using C = X3Cfg<KS, R, WN>;
@@ -221,6 +294,29 @@ static int launch_x3(const ConvKArgs& ka, int cout_pad, hipStream_t s) {
     a.tiles_y = (a.H + C::TH - 1) / C::TH;
     dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N), (unsigned)(cout_pad / 32));
     conv_x3_kernel<KS, R, WN, EPI, WIDE><<<grid, dim3(64 * C::NW), C::LDS_BYTES, s>>>(a);
+    BH_CHECK_LAUNCH();
+    return 0;
+}
+
+// the three-phase dense-block launch: `convs` are the fully prepared kernel arguments of convs 0, 1, 2 (same N, H, W;
+// write-through stores required), `sync` = [counter][2 * T flags] device words, counter zeroed by the caller
+int bh_launch_rdb3_x3(const ConvKArgs* convs, unsigned* counter, unsigned* flags, unsigned epoch, int cus, hipStream_t s) {
+    using C = X3Cfg<3, 2, 8>;
+    static std::atomic<unsigned long long> lds_set{0};
+    if (int rc = bh_set_max_lds(&conv_x3_rdb3_kernel<2, 8>, C::LDS_BYTES, lds_set)) return rc;
+    Rdb3Args a;
+    for (int p = 0; p < 3; ++p) {
+        a.conv[p] = convs[p];
+        a.conv[p].tiles_x = (convs[p].W + 31) / 32;
+        a.conv[p].tiles_y = (convs[p].H + C::TH - 1) / C::TH;
+        if (!a.conv[p].wt) return BINHIP_E_SHAPE;
+    }
+    a.T = a.conv[0].tiles_x * a.conv[0].tiles_y * a.conv[0].N;
+    a.counter = counter; a.flags = flags; a.epoch = epoch;
+    const long long items = 3ll * a.T;
+    const long long slots = 2ll * (cus > 0 ? cus : 256);
+    const unsigned grid = (unsigned)(items < slots ? items : slots);
+    conv_x3_rdb3_kernel<2, 8><<<dim3(grid), dim3(64 * C::NW), C::LDS_BYTES, s>>>(a);
     BH_CHECK_LAUNCH();
     return 0;
 }

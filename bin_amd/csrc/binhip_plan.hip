@@ -9,7 +9,7 @@
 //                   BLK[d][6+2c : 8+2c] = output of conv c of RDB d  -> "cat" is free
 //   G0,G1 [6]       GFF.0 / GFF.1(+f__1)
 //   U    [4]        UPNet.0 output after PixelShuffle, full resolution
-#include "binhip_internal.h"
+#include "binhip_conv_common.h"
 
 namespace {
 
@@ -17,6 +17,8 @@ struct Ws {
     int64_t P, PF;        // plane elems at half / full res
     int kc0;
     int64_t x0, f1, blk, g0, g1, u, total;   // element offsets of the hi part
+    int64_t sync;                            // element offset of the dense-block sync words (12 counters + 2 T flags, uint32)
+    int tiles;                               // 16x32 tiles of one dense-block conv launch
     int64_t s_x0, s_f1, s_blk, s_g, s_u;     // sizes (elements) of each tensor's hi part
     int nt;
 };
@@ -37,6 +39,11 @@ Ws make_ws(int N, int H, int W, int nin, int nt) {
     w.g0 = o; o += mul * w.s_g;
     w.g1 = o; o += mul * w.s_g;
     w.u = o; o += mul * w.s_u;
+    // sync words of the three-phase dense-block launches (binhip_conv_x3.hip): 16 counters (12 used, one per block) + two
+    // flag words per tile; 4-byte words kept in the fp16-element address space (2 elements each), 256-B aligned
+    w.tiles = N * ((h + 15) / 16) * ((ww + 31) / 32);
+    o = (o + 127) & ~(int64_t)127;
+    w.sync = o; o += 2 * (16 + 2 * (int64_t)w.tiles);
     w.total = o;
     return w;
 }
@@ -75,9 +82,9 @@ int binhip_rdn_forward(const BinRdnPlan* p, const float* const* inputs, float* o
     int rc = binhip_pack_inputs(inputs, nin, N, H, W, HI(w.x0), LO(w.x0, w.s_x0), p->status, stream);
     if (rc) return rc;
 
-    auto conv = [&](int layer, int ks, int cin_chunks, int cout, int cout_pad, int epi, int relu, int Hc, int Wc,
-                    int64_t x_off, int64_t x_size, int cpg, int64_t gstride,
-                    int64_t y_off, int64_t y_size, int64_t r_off, int64_t r_size) -> int {
+    auto mk = [&](int layer, int ks, int cin_chunks, int cout, int cout_pad, int epi, int relu, int Hc, int Wc,
+                  int64_t x_off, int64_t x_size, int cpg, int64_t gstride,
+                  int64_t y_off, int64_t y_size, int64_t r_off, int64_t r_size) -> BhConvCall {
         BhConvCall c;
         c.d.N = N; c.d.H = Hc; c.d.W = Wc; c.d.ksize = ks; c.d.cin_chunks = cin_chunks; c.d.cout = cout;
         c.d.cout_pad = cout_pad; c.d.nterms = nt; c.d.epilogue = epi; c.d.relu = relu;
@@ -97,8 +104,25 @@ int binhip_rdn_forward(const BinRdnPlan* p, const float* const* inputs, float* o
             c.d.n_images = nin;
             for (int i = 0; i < nin; ++i) c.images[i] = inputs[i];
         }
-        return bh_launch_conv(c, s);
+        return c;
     };
+    auto conv = [&](int layer, int ks, int cin_chunks, int cout, int cout_pad, int epi, int relu, int Hc, int Wc,
+                    int64_t x_off, int64_t x_size, int cpg, int64_t gstride,
+                    int64_t y_off, int64_t y_size, int64_t r_off, int64_t r_size) -> int {
+        return bh_launch_conv(mk(layer, ks, cin_chunks, cout, cout_pad, epi, relu, Hc, Wc, x_off, x_size, cpg, gstride,
+                                 y_off, y_size, r_off, r_size), s);
+    };
+    // three-phase dense-block launches (BINHIP_PLAN_RDB3, fp32-class path): zero the 12 work-queue heads once per call;
+    // the per-tile flags need no reset — block d publishes the value d + 1, which no earlier launch of this call and no
+    // earlier call (its last writer was block 11 -> 12, or block d itself with the same planes long complete) can
+    // leave behind for block d ... except the same block of the PREVIOUS call: so the flags are cleared as well.
+    const bool rdb3 = (p->reserved & BINHIP_PLAN_RDB3) && nt == 3;
+    unsigned* sync_words = (unsigned*)(base + w.sync);
+    const int cus = binhip_device_cus();
+    if (rdb3) {
+        hipError_t me = hipMemsetAsync(sync_words, 0, (size_t)(16 + 2 * (size_t)w.tiles) * 4, s);
+        if (me != hipSuccess) return (int)me;
+    }
     const int P_ = BINHIP_EPI_PLANES;
     const int64_t P = w.P;
     // SFENet1 5x5 (RDN.py:187/245/299) and SFENet2 3x3 (:188)
@@ -108,7 +132,23 @@ int binhip_rdn_forward(const BinRdnPlan* p, const float* const* inputs, float* o
     for (int d = 0; d < 12; ++d) {
         const int64_t b = w.blk + (int64_t)d * 14 * P;
         const bool fuse = !(p->reserved & BINHIP_PLAN_NO_FUSE);
-        for (int c = 0; c < (fuse ? 3 : 4); ++c) {
+        bool done3 = false;
+        if (rdb3 && fuse) {
+            // convs 0-2 as three phases of one launch (work queue + neighbour flags instead of two kernel boundaries)
+            ConvKArgs ka[3];
+            bool ok3 = true;
+            for (int c = 0; c < 3 && ok3; ++c) {
+                BhConvCall cc = mk(2 + 5 * d + c, 3, 6 + 2 * c, 32, 32, P_, 1, h, ww, b, w.s_blk, 0, 0,
+                                   b + (int64_t)(6 + 2 * c) * P, w.s_blk, -1, 0);
+                if ((rc = bh_prepare_conv(cc, &ka[c]))) return rc;
+                ok3 = ok3 && ka[c].wt;
+            }
+            if (ok3) {
+                if ((rc = bh_launch_rdb3_x3(ka, sync_words + d, sync_words + 16, (unsigned)(d + 1), cus, s))) return rc;
+                done3 = true;
+            }
+        }
+        for (int c = 0; c < (fuse ? 3 : 4) && !done3; ++c) {
             if ((rc = conv(2 + 5 * d + c, 3, 6 + 2 * c, 32, 32, P_, 1, h, ww, b, w.s_blk, 0, 0,
                            b + (int64_t)(6 + 2 * c) * P, w.s_blk, -1, 0))) return rc;
         }

@@ -122,7 +122,11 @@ def workspace(nbytes, device, key="fwd"):
     return ws
 
 
-PLAN_FLAGS = 0          # module-level default (tests flip BINHIP_PLAN_NO_FUSE through this)
+import os as _os
+
+# module-level default plan flags (tests flip BINHIP_PLAN_NO_FUSE / BINHIP_PLAN_RDB3 through this).
+# BIN_AMD_RDB3=1: convs 0-2 of every dense block as three phases of one launch (fp32-class path)
+PLAN_FLAGS = L.PLAN_RDB3 if _os.environ.get("BIN_AMD_RDB3", "0") == "1" else 0
 
 
 def rdn_forward(weights, inputs, out=None, ws=None, flags=None, profiler=None):

@@ -346,3 +346,29 @@ def test_concurrent_host_threads_share_the_library():
     for i in range(2):
         for a, b in zip(results[i], serial[i]):
             assert torch.equal(a, b)
+
+
+def test_three_phase_dense_block_launch_is_bit_identical(canon_gpu):
+    """BINHIP_PLAN_RDB3 (opt-in): convs 0-2 of every dense block as three phases of ONE launch — (phase, tile) items from an
+    atomic work queue, per-tile neighbour flags instead of kernel boundaries, write-through stores + drained flag for
+    cross-XCD visibility.  Must return the per-launch path's bits on ragged and multi-image shapes, repeatedly and while
+    another stream loads the chip unevenly, and must never trip the bounded-spin status bit."""
+    from bin_amd import _lib as L, ops
+    from bin_amd.rdn_plan import RdnWeights, rdn_forward
+    ops.check_status()
+    g = torch.Generator().manual_seed(5)
+    wts = RdnWeights(canon_gpu, 3, 3, prefix="model2.")
+    noise = torch.randn(2048, 2048, device="cuda")
+    side = torch.cuda.Stream()
+    for (n, h, w) in ((1, 64, 96), (2, 40, 72), (3, 130, 190), (1, 384, 672)):
+        ins = [torch.rand(n, 3, h, w, generator=g).cuda() for _ in range(3)]
+        ref = rdn_forward(wts, ins, flags=0).clone()
+        for rep in range(4):
+            if rep >= 2:
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        noise @ noise
+            out = rdn_forward(wts, ins, flags=L.PLAN_RDB3)
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref), (n, h, w, rep)
+        ops.check_status()
