@@ -370,6 +370,7 @@ int bh_prepare_conv(const BhConvCall& c, ConvKArgs* out) {
     a.relu = d.relu; a.has_res = (c.r_hi != nullptr); a.nimg = d.n_images; a.cout = d.cout;
     a.och_limit = (d.epilogue == BINHIP_EPI_PLANES) ? (d.cout + 15) / 16 : (1 << 30);
     a.tiles_x = a.tiles_y = 0;
+    a.ncol = 1;
     a.xcd_remap = 1;
     a.dbg = 0;
     a.wt = 0;

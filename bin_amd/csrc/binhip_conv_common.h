@@ -31,6 +31,7 @@ struct ConvKArgs {
     int nchunks;
     int cpg;
     int tiles_x, tiles_y;
+    int ncol;                 // plane-split kernel: output columns of 32 rows sharing a tile (1-D grid, column fastest)
     int relu, has_res, nimg, cout;
     int xcd_remap;
     int wt;                   // write-through (sc1) output stores

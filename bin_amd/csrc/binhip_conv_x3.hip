@@ -206,13 +206,19 @@ template <int KS, int R, int WN, int EPI, int WIDE>
 __global__ void __launch_bounds__(64 * WN) __attribute__((amdgpu_waves_per_eu(4, 4)))
 conv_x3_kernel(const ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // 1-D grid of tiles x output columns, column fastest: after the XCD banding the `ncol` workgroups that share one input
+    // patch are neighbours on ONE XCD, so the patch is fetched into that L2 once (a (tiles, ncol) grid ran each column as a
+    // separate sweep: UPNet.0's 8 columns fetched 884 MB for 99 MB of input)
     int bid = blockIdx.x;
     if (a.xcd_remap) bid = xcd_band(bid, gridDim.x);
+    const int ncol = a.ncol;
+    const int z = bid % ncol;
+    bid /= ncol;
     const int tx = bid % a.tiles_x;
     bid /= a.tiles_x;
     const int ty = bid % a.tiles_y;
     const int img = bid / a.tiles_y;
-    x3_tile<KS, R, WN, EPI>(a, smem, img, ty, tx, blockIdx.y);
+    x3_tile<KS, R, WN, EPI>(a, smem, img, ty, tx, z);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -292,7 +298,8 @@ static int launch_x3(const ConvKArgs& ka, int cout_pad, hipStream_t s) {
     ConvKArgs a = ka;
     a.tiles_x = (a.W + 31) / 32;
     a.tiles_y = (a.H + C::TH - 1) / C::TH;
-    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N), (unsigned)(cout_pad / 32));
+    a.ncol = cout_pad / 32;
+    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N * a.ncol));
     conv_x3_kernel<KS, R, WN, EPI, WIDE><<<grid, dim3(64 * C::NW), C::LDS_BYTES, s>>>(a);
     BH_CHECK_LAUNCH();
     return 0;

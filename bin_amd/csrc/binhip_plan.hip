@@ -112,10 +112,9 @@ int binhip_rdn_forward(const BinRdnPlan* p, const float* const* inputs, float* o
         return bh_launch_conv(mk(layer, ks, cin_chunks, cout, cout_pad, epi, relu, Hc, Wc, x_off, x_size, cpg, gstride,
                                  y_off, y_size, r_off, r_size), s);
     };
-    // three-phase dense-block launches (BINHIP_PLAN_RDB3, fp32-class path): zero the 12 work-queue heads once per call;
-    // the per-tile flags need no reset — block d publishes the value d + 1, which no earlier launch of this call and no
-    // earlier call (its last writer was block 11 -> 12, or block d itself with the same planes long complete) can
-    // leave behind for block d ... except the same block of the PREVIOUS call: so the flags are cleared as well.
+    // three-phase dense-block launches (BINHIP_PLAN_RDB3, opt-in, fp32-class path): one memset per call zeroes the 12
+    // work-queue heads and the per-tile flags (block d publishes the value d + 1, so the blocks of one call never confuse
+    // each other's flags; the memset only removes what an earlier call or uninitialised memory left behind)
     const bool rdb3 = (p->reserved & BINHIP_PLAN_RDB3) && nt == 3;
     unsigned* sync_words = (unsigned*)(base + w.sync);
     const int cus = binhip_device_cus();
