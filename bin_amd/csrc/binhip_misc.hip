@@ -235,10 +235,19 @@ amax_partial_kernel(const float* __restrict__ x, long long n, float* __restrict_
     __syncthreads();
     if (threadIdx.x == 0) partials[blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
 }
-__global__ void grad_scale_final_kernel(const float* __restrict__ partials, int nb, float target, float* __restrict__ sc) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    float m = 0.f;
-    for (int i = 0; i < nb; ++i) m = fmaxf(m, partials[i]);
+__global__ void __launch_bounds__(256)
+grad_scale_final_kernel(const float* __restrict__ partials, int nb, float target, float* __restrict__ sc) {
+    __shared__ float sm[256];
+    float m = 0.f;                                        // max is order-independent: a parallel sweep is exact
+    for (int i = threadIdx.x; i < nb; i += 256) m = fmaxf(m, partials[i]);
+    sm[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sm[threadIdx.x] = fmaxf(sm[threadIdx.x], sm[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    m = sm[0];
     float s = 1.f;
     if (m > 0.f && isfinite(m)) {
         int e = (int)floorf(log2f(target / m));
@@ -434,13 +443,23 @@ convlstm_bwd_weight_kernel(const float* __restrict__ dgates, const float* __rest
         partials[(long long)blockIdx.x * 660 + k] = acc;
     }
 }
-__global__ void convlstm_bwd_weight_final_kernel(const float* __restrict__ partials, int nb, float* __restrict__ dw,
-                                                 float* __restrict__ db) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= 660) return;
+// one 256-thread block per output k (648 weights + 12 biases): thread t adds the partials t, t + 256, ... in double, the
+// 256 sums are combined by a fixed tree -> deterministic (a single thread per output walking all `nb` partials took 250 us)
+__global__ void __launch_bounds__(256)
+convlstm_bwd_weight_final_kernel(const float* __restrict__ partials, int nb, float* __restrict__ dw, float* __restrict__ db) {
+    __shared__ double sm[256];
+    const int k = blockIdx.x;
     double acc = 0.0;
-    for (int i = 0; i < nb; ++i) acc += (double)partials[(long long)i * 660 + k];
-    if (k < 648) dw[k] = (float)acc; else db[k - 648] = (float)acc;
+    for (int i = threadIdx.x; i < nb; i += 256) acc += (double)partials[(long long)i * 660 + k];
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (k < 648) dw[k] = (float)sm[0]; else db[k - 648] = (float)sm[0];
+    }
 }
 
 extern "C" {
@@ -580,7 +599,7 @@ int binhip_grad_scale(const float* g, int64_t numel, float target, float* partia
     long long nb = (numel + 255) / 256;
     if (nb > CHARB_BLOCKS) nb = CHARB_BLOCKS;
     hipLaunchKernelGGL(amax_partial_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, g, (long long)numel, partials);
-    hipLaunchKernelGGL(grad_scale_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partials, (int)nb, target, scale_out);
+    hipLaunchKernelGGL(grad_scale_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, (int)nb, target, scale_out);
     BH_CHECK_LAUNCH();
     return 0;
 }
@@ -642,7 +661,7 @@ int binhip_convlstm_bwd(const float* x, const float* c_prev, const float* h_prev
         const int nblk = tiles_x * tiles_y * N;
         hipLaunchKernelGGL(convlstm_bwd_weight_kernel, dim3((unsigned)nblk), dim3(256), 0, s, dg, x, h_prev, N, H, W, tiles_x,
                            tiles_y, part);
-        hipLaunchKernelGGL(convlstm_bwd_weight_final_kernel, dim3(3), dim3(256), 0, s, part, nblk, dw, db);
+        hipLaunchKernelGGL(convlstm_bwd_weight_final_kernel, dim3(660), dim3(256), 0, s, part, nblk, dw, db);
     }
     BH_CHECK_LAUNCH();
     return 0;
