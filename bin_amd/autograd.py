@@ -7,8 +7,11 @@
                (dgrad on the forward conv kernel with transposed/flipped weights, MFMA wgrad with LDS
                transpose reads, fused ReLU masks / skip adds / PixelShuffle inverse).
 * `_ConvLstmFn` — ConvLSTMCell (RDN.py:50-95) forward/backward kernels.
-Training precision defaults to "f16x3" (fp32-class gradients); set BIN_AMD_TRAIN_PRECISION=f16 to trade
-gradient accuracy (~1e-3 relative) for speed.
+Training precision defaults to "f16x3" (fp32-class gradients, ~5e-6 relative vs torch autograd of the oracle).
+BIN_AMD_TRAIN_PRECISION=f16 (single fp16 product in forward AND backward) is NOT a training mode to rely on: its forward's
+~1e-3 activation error flips ReLU masks, and individual parameter gradients come out 1-25 % off
+(tests/test_gpu_backward.py, tolerance 2.5e-1).  The supported speed/accuracy trade is BACKWARD_PRECISION = "f16" behind the
+f16x3 forward (exact loss and masks, ~2e-3 relative gradient error).
 """
 import ctypes as C
 import os
@@ -71,6 +74,11 @@ class _RdnFn(torch.autograd.Function):
         ctx.dims = (n, h, w)
         ctx.param_meta = [(tuple(a.shape), a.device) for a in args[n_frames:]]
         ctx.params = args[n_frames:]
+        # the backward-data weights are rebuilt from the CURRENT parameters: like torch's saved-tensor version check,
+        # refuse a backward after an in-place update of the weights this forward used (forward -> optimizer.step() ->
+        # backward would otherwise silently mix old activations with new weights)
+        ctx.param_versions = [a._version for a in args[n_frames:]]
+        ctx.weights_gen = module._wgen
         # backward calls still owed to this weight set in the current step (the pyramid shares model1 / model2 / model3
         # between 4-5 / 3 / 2 calls): when the count returns to zero the set's gradients are complete and a data-parallel
         # reducer may start their all-reduce while the rest of the backward is still running (bin_model.FlatGradAllReduce)
@@ -84,6 +92,10 @@ class _RdnFn(torch.autograd.Function):
         dev = gout.device
         gout = gout.contiguous().float()
         lib = L.lib()
+        if ctx.weights_gen != module._wgen or any(a._version != v for a, v in zip(ctx.params, ctx.param_versions)):
+            raise RuntimeError("bin_amd: a parameter of this RDN was modified in place between its forward and its backward "
+                               "(optimizer step, load_state_dict, broadcast ...): the gradient would be computed with "
+                               "weights the forward did not use")
         nt_bwd = 1 if (BACKWARD_PRECISION == "f16" and nterms == 3) else nterms
         dgw = module.kernel_weights(nterms).dgrad(module, nt_bwd)
         plan = L.BinRdnBwdPlan()

@@ -104,7 +104,11 @@ class BaseModel:
 
     def load_network(self, load_path, network, strict=True):
         loaded = torch.load(load_path, map_location="cpu")
-        unwrap(network).load_state_dict(clean_state_dict_keys(loaded, strict), strict=strict)
+        net = unwrap(network)
+        net.load_state_dict(clean_state_dict_keys(loaded, strict), strict=strict)
+        for mod in net.modules():                    # load_state_dict copies in place (versions bump), but be explicit:
+            if hasattr(mod, "invalidate_kernel_weights"):        # the relayouted kernel weights must be rebuilt
+                mod.invalidate_kernel_weights()
 
     def save_training_state(self, epoch, iter_step):
         """`{iter}.state` with everything needed to resume (reference base_model.py:105-114)."""

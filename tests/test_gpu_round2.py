@@ -372,3 +372,29 @@ def test_three_phase_dense_block_launch_is_bit_identical(canon_gpu):
             torch.cuda.synchronize()
             assert torch.equal(out, ref), (n, h, w, rep)
         ops.check_status()
+
+
+def test_backward_refuses_weights_modified_after_forward(canon_cpu):
+    """The backward-data weights are rebuilt from the current parameters; like torch's saved-tensor version check, a
+    backward after an in-place update of the weights its forward used must raise instead of mixing old activations with
+    new weights.  Writes through `.data` do not bump versions: `invalidate_kernel_weights()` covers those."""
+    from bin_amd.models.archs import RDN as A
+    from bin_amd.weights import rdn_param_shapes
+    mod = A.RDN_residual_interp_2_input(G0=96, D=12)
+    mod.load_state_dict({n: canon_cpu[f"model1.{n}"] for n in rdn_param_shapes(2)})
+    mod = mod.cuda()
+    g = torch.Generator().manual_seed(2)
+    ins = [torch.rand(1, 3, 32, 32, generator=g).cuda().requires_grad_(True) for _ in range(2)]
+    out = mod(*ins)
+    with torch.no_grad():
+        mod.SFENet1.weight.mul_(1.0)                      # in-place: bumps the version counter
+    with pytest.raises(RuntimeError, match="modified in place"):
+        out.sum().backward()
+    out = mod(*ins)
+    mod.SFENet1.weight.data.mul_(1.0)                     # through .data: invisible to versions ...
+    mod.invalidate_kernel_weights()                       # ... so the owner says so explicitly
+    with pytest.raises(RuntimeError, match="modified in place"):
+        out.sum().backward()
+    out = mod(*ins)                                       # a fresh forward is fine again
+    out.sum().backward()
+    assert mod.SFENet1.weight.grad is not None and torch.isfinite(mod.SFENet1.weight.grad).all()
