@@ -101,7 +101,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, floatx16 (&acc
         }
     } else {
         union H4 { half4 h; unsigned u[2]; };
-        bool sat = false;
+        unsigned sat = 0;
         const int gxc = gx < W ? gx : W - 1;     // clamped coordinates: loads need no branch, stores are predicated
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -192,7 +192,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, floatx16 (&acc
                 }
             }
         }
-        if (a.flags && __builtin_amdgcn_ballot_w64(sat) != 0 && (threadIdx.x & 63) == 0)
+        if (a.flags && __builtin_amdgcn_ballot_w64(sat != 0) != 0 && (threadIdx.x & 63) == 0)
             atomicOr(a.flags, BINHIP_FLAG_SATURATED);
     }
 }

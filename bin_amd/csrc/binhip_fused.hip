@@ -215,7 +215,7 @@ rdb_tail_kernel(const TailKArgs a) {
     constexpr int O3_PLANE = C::NW * C::R * 2 * 32 * 32;     // hi tiles of all waves, then lo tiles
     const int gx = tx0 + n;
     union H4 { half4 h; unsigned u[2]; };
-    bool sat = false;
+    unsigned sat = 0;
 #pragma unroll
     for (int r = 0; r < C::R; ++r) {
         const int gy = ty0 + wave * C::R + r;
@@ -335,7 +335,7 @@ rdb_tail_kernel(const TailKArgs a) {
             }
         }
     }
-    if (a.flags && __builtin_amdgcn_ballot_w64(sat) != 0 && lane == 0) atomicOr(a.flags, BINHIP_FLAG_SATURATED);
+    if (a.flags && __builtin_amdgcn_ballot_w64(sat != 0) != 0 && lane == 0) atomicOr(a.flags, BINHIP_FLAG_SATURATED);
 }
 
 template <int NT, int NBUF>

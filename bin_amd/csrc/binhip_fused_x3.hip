@@ -233,7 +233,7 @@ rdb_tail_x3_kernel(const TailKArgs a) {
     char* o3l = smem + TX::O3L_OFF + wave * (TX::R * 2 * 32 * 32);
     const int gx = tx0 + n;
     union H4 { half4 h; unsigned u[2]; };
-    bool sat = false;
+    unsigned sat = 0;
 #pragma unroll
     for (int r = 0; r < TX::R; ++r) {
         const int gy = ty0 + wave * TX::R + r;
@@ -301,7 +301,7 @@ rdb_tail_x3_kernel(const TailKArgs a) {
             }
         }
     }
-    if (a.flags && __builtin_amdgcn_ballot_w64(sat) != 0 && lane == 0) atomicOr(a.flags, BINHIP_FLAG_SATURATED);
+    if (a.flags && __builtin_amdgcn_ballot_w64(sat != 0) != 0 && lane == 0) atomicOr(a.flags, BINHIP_FLAG_SATURATED);
 
     // ---- LFF epilogue: bias (the block input = RDB residual is already in the accumulators) -> 6 output planes -------
     ConvKArgs e;

@@ -23,7 +23,7 @@ __global__ void nchw_to_planes_kernel(const float* __restrict__ x, int N, int C,
     const int n = (int)(u % N);
     const int ch = (int)(u / N);
     half8 hv, lv;
-    bool sat = false;
+    unsigned sat = 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int c = ch * 16 + s * 8 + e;
@@ -33,7 +33,7 @@ __global__ void nchw_to_planes_kernel(const float* __restrict__ x, int N, int C,
     }
     *reinterpret_cast<half8*>(y_hi + t * 8) = hv;
     if (y_lo) *reinterpret_cast<half8*>(y_lo + t * 8) = lv;
-    if (sat && flags) atomicOr(flags, BINHIP_FLAG_SATURATED);
+    if (sat != 0 && flags) atomicOr(flags, BINHIP_FLAG_SATURATED);
 }
 
 // one thread = one (n, c, pixel) output element; reads are 2-byte gathers (test/boundary glue only)
@@ -88,7 +88,7 @@ __global__ void pack_inputs_kernel(PackArgs a, _Float16* __restrict__ y_hi, _Flo
     const int ch = (int)(u / a.N);
     const int y = (int)(pix / w), x = (int)(pix % w);
     half8 hv, lv;
-    bool sat = false;
+    unsigned sat = 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int c = ch * 16 + s * 8 + e;     // = 4*cc + 2*i + j   (RDN.py:128-132)
@@ -103,7 +103,7 @@ __global__ void pack_inputs_kernel(PackArgs a, _Float16* __restrict__ y_hi, _Flo
     }
     *reinterpret_cast<half8*>(y_hi + t * 8) = hv;
     if (y_lo) *reinterpret_cast<half8*>(y_lo + t * 8) = lv;
-    if (sat && flags) atomicOr(flags, BINHIP_FLAG_SATURATED);
+    if (sat != 0 && flags) atomicOr(flags, BINHIP_FLAG_SATURATED);
 }
 
 // ---- harness glue: the per-frame host work of test.py moved onto the device -----------------
