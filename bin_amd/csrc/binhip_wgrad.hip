@@ -35,6 +35,7 @@ struct WgradKArgs {
     int cin_chunks, cout_chunks;
     int tiles_x, tiles_y, ntiles;
     int PB, ncp, ncot;
+    int ppg;      // 1x1 kernel: input-channel pairs per workgroup column (blockIdx.y)
     int dbg;      // ablation (timing experiments): 1 skip DMA, 2 skip MFMA/LDS reads, 4 skip the final reduction+store
 };
 
@@ -73,6 +74,28 @@ __device__ __forceinline__ half8 tr_frag(const char* img, int chunk_bytes, int p
         r[rd * 4 + 0] = u.h[0]; r[rd * 4 + 1] = u.h[1]; r[rd * 4 + 2] = u.h[2]; r[rd * 4 + 3] = u.h[3];
     }
     return r;
+}
+
+// The same fragment with the reads issued from inline asm.  The compiler knows nothing about the alias classes of the
+// transpose-read builtin, so after an LDS-DMA (buffer_load ... lds) it protects every tr_frag() with s_waitcnt vmcnt(0) —
+// which serialises "prefetch the next stage" and "compute this one".  Asm reads are invisible to that pass; the price is
+// that the lgkmcnt wait is ours: tr_issue() ... tr_wait(...) on the SAME registers before their first use.
+typedef __attribute__((address_space(3))) const char lds_cchar_t;
+__device__ __forceinline__ unsigned lds_addr(const char* p) { return (unsigned)(size_t)(lds_cchar_t*)p; }
+// per-lane part of the address, valid for pixel offsets that are multiples of 16 (then (p >> 3) & 1 == lane >> 5)
+__device__ __forceinline__ unsigned tr_lane_off(int chunk_bytes, int lane) {
+    const int t = lane & 15, ch = (lane >> 4) & 1, kg = lane >> 5;
+    return (unsigned)(ch * chunk_bytes + (kg * 8 + (t >> 2)) * 32 + ((((t & 3) >> 1) ^ kg) << 4) + ((t & 1) << 3));
+}
+struct TrFrag { short4_ a, b; };     // pixels +0..3 and +4..7 of the lane's channel
+__device__ __forceinline__ void tr_issue(TrFrag& f, unsigned addr) {      // addr = lds_addr(chunk strip) + lane part + p0 * 32
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.a) : "v"(addr));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:128" : "=v"(f.b) : "v"(addr));
+}
+__device__ __forceinline__ half8 tr_value(const TrFrag& f) {
+    union { struct { short4_ a, b; } s; half8 h; } u;
+    u.s.a = f.a; u.s.b = f.b;
+    return u.h;
 }
 
 template <int KS, int TR, int NT>
@@ -351,205 +374,223 @@ wgrad_mfma_sb_kernel(const WgradKArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// 1x1 convolutions (LFF 224->96, GFF.0 1152->96): with a single tap the whole [NCPB x 32 ci] x [96 co] gradient tile
-// fits in registers (NCPB*3 accumulators), so one workgroup keeps ALL three output tiles and NCPB = 4 input-channel
-// pairs: X and gY are each streamed through LDS exactly once (the generic kernel re-reads X per output tile and gY
-// per channel pair: 705 MB instead of 168 MB for LFF at 8x128x128).  Pixel tile 4 x 32, wave w owns row w.
-constexpr int W1_NCPB = 4, W1_NCOT = 3, W1_TH = 4;   // 12 accumulator tiles = 192 registers
+// 1x1 convolutions (LFF 224->96, GFF.0 1152->96).  A 1x1 weight gradient does 2*Cin*Cout flops per pixel for
+// (Cin + Cout) * 2 B of operands per plane: 77 flop/B in f16x3 — four times below the machine balance, so this is a
+// STREAMING kernel and its design goal is bytes: every X and gY plane byte crosses HBM once per channel-pair group and
+// enough of them are in flight per CU to cover the HBM latency.
+//   * One workgroup (8 waves, one per CU: the LDS is all staging buffer) walks strips of TR x 32 pixels; a stage holds the
+//     strip of ALL its operands — 6 gY chunks and `ppg` input-channel pairs, hi and lo planes — and is double buffered
+//     (LFF, f16x3: 2 x 80 KB, so ~80 KB per CU are always in flight).
+//   * Wave w owns input-channel pair(s) w*PPW .. of the group and all three 32-wide output tiles: its 3*PPW accumulator tiles
+//     see every pixel of the strip, so there is no K-split across waves, no end-of-kernel cross-wave reduction, and the
+//     accumulators are 48*PPW registers instead of the 192 a "one wave = one pixel row of all tiles" split needs (the round-1
+//     kernel: 1 wave per SIMD, a barrier per 16 KB, gY read once per group of FOUR pairs — 1.09 GB for 0.84 GB of
+//     operands on LFF at 40 x 128 x 128 — and 2.8 TB/s).
+//   * ncp > 8 (GFF.0: 36 pairs): PPW = 2 and ceil(ncp / 16) balanced groups (3 x 12), gY re-read once per group.
+// The last wave of group 0 also accumulates the bias gradient from the gY fragments it loads anyway.
+constexpr int W1_NW = 8, W1_NCOT = 3;
 
-template <int NT>
-struct W1Cfg {
-    static constexpr int NPL = (NT == 3) ? 2 : 1;
-    static constexpr int CH_BYTES = W1_TH * 32 * 32;                 // one chunk tile: 4 KiB
-    static constexpr int G_BYTES = NPL * 2 * W1_NCOT * CH_BYTES;     // gY tile, 6 chunks per plane
-    static constexpr int X_BYTES = NPL * 2 * CH_BYTES;               // one channel pair of X
-    static constexpr int LDS_BYTES = 2 * G_BYTES + 2 * X_BYTES;      // both double buffered
-    static_assert(LDS_BYTES >= 16384 && LDS_BYTES <= 160 * 1024, "LDS budget");
-};
-
-template <int NT>
-__device__ __forceinline__ void w1_issue_chunk(const _Float16* base, long long off, bool have, unsigned plane_bytes, char* lds,
-                                               int img, int ty0, int tx0, int H, int W, int wave, int lane) {
-    // one 4 x 32 pixel chunk tile = 4 KiB = 4 DMA pieces, one per wave
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(have ? base + off : base), 0,
-                                                                  have ? plane_bytes : 0u, 0x00020000);
-    const int q = wave * 64 + lane;
-    const int p = q >> 1, s = q & 1;
-    const int gy = ty0 + (p >> 5), gx = tx0 + (p & 31);
-    const int cg = s ^ ((p >> 3) & 1);
-    const bool ok = gy < H && gx < W;
-    const unsigned vo = ok ? (unsigned)((((long long)img * H + gy) * W + gx) * 32 + cg * 16) : 0x80000000u;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(lds + wave * 1024), 16, vo, 0, 0, 0);
+struct W1Plan { int ppw, tr, cgroups, ppg; unsigned lds; };
+static inline W1Plan w1_plan(int ncp) {
+    W1Plan p;
+    p.ppw = ncp <= W1_NW ? 1 : 2;
+    const int cap = W1_NW * p.ppw;
+    p.cgroups = (ncp + cap - 1) / cap;
+    p.ppg = (ncp + p.cgroups - 1) / p.cgroups;
+    const int slots = 2 * (2 * W1_NCOT + 2 * p.ppg);     // sized for two planes (f16x3); f16 uses half of it
+    p.tr = (p.ppw == 1 && 2 * slots * 2 * 1024 <= 160 * 1024) ? 2 : 1;
+    p.lds = 2u * slots * p.tr * 1024;
+    return p;
 }
 
-template <int NT>
-__global__ void __launch_bounds__(256)
+template <int NT, int PPW, int TR>
+__global__ void __launch_bounds__(64 * W1_NW)
 wgrad1x1_kernel(const WgradKArgs a) {
-    using C = W1Cfg<NT>;
+    constexpr int NPL = (NT == 3) ? 2 : 1;
+    constexpr int CH = TR * 1024;                         // one chunk strip: TR rows x 32 px x 32 B
+    constexpr int GSLOTS = NPL * 2 * W1_NCOT;
+    constexpr int PAIR_BYTES = NPL * 2 * CH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pb = blockIdx.x;
-    const int cpg = blockIdx.y;                   // group of W1_NCPB channel pairs
-    const int cp0 = cpg * W1_NCPB;
+    const int cpg = blockIdx.y;
+    const int ppg = a.ppg;
+    const int cp0 = cpg * ppg;
     const long long plane_elems = (long long)a.N * a.H * a.W * 16;
     const unsigned plane_bytes = (unsigned)(plane_elems * 2);
-    const bool do_bias = (cpg == 0);
-    char* gbuf = smem;                            // [2][NPL][6 chunks][4 KiB]
-    char* xbuf = smem + 2 * C::G_BYTES;           // [2][NPL][2 chunks][4 KiB]
+    const int nslots = GSLOTS + ppg * NPL * 2;
+    const int stage_bytes = nslots * CH;
+    const bool bias_wave = (cpg == 0) && (wave == W1_NW - 1);
 
-    floatx16 acc[W1_NCPB][W1_NCOT];
-    float bsum[W1_NCOT] = {0.f, 0.f, 0.f};   // bias: per-lane sum of this lane's gY fragment elements (co = lane & 31)
+    bool valid[PPW];
 #pragma unroll
-    for (int i = 0; i < W1_NCPB; ++i)
+    for (int i = 0; i < PPW; ++i) valid[i] = (wave * PPW + i < ppg) && (cp0 + wave * PPW + i < a.ncp);
+
+    floatx16 acc[PPW][W1_NCOT];
+    float bsum[W1_NCOT] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < PPW; ++i)
 #pragma unroll
         for (int j = 0; j < W1_NCOT; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // issue helpers are inlined by hand (no lambdas in kernels): gY tile of `tile` into g-buffer gb, X pair cp into x-buffer xb
-#define W1_TILE_COORDS(tile_)                                   \
-    int b_ = (tile_);                                           \
-    const int tx_ = b_ % a.tiles_x; b_ /= a.tiles_x;            \
-    const int ty_ = b_ % a.tiles_y;                             \
-    const int img_ = b_ / a.tiles_y;                            \
-    const int tx0_ = tx_ * 32, ty0_ = ty_ * W1_TH;
-#define W1_ISSUE_G(tile_, gb_)                                                                                         \
-    {                                                                                                                  \
-        W1_TILE_COORDS(tile_)                                                                                          \
-        _Pragma("unroll") for (int pl = 0; pl < C::NPL; ++pl)                                                          \
-        _Pragma("unroll") for (int c6 = 0; c6 < 2 * W1_NCOT; ++c6)                                                     \
-            w1_issue_chunk<NT>(pl ? a.g_lo : a.g_hi, (long long)c6 * plane_elems, c6 < a.cout_chunks, plane_bytes,     \
-                               gbuf + (gb_) * C::G_BYTES + (pl * 2 * W1_NCOT + c6) * C::CH_BYTES, img_, ty0_, tx0_,    \
-                               a.H, a.W, wave, lane);                                                                  \
-    }
-#define W1_ISSUE_X(tile_, cp_, xb_)                                                                                    \
-    {                                                                                                                  \
-        W1_TILE_COORDS(tile_)                                                                                          \
-        _Pragma("unroll") for (int pl = 0; pl < C::NPL; ++pl)                                                          \
-        _Pragma("unroll") for (int hh = 0; hh < 2; ++hh) {                                                             \
-            const int c = 2 * (cp_) + hh;                                                                              \
-            const long long coff = (a.x_cpg > 0)                                                                       \
-                ? (long long)(c / a.x_cpg) * a.x_group_stride + (long long)(c % a.x_cpg) * plane_elems                 \
-                : (long long)c * plane_elems;                                                                          \
-            w1_issue_chunk<NT>(pl ? a.x_lo : a.x_hi, coff, c < a.cin_chunks, plane_bytes,                              \
-                               xbuf + (xb_) * C::X_BYTES + (pl * 2 + hh) * C::CH_BYTES, img_, ty0_, tx0_, a.H, a.W,    \
-                               wave, lane);                                                                            \
-        }                                                                                                              \
-    }
+    // per-lane part of a DMA piece (one 32-pixel row of one chunk = 1 KiB): pixel lane/2, 16-byte half swizzled by pixel/8
+    const int lp = lane >> 1;
+    const unsigned lane_off = (unsigned)(lp * 32 + (((lane & 1) ^ ((lp >> 3) & 1)) << 4));
+    const unsigned tr_off = tr_lane_off(CH, lane);
+
+    auto issue = [&](int tile, int buf) {
+        int b = tile;
+        const int tx = b % a.tiles_x; b /= a.tiles_x;
+        const int ty = b % a.tiles_y;
+        const int img = b / a.tiles_y;
+        const int tx0 = tx * 32, ty0 = ty * TR;
+        const bool col_ok = tx0 + lp < a.W;
+        char* stage = smem + buf * stage_bytes;
+        for (int k = wave; k < nslots * TR; k += W1_NW) {
+            const int slot = k / TR, r = k % TR;
+            const _Float16* src;
+            bool have;
+            if (slot < GSLOTS) {
+                const int pl = slot / (2 * W1_NCOT), c6 = slot % (2 * W1_NCOT);
+                have = c6 < a.cout_chunks;
+                src = (pl ? a.g_lo : a.g_hi) + (long long)c6 * plane_elems;
+            } else {
+                const int xs = slot - GSLOTS;
+                const int pr = xs / (NPL * 2), rem = xs % (NPL * 2);
+                const int pl = rem >> 1, c = 2 * (cp0 + pr) + (rem & 1);
+                have = c < a.cin_chunks;
+                const long long coff = (a.x_cpg > 0)
+                    ? (long long)(c / a.x_cpg) * a.x_group_stride + (long long)(c % a.x_cpg) * plane_elems
+                    : (long long)c * plane_elems;
+                src = (pl ? a.x_lo : a.x_hi) + (have ? coff : 0);
+            }
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, have ? plane_bytes : 0u, 0x00020000);
+            const int gy = ty0 + r;
+            const bool ok = col_ok && gy < a.H;
+            const unsigned vo = ok ? (unsigned)((((long long)img * a.H + gy) * a.W + tx0) * 32) + lane_off : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(stage + slot * CH + r * 1024), 16, vo, 0, 0, 0);
+        }
+    };
 
     int tile = pb;
-    int gb = 0, xb = 0;
-    if (tile < a.ntiles && !(a.dbg & 1)) {
-        W1_ISSUE_G(tile, 0)
-        W1_ISSUE_X(tile, cp0, 0)
-    }
+    int buf = 0;
+    if (tile < a.ntiles && !(a.dbg & 1)) issue(tile, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (; tile < a.ntiles; tile += a.PB) {
-        const int nxt_tile = tile + a.PB;
-        half8 Bh[2][W1_NCOT], Bl[2][W1_NCOT];
+        if (tile + a.PB < a.ntiles && !(a.dbg & 1)) issue(tile + a.PB, buf ^ 1);
         if (!(a.dbg & 2)) {
-            const char* gbase = gbuf + gb * C::G_BYTES;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+            const unsigned gst = lds_addr(smem + buf * stage_bytes) + tr_off;
+            const unsigned xst = gst + GSLOTS * CH + wave * PPW * PAIR_BYTES;
+            // fragments of pixel step ks + 1 are in flight while step ks multiplies
+            TrFrag Bh[2][W1_NCOT], Bl[2][W1_NCOT], Ah[2][PPW], Al[2][PPW];
+            auto load = [&](int ks, int q) {
 #pragma unroll
                 for (int j = 0; j < W1_NCOT; ++j) {
-                    Bh[ks][j] = tr_frag(gbase + j * 2 * C::CH_BYTES, C::CH_BYTES, wave * 32 + ks * 16, lane);
-                    if constexpr (NT == 3)
-                        Bl[ks][j] = tr_frag(gbase + (2 * W1_NCOT + j * 2) * C::CH_BYTES, C::CH_BYTES, wave * 32 + ks * 16, lane);
+                    tr_issue(Bh[q][j], gst + 2 * j * CH + ks * 512);
+                    if constexpr (NT == 3) tr_issue(Bl[q][j], gst + (2 * W1_NCOT + 2 * j) * CH + ks * 512);
                 }
-            if (do_bias) {
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
+                for (int i = 0; i < PPW; ++i) {
+                    tr_issue(Ah[q][i], xst + i * PAIR_BYTES + ks * 512);
+                    if constexpr (NT == 3) tr_issue(Al[q][i], xst + i * PAIR_BYTES + 2 * CH + ks * 512);
+                }
+            };
+            load(0, 0);
 #pragma unroll
-                    for (int j = 0; j < W1_NCOT; ++j) {
+            for (int ks = 0; ks < 2 * TR; ++ks) {
+                const int q = ks & 1;
+                // everything outstanding belongs to step ks; tie its registers to the wait so no use moves above it
+                if constexpr (NT == 3) {
+                    if constexpr (PPW == 2)
+                        asm volatile("s_waitcnt lgkmcnt(0)"
+                                     : "+v"(Bh[q][0].a), "+v"(Bh[q][0].b), "+v"(Bh[q][1].a), "+v"(Bh[q][1].b), "+v"(Bh[q][2].a),
+                                       "+v"(Bh[q][2].b), "+v"(Bl[q][0].a), "+v"(Bl[q][0].b), "+v"(Bl[q][1].a), "+v"(Bl[q][1].b),
+                                       "+v"(Bl[q][2].a), "+v"(Bl[q][2].b), "+v"(Ah[q][0].a), "+v"(Ah[q][0].b), "+v"(Al[q][0].a),
+                                       "+v"(Al[q][0].b), "+v"(Ah[q][PPW - 1].a), "+v"(Ah[q][PPW - 1].b), "+v"(Al[q][PPW - 1].a),
+                                       "+v"(Al[q][PPW - 1].b));
+                    else
+                        asm volatile("s_waitcnt lgkmcnt(0)"
+                                     : "+v"(Bh[q][0].a), "+v"(Bh[q][0].b), "+v"(Bh[q][1].a), "+v"(Bh[q][1].b), "+v"(Bh[q][2].a),
+                                       "+v"(Bh[q][2].b), "+v"(Bl[q][0].a), "+v"(Bl[q][0].b), "+v"(Bl[q][1].a), "+v"(Bl[q][1].b),
+                                       "+v"(Bl[q][2].a), "+v"(Bl[q][2].b), "+v"(Ah[q][0].a), "+v"(Ah[q][0].b), "+v"(Al[q][0].a),
+                                       "+v"(Al[q][0].b));
+                } else {
+                    if constexpr (PPW == 2)
+                        asm volatile("s_waitcnt lgkmcnt(0)"
+                                     : "+v"(Bh[q][0].a), "+v"(Bh[q][0].b), "+v"(Bh[q][1].a), "+v"(Bh[q][1].b), "+v"(Bh[q][2].a),
+                                       "+v"(Bh[q][2].b), "+v"(Ah[q][0].a), "+v"(Ah[q][0].b), "+v"(Ah[q][PPW - 1].a),
+                                       "+v"(Ah[q][PPW - 1].b));
+                    else
+                        asm volatile("s_waitcnt lgkmcnt(0)"
+                                     : "+v"(Bh[q][0].a), "+v"(Bh[q][0].b), "+v"(Bh[q][1].a), "+v"(Bh[q][1].b), "+v"(Bh[q][2].a),
+                                       "+v"(Bh[q][2].b), "+v"(Ah[q][0].a), "+v"(Ah[q][0].b));
+                }
+                if (ks + 1 < 2 * TR) load(ks + 1, q ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                half8 bh[W1_NCOT], bl[W1_NCOT];
+#pragma unroll
+                for (int j = 0; j < W1_NCOT; ++j) {
+                    bh[j] = tr_value(Bh[q][j]);
+                    if constexpr (NT == 3) bl[j] = tr_value(Bl[q][j]);
+                }
+                if (bias_wave) {
+#pragma unroll
+                    for (int j = 0; j < W1_NCOT; ++j)
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            bsum[j] += (float)Bh[ks][j][e];
-                            if constexpr (NT == 3) bsum[j] += (float)Bl[ks][j][e];
+                            bsum[j] += (float)bh[j][e];
+                            if constexpr (NT == 3) bsum[j] += (float)bl[j][e];
                         }
-                    }
-            }
-        }
-#pragma unroll
-        for (int cpl = 0; cpl < W1_NCPB; ++cpl) {
-            // prefetch: next channel pair of this tile, or the next tile's gY + first pair
-            if (!(a.dbg & 1)) {
-                if (cpl + 1 < W1_NCPB) {
-                    if (cp0 + cpl + 1 < a.ncp) W1_ISSUE_X(tile, cp0 + cpl + 1, xb ^ 1)
-                } else if (nxt_tile < a.ntiles) {
-                    W1_ISSUE_G(nxt_tile, gb ^ 1)
-                    W1_ISSUE_X(nxt_tile, cp0, xb ^ 1)
                 }
-            }
-            if (cp0 + cpl < a.ncp && !(a.dbg & 2)) {
-                const char* xbase = xbuf + xb * C::X_BYTES;
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const half8 Ah = tr_frag(xbase, C::CH_BYTES, wave * 32 + ks * 16, lane);
-                    half8 Al;
-                    if constexpr (NT == 3) Al = tr_frag(xbase + 2 * C::CH_BYTES, C::CH_BYTES, wave * 32 + ks * 16, lane);
+                for (int i = 0; i < PPW; ++i) {
+                    if (!valid[i]) continue;
+                    const half8 ah = tr_value(Ah[q][i]);
+                    half8 al;
+                    if constexpr (NT == 3) al = tr_value(Al[q][i]);
 #pragma unroll
                     for (int j = 0; j < W1_NCOT; ++j) {
                         if constexpr (NT == 3) {
-                            acc[cpl][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh[ks][j], acc[cpl][j], 0, 0, 0);
-                            acc[cpl][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl[ks][j], acc[cpl][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc[i][j], 0, 0, 0);
                         }
-                        acc[cpl][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh[ks][j], acc[cpl][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[i][j], 0, 0, 0);
                     }
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            xb ^= 1;
         }
-        gb ^= 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        buf ^= 1;
     }
-#undef W1_ISSUE_G
-#undef W1_ISSUE_X
-#undef W1_TILE_COORDS
 
     if (a.dbg & 4) { if (acc[0][0][0] == 12345.f) a.partial[0] = bsum[0]; return; }
-    // ---- reduce the 4 waves through LDS; partial layout identical to the generic kernel (ntap = 1, z = co tile)
-    float* red = reinterpret_cast<float*>(smem);
+    // ---- every accumulator tile is complete in its wave: straight to the partial buffer (layout of the generic kernel,
+    // ntap = 1, z = co tile; 32 lanes = 32 consecutive floats)
     const int n = lane & 31, hi = lane >> 5;
 #pragma unroll
-    for (int cpl = 0; cpl < W1_NCPB; ++cpl) {
-        const bool cp_valid = cp0 + cpl < a.ncp;          // block-uniform
+    for (int i = 0; i < PPW; ++i) {
+        if (!valid[i]) continue;
+        const int cp = cp0 + wave * PPW + i;
 #pragma unroll
         for (int j = 0; j < W1_NCOT; ++j) {
-            if (!cp_valid) continue;
-            __syncthreads();
+            if (j >= a.ncot) continue;
+            float* dst = a.partial + (((long long)j * a.ncp + cp) * a.PB + pb) * 1024 + n;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = (e & 3) + 8 * (e >> 2) + 4 * hi;
-                red[wave * 1024 + m * 32 + n] = acc[cpl][j][e];
-            }
-            __syncthreads();
-            if (j < a.ncot) {
-                const long long blk = ((long long)j * a.ncp + (cp0 + cpl)) * a.PB + pb;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int idx = tid + 256 * i;
-                    a.partial[blk * 1024 + idx] = (red[idx] + red[1024 + idx]) + (red[2048 + idx] + red[3072 + idx]);
-                }
-            }
+            for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2) + 4 * hi) * 32] = acc[i][j][e];
         }
     }
-    if (do_bias) {
+    if (bias_wave) {
+        // a gY fragment lane holds 8 pixels of output channel lane & 31; lanes l and l + 32 hold the two pixel halves
 #pragma unroll
         for (int j = 0; j < W1_NCOT; ++j) {
-            __syncthreads();
-            red[tid] = bsum[j];                       // [wave][kg][co]
-            __syncthreads();
-            if (tid < 32 && j < a.ncot) {
-                float t = 0.f;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) t += red[k * 32 + tid];
-                a.partial_b[((long long)j * a.PB + pb) * 32 + tid] = t;
-            }
+            const float t = bsum[j] + __shfl_xor(bsum[j], 32);
+            if (lane < 32 && j < a.ncot) a.partial_b[((long long)j * a.PB + pb) * 32 + lane] = t;
         }
     }
 }
@@ -629,11 +670,11 @@ WgGeom wg_geom(int ksize, int N, int H, int W, int cin_chunks, int cout, int cus
         g.tr = 1; g.ndyg = 1; g.ntap = 1;
         g.ncp = (cin_chunks + 1) / 2;
         g.ncot = (cout + 31) / 32;
+        const W1Plan wp = w1_plan(g.ncp);
         g.tiles_x = (W + 31) / 32;
-        g.tiles_y = (H + W1_TH - 1) / W1_TH;
+        g.tiles_y = (H + wp.tr - 1) / wp.tr;
         g.ntiles = g.tiles_x * g.tiles_y * N;
-        const int cgroups = (g.ncp + W1_NCPB - 1) / W1_NCPB;
-        int pb = (cus > 0 ? cus : 256) / cgroups;
+        int pb = (cus > 0 ? cus : 256) / wp.cgroups;      // one workgroup per CU (the LDS is all staging buffer)
         if (pb < 1) pb = 1;
         if (pb > g.ntiles) pb = g.ntiles;
         g.PB = pb;
@@ -678,6 +719,16 @@ int launch_wg_sb(const WgradKArgs& a, const WgGeom& g, hipStream_t s) {
     if (int rc = bh_set_max_lds(&wgrad_mfma_sb_kernel<KS, TR, NT>, LDS, lds_set)) return rc;
     dim3 grid((unsigned)g.PB, (unsigned)g.ncp, (unsigned)(g.ncot * g.ndyg));
     wgrad_mfma_sb_kernel<KS, TR, NT><<<grid, dim3(256), LDS, s>>>(a);
+    BH_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int NT, int PPW, int TR>
+int launch_w1(const WgradKArgs& a, const WgGeom& g, const W1Plan& wp, hipStream_t s) {
+    static std::atomic<unsigned long long> lds_set{0};
+    if (int rc = bh_set_max_lds(&wgrad1x1_kernel<NT, PPW, TR>, 160 * 1024, lds_set)) return rc;
+    const unsigned lds = (NT == 3) ? wp.lds : wp.lds / 2;
+    wgrad1x1_kernel<NT, PPW, TR><<<dim3((unsigned)g.PB, (unsigned)wp.cgroups), dim3(64 * W1_NW), lds < 16384 ? 16384 : lds, s>>>(a);
     BH_CHECK_LAUNCH();
     return 0;
 }
@@ -735,24 +786,16 @@ int bh_wgrad_partials(const BinConvDesc* d, const void* x_hi, const void* x_lo, 
     a.N = d->N; a.H = d->H; a.W = d->W;
     a.cin_chunks = d->cin_chunks; a.cout_chunks = (d->cout + 15) / 16;
     a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.ntiles = g.ntiles;
-    a.PB = g.PB; a.ncp = g.ncp; a.ncot = g.ncot;
+    a.PB = g.PB; a.ncp = g.ncp; a.ncot = g.ncot; a.ppg = 0;
     a.dbg = WG_DBG & 15;
     hipStream_t s = (hipStream_t)stream;
     int rc = BINHIP_E_SHAPE;
     if (use_w1(d->ksize, d->cout)) {
-        const int cgroups = (g.ncp + W1_NCPB - 1) / W1_NCPB;
-        dim3 grid((unsigned)g.PB, (unsigned)cgroups);
-        if (d->nterms == 1) {
-            static std::atomic<unsigned long long> set1{0};
-            if (int rc1 = bh_set_max_lds(&wgrad1x1_kernel<1>, W1Cfg<1>::LDS_BYTES, set1)) return rc1;
-            wgrad1x1_kernel<1><<<grid, dim3(256), W1Cfg<1>::LDS_BYTES, s>>>(a);
-        } else {
-            static std::atomic<unsigned long long> set3{0};
-            if (int rc3 = bh_set_max_lds(&wgrad1x1_kernel<3>, W1Cfg<3>::LDS_BYTES, set3)) return rc3;
-            wgrad1x1_kernel<3><<<grid, dim3(256), W1Cfg<3>::LDS_BYTES, s>>>(a);
-        }
-        BH_CHECK_LAUNCH();
-        rc = 0;
+        const W1Plan wp = w1_plan(g.ncp);
+        a.ppg = wp.ppg;
+        rc = (d->nterms == 1)
+            ? (wp.ppw == 2 ? launch_w1<1, 2, 1>(a, g, wp, s) : wp.tr == 2 ? launch_w1<1, 1, 2>(a, g, wp, s) : launch_w1<1, 1, 1>(a, g, wp, s))
+            : (wp.ppw == 2 ? launch_w1<3, 2, 1>(a, g, wp, s) : wp.tr == 2 ? launch_w1<3, 1, 2>(a, g, wp, s) : launch_w1<3, 1, 1>(a, g, wp, s));
     } else if (d->ksize == 3 && !(WG_DBG & 16)) {   // default: lean 2-workgroup/CU kernel; flag 16 = the double-buffered one
         rc = (d->nterms == 1) ? launch_wg_sb<3, 3, 1>(a, g, s) : launch_wg_sb<3, 3, 3>(a, g, s);
     } else if (d->nterms == 1) {

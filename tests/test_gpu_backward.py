@@ -59,6 +59,29 @@ def test_wgrad_ragged(nterms, shape):
     assert _rel(db.cpu().double(), b.grad) <= TOL[nterms]
 
 
+@pytest.mark.parametrize("nterms", [3, 1])
+@pytest.mark.parametrize("cfg", [(1, 5, 7, 40, 35), (2, 19, 45, 224, 96), (1, 8, 32, 16, 96), (1, 33, 70, 600, 64),
+                                 (3, 6, 40, 272, 96), (1, 130, 64, 1152, 96)])
+def test_wgrad_1x1_ragged(nterms, cfg):
+    """the streaming 1x1 kernel: one / two channel pairs per wave, 1-3 workgroup columns, odd chunk counts, strips that hang
+    over the right and bottom edges, more workgroups than strips (reference: autograd of F.conv2d, RDN.py:141,162)."""
+    from bin_amd import ops
+    n, h, w, cin, cout = cfg
+    gen = torch.Generator().manual_seed(h * 100 + w + cin)
+    x = torch.randn(n, cin, h, w, generator=gen, dtype=torch.float64)
+    gy = torch.randn(n, cout, h, w, generator=gen, dtype=torch.float64)
+    wt = torch.zeros(cout, cin, 1, 1, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(x, wt, b).backward(gy)
+    dw, db = ops.conv2d_bwd_weight(ops.nchw_to_planes(x.float().cuda(), nterms),
+                                   ops.nchw_to_planes(gy.float().cuda(), nterms), cout, cin, 1, nterms)
+    assert _rel(dw.cpu().double(), wt.grad) <= TOL[nterms]
+    assert _rel(db.cpu().double(), b.grad) <= TOL[nterms]
+    dw2, db2 = ops.conv2d_bwd_weight(ops.nchw_to_planes(x.float().cuda(), nterms),
+                                     ops.nchw_to_planes(gy.float().cuda(), nterms), cout, cin, 1, nterms)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2), "fixed summation order"
+
+
 def test_convlstm_backward_vs_autograd(canon_cpu, canon_gpu):
     from bin_amd.autograd import convlstm_apply
     from oracle import rdn_oracle as O
