@@ -460,7 +460,10 @@ def main():
                     "traffic": pmc_traffic(prec), "avg_kernel_us": round(avg_s * 1e6, 2), "launches": kern_n.value,
                     "algorithmic_bytes_per_launch": int(ab), "bytes_per_element": BYTES_PER_ELEM[prec],
                     "mfma": {"achieved": round(mf, 1), "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(mf / MFMA_PEAK_TF, 4),
-                             "note": f"executed MFMA FLOPs = {PRODUCTS[prec]} x the conv's algorithmic FLOPs"},
+                             "note": f"executed MFMA FLOPs = {PRODUCTS[prec]} x the conv's algorithmic FLOPs",
+                             "sustained_at_power_cap": {"random_fp16": 1663.0, "zeros": 2473.0, "unit": "TFLOP/s",
+                                                        "source": "profiles/r02_power_cap.md: register-resident v_mfma_f32_32x32x16_f16 "
+                                                                  "alone, tools/probe_mfma_power.hip (not measured in this run)"}},
                     "whole_forward": {"algorithmic_GB": round(abytes / 1e9, 1), "achieved_GBs": round(whole_gbs, 1),
                                       "frac_hbm": round(whole_gbs / HBM_PEAK_GBS, 4),
                                       "achieved_TFLOPs": round(flops / (ms * 1e-3) / 1e12, 1),
