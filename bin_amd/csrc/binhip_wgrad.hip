@@ -92,6 +92,18 @@ __device__ __forceinline__ void tr_issue(TrFrag& f, unsigned addr) {      // add
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.a) : "v"(addr));
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:128" : "=v"(f.b) : "v"(addr));
 }
+// general pixel offset (tap-shifted patches): both 4-pixel reads get their own swizzled address
+__device__ __forceinline__ void tr_issue_at(TrFrag& f, const char* img, int chunk_bytes, int p0, int lane) {
+    const int t = lane & 15, ch = (lane >> 4) & 1, kg = lane >> 5;
+    const unsigned base = lds_addr(img + ch * chunk_bytes) + ((t & 1) << 3);
+    const int pa = p0 + kg * 8 + (t >> 2), pb = pa + 4;
+    const unsigned oa = base + pa * 32 + ((((t & 3) >> 1) ^ ((pa >> 3) & 1)) << 4);
+    const unsigned ob = base + pb * 32 + ((((t & 3) >> 1) ^ ((pb >> 3) & 1)) << 4);
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.a) : "v"(oa));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.b) : "v"(ob));
+}
+// after an `s_waitcnt lgkmcnt(0)` asm: re-defines the fragment's registers so that no use can be scheduled above the wait
+__device__ __forceinline__ void tr_tie(TrFrag& f) { asm volatile("" : "+v"(f.a), "+v"(f.b)); }
 __device__ __forceinline__ half8 tr_value(const TrFrag& f) {
     union { struct { short4_ a, b; } s; half8 h; } u;
     u.s.a = f.a; u.s.b = f.b;
@@ -202,43 +214,49 @@ wgrad_mfma_kernel(const WgradKArgs a) {
         // 4 K-steps per wave and tile (2 rows x 2 half-rows of 16 pixels), software-pipelined: the transpose reads of
         // K-step s+1 are issued before the MFMAs of K-step s (a workgroup is alone on its CU, one wave per SIMD, so
         // nothing else hides the LDS latency); sched_barriers keep the scheduler from sinking the reads again.
-        half8 Bh[2], Bl[2], Ah[2][C::NTAP], Al[2][C::NTAP];
-        {
-            const int row = wave * 2, x0 = 0;
-            Bh[0] = tr_frag(gb, C::GBYTES, row * 32 + x0, lane);
-            if constexpr (NT == 3) Bl[0] = tr_frag(gb + C::PLANE_BYTES, C::GBYTES, row * 32 + x0, lane);
+        // The reads are issued from asm (tr_issue_at): the builtin would be fenced with vmcnt(0) against the prefetch above.
+        TrFrag Bh[2], Bl[2], Ah[2][C::NTAP], Al[2][C::NTAP];
+        auto load = [&](int s4, int q) {
+            const int row = wave * 2 + (s4 >> 1), x0 = (s4 & 1) * 16;
+            tr_issue_at(Bh[q], gb, C::GBYTES, row * 32 + x0, lane);
+            if constexpr (NT == 3) tr_issue_at(Bl[q], gb + C::PLANE_BYTES, C::GBYTES, row * 32 + x0, lane);
 #pragma unroll
             for (int t = 0; t < C::NTAP; ++t) {
                 const int p0 = (row + t / KS) * C::PW + x0 + t % KS;
-                Ah[0][t] = tr_frag(xb, C::XBYTES, p0, lane);
-                if constexpr (NT == 3) Al[0][t] = tr_frag(xb + C::PLANE_BYTES, C::XBYTES, p0, lane);
+                tr_issue_at(Ah[q][t], xb, C::XBYTES, p0, lane);
+                if constexpr (NT == 3) tr_issue_at(Al[q][t], xb + C::PLANE_BYTES, C::XBYTES, p0, lane);
             }
-        }
+        };
+        load(0, 0);
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
-            if (s4 + 1 < 4) {
-                const int row = wave * 2 + ((s4 + 1) >> 1), x0 = ((s4 + 1) & 1) * 16;
-                Bh[(s4 + 1) & 1] = tr_frag(gb, C::GBYTES, row * 32 + x0, lane);
-                if constexpr (NT == 3) Bl[(s4 + 1) & 1] = tr_frag(gb + C::PLANE_BYTES, C::GBYTES, row * 32 + x0, lane);
+            const int q = s4 & 1;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            tr_tie(Bh[q]);
+            if constexpr (NT == 3) tr_tie(Bl[q]);
 #pragma unroll
-                for (int t = 0; t < C::NTAP; ++t) {
-                    const int p0 = (row + t / KS) * C::PW + x0 + t % KS;
-                    Ah[(s4 + 1) & 1][t] = tr_frag(xb, C::XBYTES, p0, lane);
-                    if constexpr (NT == 3) Al[(s4 + 1) & 1][t] = tr_frag(xb + C::PLANE_BYTES, C::XBYTES, p0, lane);
-                }
+            for (int t = 0; t < C::NTAP; ++t) {
+                tr_tie(Ah[q][t]);
+                if constexpr (NT == 3) tr_tie(Al[q][t]);
             }
+            if (s4 + 1 < 4) load(s4 + 1, q ^ 1);
             __builtin_amdgcn_sched_barrier(0);
+            const half8 bh = tr_value(Bh[q]);
+            half8 bl;
+            if constexpr (NT == 3) bl = tr_value(Bl[q]);
             if (do_bias) {
-                accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, Bh[s4 & 1], accb, 0, 0, 0);
-                if constexpr (NT == 3) accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, Bl[s4 & 1], accb, 0, 0, 0);
+                accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, bh, accb, 0, 0, 0);
+                if constexpr (NT == 3) accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, bl, accb, 0, 0, 0);
             }
 #pragma unroll
             for (int t = 0; t < C::NTAP; ++t) {
+                const half8 ah = tr_value(Ah[q][t]);
                 if constexpr (NT == 3) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[s4 & 1][t], Bh[s4 & 1], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[s4 & 1][t], Bl[s4 & 1], acc[t], 0, 0, 0);
+                    const half8 al = tr_value(Al[q][t]);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
                 }
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[s4 & 1][t], Bh[s4 & 1], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -796,16 +814,16 @@ int bh_wgrad_partials(const BinConvDesc* d, const void* x_hi, const void* x_lo, 
         rc = (d->nterms == 1)
             ? (wp.ppw == 2 ? launch_w1<1, 2, 1>(a, g, wp, s) : wp.tr == 2 ? launch_w1<1, 1, 2>(a, g, wp, s) : launch_w1<1, 1, 1>(a, g, wp, s))
             : (wp.ppw == 2 ? launch_w1<3, 2, 1>(a, g, wp, s) : wp.tr == 2 ? launch_w1<3, 1, 2>(a, g, wp, s) : launch_w1<3, 1, 1>(a, g, wp, s));
-    } else if (d->ksize == 3 && !(WG_DBG & 16)) {   // default: lean 2-workgroup/CU kernel; flag 16 = the double-buffered one
+#if BINHIP_TUNING
+    } else if (d->ksize == 3 && (WG_DBG & 16)) {    // side builds: the double-buffered one-workgroup-per-CU kernel for 3x3
+        rc = (d->nterms == 1) ? launch_wg<3, 3, 1>(a, g, s) : launch_wg<3, 3, 3>(a, g, s);
+#endif
+    } else if (d->ksize == 3) {                     // lean kernel, two workgroups per CU
         rc = (d->nterms == 1) ? launch_wg_sb<3, 3, 1>(a, g, s) : launch_wg_sb<3, 3, 3>(a, g, s);
-    } else if (d->nterms == 1) {
-        if (d->ksize == 3) rc = launch_wg<3, 3, 1>(a, g, s);
-        else if (d->ksize == 1) rc = launch_wg<1, 1, 1>(a, g, s);
-        else rc = launch_wg<5, 1, 1>(a, g, s);
-    } else {
-        if (d->ksize == 3) rc = launch_wg<3, 3, 3>(a, g, s);
-        else if (d->ksize == 1) rc = launch_wg<1, 1, 3>(a, g, s);
-        else rc = launch_wg<5, 1, 3>(a, g, s);
+    } else if (d->ksize == 1) {                     // 1x1 with more than 96 outputs (not on the bin_stage4 path)
+        rc = (d->nterms == 1) ? launch_wg<1, 1, 1>(a, g, s) : launch_wg<1, 1, 3>(a, g, s);
+    } else {                                        // 5x5 (SFENet1)
+        rc = (d->nterms == 1) ? launch_wg<5, 1, 1>(a, g, s) : launch_wg<5, 1, 3>(a, g, s);
     }
     if (rc) return rc;
     out->partial = a.partial; out->partial_b = a.partial_b;

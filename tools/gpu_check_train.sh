@@ -2,7 +2,7 @@
 # backward-path check: the backward / round-2 GPU tests, the training bench line, and the training kernel table
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out; export TMPDIR=/tmp
-( timeout 900 python -m pytest tests/test_gpu_backward.py tests/test_gpu_round2.py -q -x 2>&1 | tail -5 ) > gpurun_out/ct_pytest.log 2>&1
+( timeout 900 python -m pytest tests/test_gpu_backward.py tests/test_gpu_round2.py -q -x 2>&1 | grep -E "passed|failed|rror|^E " | tail -8 ) > gpurun_out/ct_pytest.log 2>&1
 cat gpurun_out/ct_pytest.log
 ( timeout 300 python bench.py --mode train 2>&1 | tail -1 ) > gpurun_out/ct_bench_train.json 2>&1
 grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*' gpurun_out/ct_bench_train.json
