@@ -24,6 +24,14 @@
 #ifndef BINHIP_ABLATE
 #define BINHIP_ABLATE 0
 #endif
+// wave tile of the default instantiation: R output rows per wave, WN waves per workgroup (tile = R*WN x 32 pixels); side builds
+// (tools/) override it to measure other shapes
+#ifndef BINHIP_X3_R
+#define BINHIP_X3_R 2
+#endif
+#ifndef BINHIP_X3_WN
+#define BINHIP_X3_WN 8
+#endif
 
 template <int KS, int R, int WN>
 struct X3Cfg {
@@ -203,7 +211,7 @@ __device__ __forceinline__ void x3_tile(const ConvKArgs& a, char* smem, int img,
 // WIDE only names the instantiation: 0 = one 32-row output block (the dense-block convs, UPNet.2), 1 = several workgroup
 // columns — same code, separate symbols, so per-kernel profiles keep the dominant dense-block conv apart from the wide layers
 template <int KS, int R, int WN, int EPI, int WIDE>
-__global__ void __launch_bounds__(64 * WN) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ void __launch_bounds__(64 * WN) __attribute__((amdgpu_waves_per_eu(WN / 2, WN / 2)))
 conv_x3_kernel(const ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // 1-D grid of tiles x output columns, column fastest: after the XCD banding the `ncol` workgroups that share one input
@@ -246,7 +254,7 @@ struct Rdb3Args {
 constexpr unsigned RDB3_SPIN_LIMIT = 1u << 22;
 
 template <int R, int WN>
-__global__ void __launch_bounds__(64 * WN) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ void __launch_bounds__(64 * WN) __attribute__((amdgpu_waves_per_eu(WN / 2, WN / 2)))
 conv_x3_rdb3_kernel(const Rdb3Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ unsigned s_idx;
@@ -308,9 +316,9 @@ static int launch_x3(const ConvKArgs& ka, int cout_pad, hipStream_t s) {
 // the three-phase dense-block launch: `convs` are the fully prepared kernel arguments of convs 0, 1, 2 (same N, H, W;
 // write-through stores required), `sync` = [counter][2 * T flags] device words, counter zeroed by the caller
 int bh_launch_rdb3_x3(const ConvKArgs* convs, unsigned* counter, unsigned* flags, unsigned epoch, int cus, hipStream_t s) {
-    using C = X3Cfg<3, 2, 8>;
+    using C = X3Cfg<3, BINHIP_X3_R, BINHIP_X3_WN>;
     static std::atomic<unsigned long long> lds_set{0};
-    if (int rc = bh_set_max_lds(&conv_x3_rdb3_kernel<2, 8>, C::LDS_BYTES, lds_set)) return rc;
+    if (int rc = bh_set_max_lds(&conv_x3_rdb3_kernel<BINHIP_X3_R, BINHIP_X3_WN>, C::LDS_BYTES, lds_set)) return rc;
     Rdb3Args a;
     for (int p = 0; p < 3; ++p) {
         a.conv[p] = convs[p];
@@ -323,7 +331,7 @@ int bh_launch_rdb3_x3(const ConvKArgs* convs, unsigned* counter, unsigned* flags
     const long long items = 3ll * a.T;
     const long long slots = 2ll * (cus > 0 ? cus : 256);
     const unsigned grid = (unsigned)(items < slots ? items : slots);
-    conv_x3_rdb3_kernel<2, 8><<<dim3(grid), dim3(64 * C::NW), C::LDS_BYTES, s>>>(a);
+    conv_x3_rdb3_kernel<BINHIP_X3_R, BINHIP_X3_WN><<<dim3(grid), dim3(64 * C::NW), C::LDS_BYTES, s>>>(a);
     BH_CHECK_LAUNCH();
     return 0;
 }
@@ -333,9 +341,9 @@ int bh_launch_rdb3_x3(const ConvKArgs* convs, unsigned* counter, unsigned* flags
 // columns over the same tiles: the input patch is re-read per column, from L2)
 int bh_launch_conv_x3(const ConvKArgs& a, int cout_pad, int epilogue, hipStream_t s) {
     if (epilogue == BINHIP_EPI_PLANES)
-        return cout_pad == 32 ? launch_x3<3, 2, 8, BINHIP_EPI_PLANES, 0>(a, cout_pad, s)
-                              : launch_x3<3, 2, 8, BINHIP_EPI_PLANES, 1>(a, cout_pad, s);
-    if (epilogue == BINHIP_EPI_SHUFFLE) return launch_x3<3, 2, 8, BINHIP_EPI_SHUFFLE, 1>(a, cout_pad, s);
-    if (epilogue == BINHIP_EPI_FINAL) return launch_x3<3, 2, 8, BINHIP_EPI_FINAL, 0>(a, cout_pad, s);
+        return cout_pad == 32 ? launch_x3<3, BINHIP_X3_R, BINHIP_X3_WN, BINHIP_EPI_PLANES, 0>(a, cout_pad, s)
+                              : launch_x3<3, BINHIP_X3_R, BINHIP_X3_WN, BINHIP_EPI_PLANES, 1>(a, cout_pad, s);
+    if (epilogue == BINHIP_EPI_SHUFFLE) return launch_x3<3, BINHIP_X3_R, BINHIP_X3_WN, BINHIP_EPI_SHUFFLE, 1>(a, cout_pad, s);
+    if (epilogue == BINHIP_EPI_FINAL) return launch_x3<3, BINHIP_X3_R, BINHIP_X3_WN, BINHIP_EPI_FINAL, 0>(a, cout_pad, s);
     return BINHIP_E_SHAPE;
 }
