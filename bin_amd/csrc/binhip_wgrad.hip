@@ -36,6 +36,7 @@ struct WgradKArgs {
     int tiles_x, tiles_y, ntiles;
     int PB, ncp, ncot;
     int ppg;      // 1x1 kernel: input-channel pairs per workgroup column (blockIdx.y)
+    int nz;       // generic / lean kernels: ncot * ndyg (1-D grid of PB * ncp * nz workgroups, see wg_block())
     int dbg;      // ablation (timing experiments): 1 skip DMA, 2 skip MFMA/LDS reads, 4 skip the final reduction+store
 };
 
@@ -172,6 +173,28 @@ __device__ __forceinline__ void wg_issue(const WgradKArgs& a, char* smem, int bu
     }
 }
 
+// Workgroup -> (pixel-block pb, channel pair cp, z = output tile / tap-row group) for the generic and lean kernels.  The
+// ncp * nz workgroups of one pb walk the SAME pixel tiles (each re-reading the gY tile its siblings read, and for nz > 1 the X
+// patch): the hardware deals consecutive workgroup ids round-robin to the 8 XCDs, so the plain (pb, cp, z) grid put the
+// siblings on different XCDs = different L2s and every one of them fetched its gY from HBM (PMC: 811 MB per launch for
+// 392 MB of operands in the dense-block layers).  With PB a multiple of 8 the id is unpacked as
+//     xcd = id % 8, slot = id / 8, pb = (slot / G) * 8 + xcd, (cp, z) = slot % G        (G = ncp * nz)
+// which keeps all siblings of a pb on ONE XCD, dispatched back to back.
+__device__ __forceinline__ void wg_block(const WgradKArgs& a, int& pb, int& cp, int& z) {
+    const int id = blockIdx.x, G = a.ncp * a.nz;
+    int r;
+    if ((a.PB & 7) == 0) {
+        const int slot = id >> 3;
+        pb = (slot / G) * 8 + (id & 7);
+        r = slot % G;
+    } else {
+        pb = id / G;
+        r = id % G;
+    }
+    cp = r % a.ncp;
+    z = r / a.ncp;
+}
+
 template <int KS, int TR, int NT>
 __global__ void __launch_bounds__(256)
 wgrad_mfma_kernel(const WgradKArgs a) {
@@ -180,9 +203,10 @@ wgrad_mfma_kernel(const WgradKArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pb = blockIdx.x, cp = blockIdx.y;
-    const int cot = blockIdx.z % a.ncot;
-    const int dyg = blockIdx.z / a.ncot;
+    int pb, cp, bz;
+    wg_block(a, pb, cp, bz);
+    const int cot = bz % a.ncot;
+    const int dyg = bz / a.ncot;
     const int dy0 = dyg * TR;
     const long long plane_elems = (long long)a.N * a.H * a.W * 16;
     const unsigned plane_bytes = (unsigned)(plane_elems * 2);
@@ -269,7 +293,7 @@ wgrad_mfma_kernel(const WgradKArgs a) {
     // ---- reduce the 4 waves through LDS, one partial per block ----------------------------------
     float* red = reinterpret_cast<float*>(smem);          // [4 waves][32 m][32 n]
     const int n = lane & 31, hi = lane >> 5;
-    const long long blk = ((long long)blockIdx.z * a.ncp + cp) * a.PB + pb;
+    const long long blk = ((long long)bz * a.ncp + cp) * a.PB + pb;
 #pragma unroll
     for (int t = 0; t < C::NTAP; ++t) {
         __syncthreads();
@@ -309,9 +333,10 @@ wgrad_mfma_sb_kernel(const WgradKArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pb = blockIdx.x, cp = blockIdx.y;
-    const int cot = blockIdx.z % a.ncot;
-    const int dyg = blockIdx.z / a.ncot;
+    int pb, cp, bz;
+    wg_block(a, pb, cp, bz);
+    const int cot = bz % a.ncot;
+    const int dyg = bz / a.ncot;
     const int dy0 = dyg * TR;
     const long long plane_elems = (long long)a.N * a.H * a.W * 16;
     const unsigned plane_bytes = (unsigned)(plane_elems * 2);
@@ -362,7 +387,7 @@ wgrad_mfma_sb_kernel(const WgradKArgs a) {
     if (a.dbg & 4) { if (acc[0][0] == 12345.f) a.partial[0] = bsum; return; }
     float* red = reinterpret_cast<float*>(smem);
     const int n = lane & 31, hi = lane >> 5;
-    const long long blk = ((long long)blockIdx.z * a.ncp + cp) * a.PB + pb;
+    const long long blk = ((long long)bz * a.ncp + cp) * a.PB + pb;
 #pragma unroll
     for (int t = 0; t < C::NTAP; ++t) {
         __syncthreads();
@@ -712,6 +737,7 @@ WgGeom wg_geom(int ksize, int N, int H, int W, int cin_chunks, int cout, int cus
     int pb = (2 * (cus > 0 ? cus : 256)) / groups;     // floor: never one straggler workgroup in an extra round
     if (pb < 1) pb = 1;
     if (pb > g.ntiles) pb = g.ntiles;
+    if (pb >= 8) pb &= ~7;                              // wg_block(): siblings of a pixel block share an XCD
     g.PB = pb;
     g.partial_floats = (size_t)groups * pb * g.ntap * 1024;
     g.bias_floats = (size_t)g.ncot * pb * 32;
@@ -723,7 +749,7 @@ int launch_wg(const WgradKArgs& a, const WgGeom& g, hipStream_t s) {
     using C = WgCfg<KS, TR, NT>;
     static std::atomic<unsigned long long> lds_set{0};
     if (int rc = bh_set_max_lds(&wgrad_mfma_kernel<KS, TR, NT>, C::LDS_BYTES, lds_set)) return rc;
-    dim3 grid((unsigned)g.PB, (unsigned)g.ncp, (unsigned)(g.ncot * g.ndyg));
+    dim3 grid((unsigned)(g.PB * g.ncp * g.ncot * g.ndyg));
     wgrad_mfma_kernel<KS, TR, NT><<<grid, dim3(256), C::LDS_BYTES, s>>>(a);
     BH_CHECK_LAUNCH();
     return 0;
@@ -735,7 +761,7 @@ int launch_wg_sb(const WgradKArgs& a, const WgGeom& g, hipStream_t s) {
     constexpr int LDS = C::BUF_BYTES > 16384 ? C::BUF_BYTES : 16384;
     static std::atomic<unsigned long long> lds_set{0};
     if (int rc = bh_set_max_lds(&wgrad_mfma_sb_kernel<KS, TR, NT>, LDS, lds_set)) return rc;
-    dim3 grid((unsigned)g.PB, (unsigned)g.ncp, (unsigned)(g.ncot * g.ndyg));
+    dim3 grid((unsigned)(g.PB * g.ncp * g.ncot * g.ndyg));
     wgrad_mfma_sb_kernel<KS, TR, NT><<<grid, dim3(256), LDS, s>>>(a);
     BH_CHECK_LAUNCH();
     return 0;
@@ -804,7 +830,7 @@ int bh_wgrad_partials(const BinConvDesc* d, const void* x_hi, const void* x_lo, 
     a.N = d->N; a.H = d->H; a.W = d->W;
     a.cin_chunks = d->cin_chunks; a.cout_chunks = (d->cout + 15) / 16;
     a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.ntiles = g.ntiles;
-    a.PB = g.PB; a.ncp = g.ncp; a.ncot = g.ncot; a.ppg = 0;
+    a.PB = g.PB; a.ncp = g.ncp; a.ncot = g.ncot; a.ppg = 0; a.nz = g.ncot * g.ndyg;
     a.dbg = WG_DBG & 15;
     hipStream_t s = (hipStream_t)stream;
     int rc = BINHIP_E_SHAPE;
