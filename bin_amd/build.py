@@ -47,7 +47,8 @@ def build_library(force=False, verbose=True, defines=(), out=None):
     for cmd, p in procs:
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs
+    # -z defs: a kernel template the host pass silently failed to instantiate shows up as an undefined symbol HERE, not at dlopen
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-z,defs", "-o", lib_path] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -15,6 +15,7 @@
 // 4 waves are reduced through LDS and ONE partial per block is written; a second kernel sums the PB partials in a
 // fixed order (deterministic), un-scales and scatters to OIHW fp32.
 #include "binhip_internal.h"
+#include <utility>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef short short4_ __attribute__((ext_vector_type(4)));
@@ -93,6 +94,15 @@ __device__ __forceinline__ void tr_issue(TrFrag& f, unsigned addr) {      // add
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.a) : "v"(addr));
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:128" : "=v"(f.b) : "v"(addr));
 }
+template <int OFF>
+__device__ __forceinline__ void tr_issue_pair(TrFrag& f, unsigned oa, unsigned ob) {      // two pre-computed addresses + immediate
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.a) : "v"(oa), "n"(OFF));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.b) : "v"(ob), "n"(OFF));
+}
+template <class F, int... S>
+__device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, S...>) {
+    (f(std::integral_constant<int, S>{}), ...);
+}
 // general pixel offset (tap-shifted patches): both 4-pixel reads get their own swizzled address
 __device__ __forceinline__ void tr_issue_at(TrFrag& f, const char* img, int chunk_bytes, int p0, int lane) {
     const int t = lane & 15, ch = (lane >> 4) & 1, kg = lane >> 5;
@@ -111,7 +121,7 @@ __device__ __forceinline__ half8 tr_value(const TrFrag& f) {
     return u.h;
 }
 
-template <int KS, int TR, int NT>
+template <int KS, int TR, int NT, int NW = 4>
 __device__ __forceinline__ void wg_issue(const WgradKArgs& a, char* smem, int buf, int tile, int cp, int cot, int dy0,
                                          int wave, int lane, long long plane_elems, unsigned plane_bytes) {
     using C = WgCfg<KS, TR, NT>;
@@ -137,8 +147,8 @@ __device__ __forceinline__ void wg_issue(const WgradKArgs& a, char* smem, int bu
                 (void*)(have ? xb + coff : xb), 0, have ? plane_bytes : 0u, 0x00020000);
             char* lds = pbase + h * C::XBYTES;
 #pragma unroll
-            for (int j = 0; j < C::NXJ; ++j) {
-                const int i = wave + 4 * j;
+            for (int j = 0; j < (C::XP + NW - 1) / NW; ++j) {
+                const int i = wave + NW * j;
                 if (i < C::XP) {
                     const int q = i * 64 + lane;
                     const int p = q >> 1, s = q & 1;
@@ -158,8 +168,9 @@ __device__ __forceinline__ void wg_issue(const WgradKArgs& a, char* smem, int bu
                 (void*)(haveg ? gb + (long long)gc * plane_elems : gb), 0, haveg ? plane_bytes : 0u, 0x00020000);
             char* gl = pbase + 2 * C::XBYTES + h * C::GBYTES;
 #pragma unroll
-            for (int j = 0; j < C::NGJ; ++j) {
-                const int i = wave + 4 * j;
+            for (int j = 0; j < (C::GP + NW - 1) / NW; ++j) {
+                const int i = wave + NW * j;
+                if (C::GP % NW != 0 && i >= C::GP) break;
                 const int q = i * 64 + lane;
                 const int p = q >> 1, s = q & 1;
                 const int py = p >> 5, px = p & 31;
@@ -349,6 +360,8 @@ wgrad_mfma_sb_kernel(const WgradKArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
+    if ((blockIdx.x >> 8) & 1)
+        for (int i = 0; i < ((a.dbg >> 8) & 255); ++i) __builtin_amdgcn_s_sleep(16);
     for (int tile = pb; tile < a.ntiles; tile += a.PB) {
         if (!(a.dbg & 1)) wg_issue<KS, TR, NT>(a, smem, 0, tile, cp, cot, dy0, wave, lane, plane_elems, plane_bytes);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -411,6 +424,244 @@ wgrad_mfma_sb_kernel(const WgradKArgs a) {
             float tsum = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) tsum += red[k * 32 + tid];
+            a.partial_b[((long long)cot * a.PB + pb) * 32 + tid] = tsum;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 layers, default: EIGHT waves and TWO LDS stages per workgroup.  The lean kernel above relies on two co-resident
+// workgroups covering each other's DMA waits, but the two start together, wait together and multiply together: measured
+// alone (tools/bench_wgrad.py, 160 -> 32 channels, 40 x 128 x 128), DMA-only 97 us + MFMA-only 137 us = 234 us against 224 us
+// for the real thing — no overlap at all (a one-off start stagger of one of the two recovers 17 %).  Here the overlap is
+// structural: the tile t + PB planes land in the other stage while the eight waves (one pixel row each, the K-split of the
+// lean kernel) multiply tile t; the transpose reads come from asm (see tr_issue) so nothing fences that prefetch.
+//   * Per wave and tile: 2 K-steps x 9 taps; the fragments of steps s + 1 and s + 2 are in flight while step s multiplies
+//     (counted lgkmcnt: LDS reads return in order).  The 18 per-lane tap addresses are tile-invariant and live in registers;
+//     K-step 1 and the lo plane are immediate offsets of the same address.
+//   * LDS layout of a stage: per plane [X chunk 0][X chunk 1][gY chunk 0][gY chunk 1], every second chunk 128 B further than
+//     its size: the two 16-lane halves of a transpose read address the two chunks of a pair, and with chunk sizes that are
+//     multiples of 256 B (the bank row) they met on the same banks — SQ_LDS_BANK_CONFLICT = 48 % of SQ_LDS_IDX_ACTIVE.
+//   * DMA issue per tile is a handful of VALU ops: the per-lane source offsets are tile-invariant too, a tile adds one
+//     wave-uniform base and two range checks.
+template <int NT>
+struct Wg3Cfg {
+    using C = WgCfg<3, 3, NT>;
+    static constexpr int XS = C::XBYTES + 128, GS = C::GBYTES + 128;     // chunk strides (bank offset, see above)
+    static constexpr int G0 = 2 * XS;                                   // gY chunks behind the two X chunks
+    static constexpr int PLANE = 2 * XS + 2 * GS;
+    static constexpr int STAGE = C::NPL * PLANE;
+    static constexpr int LDS_BYTES = 2 * STAGE;
+    static constexpr int NXJ = (C::XP + 7) / 8;                           // X pieces per wave (8 waves)
+    static_assert(C::GP == 8, "one gY piece (= one pixel row) per wave");
+    static_assert(PLANE + 512 + 128 < 65536, "lo plane / K-step reachable with the 16-bit DS offset");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+// DMA of one tile's planes into stage `buf` (8 waves; the tile-invariant per-lane parts come from the caller's registers)
+template <int NT>
+__device__ __forceinline__ void wg3_issue(const WgradKArgs& a, char* smem, int tile, int buf, int cp, int cot, int dy0, int wave,
+                                          const int* x_py, const int* x_px, const int* x_src, int g_px, int g_src,
+                                          long long plane_elems, unsigned plane_bytes) {
+    using C = WgCfg<3, 3, NT>;
+    using G = Wg3Cfg<NT>;
+    const int H = a.H, W = a.W;
+    int b = tile;
+    const int tx = b % a.tiles_x; b /= a.tiles_x;
+    const int ty = b % a.tiles_y;
+    const int img = b / a.tiles_y;
+    const int tx0 = tx * 32, ty0 = ty * C::TH;
+    const int y0 = ty0 + dy0 - 1, x0 = tx0 - 1;
+    const long long row0 = (long long)img * H;
+    const int xbase = (int)(((row0 + y0) * W + x0) * 32);           // may be negative at the image border (then !ok)
+    const int gbase = (int)(((row0 + ty0) * W + tx0) * 32);
+    unsigned xvo[G::NXJ];
+#pragma unroll
+    for (int j = 0; j < G::NXJ; ++j) {
+        const bool ok = (unsigned)(y0 + x_py[j]) < (unsigned)H && (unsigned)(x0 + x_px[j]) < (unsigned)W;
+        xvo[j] = ok ? (unsigned)(xbase + x_src[j]) : 0x80000000u;
+    }
+    const bool gok = (ty0 + wave < H) && (tx0 + g_px < W);
+    const unsigned gvo = gok ? (unsigned)(gbase + g_src) : 0x80000000u;
+    char* stage = smem + buf * G::STAGE;
+#pragma unroll
+    for (int pl = 0; pl < C::NPL; ++pl)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = 2 * cp + h;
+            const _Float16* xb = pl ? a.x_lo : a.x_hi;
+            const long long coff = (a.x_cpg > 0)
+                ? (long long)(c / a.x_cpg) * a.x_group_stride + (long long)(c % a.x_cpg) * plane_elems
+                : (long long)c * plane_elems;
+            const bool have = c < a.cin_chunks;
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(have ? xb + coff : xb), 0,
+                                                                          have ? plane_bytes : 0u, 0x00020000);
+            char* lds = stage + pl * G::PLANE + h * G::XS;
+#pragma unroll
+            for (int j = 0; j < G::NXJ; ++j)
+                if (wave + 8 * j < C::XP)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(lds + (wave + 8 * j) * 1024), 16, xvo[j], 0, 0, 0);
+            const int gc = 2 * cot + h;
+            const bool haveg = gc < a.cout_chunks;
+            const _Float16* gb = pl ? a.g_lo : a.g_hi;
+            __amdgpu_buffer_rsrc_t gs = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(haveg ? gb + (long long)gc * plane_elems : gb), 0, haveg ? plane_bytes : 0u, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(gs, (lds_void_t*)(stage + pl * G::PLANE + G::G0 + h * G::GS + wave * 1024),
+                                                     16, gvo, 0, 0, 0);
+        }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(512)
+wgrad3x3_db_kernel(const WgradKArgs a) {
+    using C = WgCfg<3, 3, NT>;
+    using G = Wg3Cfg<NT>;
+    constexpr int KS = 3, NTAP = 9, NSTEP = 2 * NTAP;
+    constexpr int NA = (NT == 3) ? 4 : 2;                                // read instructions of one step's A fragments
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // = pixel row of the 8 x 32 tile
+    int pb, cp, bz;
+    wg_block(a, pb, cp, bz);
+    const int cot = bz % a.ncot;
+    const int dy0 = (bz / a.ncot) * 3;
+    const int H = a.H, W = a.W;
+    const long long plane_elems = (long long)a.N * H * W * 16;
+    const unsigned plane_bytes = (unsigned)(plane_elems * 2);
+    const bool do_bias = (cp == 0) && (dy0 == 0);
+
+    floatx16 acc[NTAP];
+    float bsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    // ---- tile-invariant per-lane state -------------------------------------------------------------------------
+    // fragment reads: LDS offsets (relative to a stage) of the two 4-pixel reads of tap t, K-step 0, hi plane
+    unsigned xa[NTAP], xb2[NTAP];
+    {
+        const int tt = lane & 15, ch = (lane >> 4) & 1, kg = lane >> 5;
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) {
+            const int p0 = (wave + t / KS) * C::PW + t % KS;
+            const int pa = p0 + kg * 8 + (tt >> 2), pb4 = pa + 4;
+            const unsigned base = (unsigned)(ch * G::XS + ((tt & 1) << 3));
+            xa[t] = base + pa * 32 + ((((tt & 3) >> 1) ^ ((pa >> 3) & 1)) << 4);
+            xb2[t] = base + pb4 * 32 + ((((tt & 3) >> 1) ^ ((pb4 >> 3) & 1)) << 4);
+        }
+    }
+    const unsigned g_off = (unsigned)G::G0 + tr_lane_off(G::GS, lane) + wave * 32 * 32;
+    // DMA pieces of this wave: X patch pieces wave, wave + 8 (10 x 34 pixels, 32 B each, 64 lanes x 16 B per piece) and gY
+    // piece `wave` = pixel row `wave` of the tile.  Source offset = tile base (wave-uniform) + lane part.
+    int x_py[G::NXJ], x_px[G::NXJ], x_src[G::NXJ];
+#pragma unroll
+    for (int j = 0; j < G::NXJ; ++j) {
+        const int q = (wave + 8 * j) * 64 + lane;
+        const int p = q >> 1, sh = q & 1;
+        const bool in_patch = (wave + 8 * j < C::XP) && (p < C::PH * C::PW);
+        x_py[j] = in_patch ? p / C::PW : -(1 << 20);                       // out-of-patch lanes fail the range check
+        x_px[j] = p % C::PW;
+        x_src[j] = (x_py[j] * W + x_px[j]) * 32 + ((sh ^ ((p >> 3) & 1)) << 4);
+    }
+    const int g_px = lane >> 1;
+    const int g_src = (wave * W + g_px) * 32 + (((lane & 1) ^ ((g_px >> 3) & 1)) << 4);
+
+    int tile = pb;
+    if (tile < a.ntiles && !(a.dbg & 1))
+        wg3_issue<NT>(a, smem, tile, 0, cp, cot, dy0, wave, x_py, x_px, x_src, g_px, g_src, plane_elems, plane_bytes);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (; tile < a.ntiles; tile += a.PB) {
+        const int nxt = tile + a.PB;
+        if (nxt < a.ntiles && !(a.dbg & 1))
+            wg3_issue<NT>(a, smem, nxt, cur ^ 1, cp, cot, dy0, wave, x_py, x_px, x_src, g_px, g_src, plane_elems, plane_bytes);
+        if (!(a.dbg & 2)) {
+            const unsigned st = lds_addr(smem + cur * G::STAGE);
+            TrFrag Bh[2], Bl[2], Ah[3], Al[3];
+            auto load = [&](auto SC) {
+                constexpr int s = decltype(SC)::value, ks = s / NTAP, t = s % NTAP, q = s % 3;
+                if constexpr (t == 0) {
+                    tr_issue_pair<ks * 512>(Bh[ks], st + g_off, st + g_off + 128);
+                    if constexpr (NT == 3) tr_issue_pair<ks * 512 + G::PLANE>(Bl[ks], st + g_off, st + g_off + 128);
+                }
+                tr_issue_pair<ks * 512>(Ah[q], st + xa[t], st + xb2[t]);
+                if constexpr (NT == 3) tr_issue_pair<ks * 512 + G::PLANE>(Al[q], st + xa[t], st + xb2[t]);
+            };
+            load(std::integral_constant<int, 0>{});
+            load(std::integral_constant<int, 1>{});
+            static_for([&](auto SC) {
+                constexpr int s = decltype(SC)::value, ks = s / NTAP, t = s % NTAP, q = s % 3;
+                // outstanding: the reads of steps s and s + 1, in issue order -> leave step s + 1's in flight
+                constexpr int later = (s + 1 < NSTEP) ? NA + (((s + 1) % NTAP == 0) ? NA : 0) : 0;
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(later) : "memory");
+                tr_tie(Ah[q]);
+                if constexpr (NT == 3) tr_tie(Al[q]);
+                if constexpr (t == 0) {
+                    tr_tie(Bh[ks]);
+                    if constexpr (NT == 3) tr_tie(Bl[ks]);
+                }
+                if constexpr (s + 2 < NSTEP) load(std::integral_constant<int, s + 2>{});
+                __builtin_amdgcn_sched_barrier(0);
+                const half8 bh = tr_value(Bh[ks]);
+                half8 bl;
+                if constexpr (NT == 3) bl = tr_value(Bl[ks]);
+                if (t == 0 && do_bias) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        bsum += (float)bh[e];
+                        if constexpr (NT == 3) bsum += (float)bl[e];
+                    }
+                }
+                const half8 ah = tr_value(Ah[q]);
+                if constexpr (NT == 3) {
+                    const half8 al = tr_value(Al[q]);
+#ifdef WG3_EXPERIMENT_INDEP      /* timing experiment only (wrong sums): the three products of a step on three accumulators */
+                    acc[(t + 1) % NTAP] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[(t + 1) % NTAP], 0, 0, 0);
+                    acc[(t + 2) % NTAP] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[(t + 2) % NTAP], 0, 0, 0);
+#else
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
+#endif
+                }
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }, std::make_integer_sequence<int, NSTEP>{});
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    if (a.dbg & 4) { if (acc[0][0] == 12345.f) a.partial[0] = bsum; return; }
+    // ---- the eight rows are summed through LDS in a fixed order: one partial per workgroup and tap
+    float* red = reinterpret_cast<float*>(smem);          // [8 waves][32 m][32 n]
+    const int n = lane & 31, hi = lane >> 5;
+    const long long blk = ((long long)bz * a.ncp + cp) * a.PB + pb;
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[wave * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * hi) * 32 + n] = acc[t][e];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 512 * i;
+            a.partial[(blk * NTAP + t) * 1024 + idx] =
+                ((red[idx] + red[1024 + idx]) + (red[2048 + idx] + red[3072 + idx])) +
+                ((red[4096 + idx] + red[5120 + idx]) + (red[6144 + idx] + red[7168 + idx]));
+        }
+    }
+    if (do_bias) {
+        __syncthreads();
+        red[tid] = bsum;                              // [wave][kg][co]
+        __syncthreads();
+        if (tid < 32) {
+            float tsum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) tsum += red[k * 32 + tid];
             a.partial_b[((long long)cot * a.PB + pb) * 32 + tid] = tsum;
         }
     }
@@ -705,6 +956,15 @@ namespace {
 
 struct WgGeom { int ncp, ncot, ndyg, tr, ntap, tiles_x, tiles_y, ntiles, PB; size_t partial_floats, bias_floats; };
 
+#if BINHIP_TUNING
+// side builds only: ablation switches (1 skip DMA, 2 skip MFMA, 4 skip reduce/store; 3x3 kernel choice: 16 = the generic
+// double-buffered 4-wave kernel, 32 = the lean single-stage kernel at two workgroups per CU, bits 8..15 = its start stagger)
+int g_wg_dbg = 0;
+#define WG_DBG g_wg_dbg
+#else
+#define WG_DBG 0
+#endif
+#define WG3_LEAN ((WG_DBG & 32) != 0)
 bool use_w1(int ksize, int cout) { return ksize == 1 && cout <= 32 * W1_NCOT; }
 
 WgGeom wg_geom(int ksize, int N, int H, int W, int cin_chunks, int cout, int cus) {
@@ -734,7 +994,8 @@ WgGeom wg_geom(int ksize, int N, int H, int W, int cin_chunks, int cout, int cus
     g.tiles_y = (H + 7) / 8;
     g.ntiles = g.tiles_x * g.tiles_y * N;
     const int groups = g.ncp * g.ncot * g.ndyg;
-    int pb = (2 * (cus > 0 ? cus : 256)) / groups;     // floor: never one straggler workgroup in an extra round
+    // 3x3: one 8-wave workgroup per CU (two LDS stages); 5x5 / wide 1x1: the generic kernel, also one per CU
+    int pb = ((WG3_LEAN && ksize == 3 ? 2 : 1) * (cus > 0 ? cus : 256)) / groups;   // floor: no straggler in an extra round
     if (pb < 1) pb = 1;
     if (pb > g.ntiles) pb = g.ntiles;
     if (pb >= 8) pb &= ~7;                              // wg_block(): siblings of a pixel block share an XCD
@@ -767,6 +1028,16 @@ int launch_wg_sb(const WgradKArgs& a, const WgGeom& g, hipStream_t s) {
     return 0;
 }
 
+template <int NT>
+int launch_wg3(const WgradKArgs& a, const WgGeom& g, hipStream_t s) {
+    using C = WgCfg<3, 3, NT>;
+    static std::atomic<unsigned long long> lds_set{0};
+    if (int rc = bh_set_max_lds(&wgrad3x3_db_kernel<NT>, Wg3Cfg<NT>::LDS_BYTES, lds_set)) return rc;
+    wgrad3x3_db_kernel<NT><<<dim3((unsigned)(g.PB * g.ncp * g.ncot * g.ndyg)), dim3(512), Wg3Cfg<NT>::LDS_BYTES, s>>>(a);
+    BH_CHECK_LAUNCH();
+    return 0;
+}
+
 template <int NT, int PPW, int TR>
 int launch_w1(const WgradKArgs& a, const WgGeom& g, const W1Plan& wp, hipStream_t s) {
     static std::atomic<unsigned long long> lds_set{0};
@@ -777,12 +1048,6 @@ int launch_w1(const WgradKArgs& a, const WgGeom& g, const W1Plan& wp, hipStream_
     return 0;
 }
 
-#if BINHIP_TUNING
-int g_wg_dbg = 0;      // side builds only: ablation switches (1 skip DMA, 2 skip MFMA, 4 skip reduce/store, 16 double-buffered 3x3)
-#define WG_DBG g_wg_dbg
-#else
-#define WG_DBG 0
-#endif
 // CU count of the current device (sizes the pixel-block split); looked up per call — no cached global
 int cus() {
     const int n = binhip_device_cus();
@@ -831,7 +1096,7 @@ int bh_wgrad_partials(const BinConvDesc* d, const void* x_hi, const void* x_lo, 
     a.cin_chunks = d->cin_chunks; a.cout_chunks = (d->cout + 15) / 16;
     a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.ntiles = g.ntiles;
     a.PB = g.PB; a.ncp = g.ncp; a.ncot = g.ncot; a.ppg = 0; a.nz = g.ncot * g.ndyg;
-    a.dbg = WG_DBG & 15;
+    a.dbg = WG_DBG & 0xff0f;      // bits 8..15: start stagger of the lean kernel in units of s_sleep 16 (experiment)
     hipStream_t s = (hipStream_t)stream;
     int rc = BINHIP_E_SHAPE;
     if (use_w1(d->ksize, d->cout)) {
@@ -841,11 +1106,13 @@ int bh_wgrad_partials(const BinConvDesc* d, const void* x_hi, const void* x_lo, 
             ? (wp.ppw == 2 ? launch_w1<1, 2, 1>(a, g, wp, s) : wp.tr == 2 ? launch_w1<1, 1, 2>(a, g, wp, s) : launch_w1<1, 1, 1>(a, g, wp, s))
             : (wp.ppw == 2 ? launch_w1<3, 2, 1>(a, g, wp, s) : wp.tr == 2 ? launch_w1<3, 1, 2>(a, g, wp, s) : launch_w1<3, 1, 1>(a, g, wp, s));
 #if BINHIP_TUNING
-    } else if (d->ksize == 3 && (WG_DBG & 16)) {    // side builds: the double-buffered one-workgroup-per-CU kernel for 3x3
+    } else if (d->ksize == 3 && (WG_DBG & 16)) {    // side builds: the generic double-buffered 4-wave kernel for 3x3
         rc = (d->nterms == 1) ? launch_wg<3, 3, 1>(a, g, s) : launch_wg<3, 3, 3>(a, g, s);
-#endif
-    } else if (d->ksize == 3) {                     // lean kernel, two workgroups per CU
+    } else if (d->ksize == 3 && WG3_LEAN) {         // side builds: the lean single-stage kernel, two workgroups per CU
         rc = (d->nterms == 1) ? launch_wg_sb<3, 3, 1>(a, g, s) : launch_wg_sb<3, 3, 3>(a, g, s);
+#endif
+    } else if (d->ksize == 3) {                     // eight waves, two LDS stages, one workgroup per CU
+        rc = (d->nterms == 1) ? launch_wg3<1>(a, g, s) : launch_wg3<3>(a, g, s);
     } else if (d->ksize == 1) {                     // 1x1 with more than 96 outputs (not on the bin_stage4 path)
         rc = (d->nterms == 1) ? launch_wg<1, 1, 1>(a, g, s) : launch_wg<1, 1, 3>(a, g, s);
     } else {                                        // 5x5 (SFENet1)
