@@ -37,6 +37,7 @@ struct WgradKArgs {
     int tiles_x, tiles_y, ntiles;
     int PB, ncp, ncot;
     int ppg;      // 1x1 kernel: input-channel pairs per workgroup column (blockIdx.y)
+    int cgroups;  // rolling-row 3x3 kernel: channel-pair groups (blockIdx.y = cot * cgroups + group)
     int nz;       // generic / lean kernels: ncot * ndyg (1-D grid of PB * ncp * nz workgroups, see wg_block())
     int dbg;      // ablation (timing experiments): 1 skip DMA, 2 skip MFMA/LDS reads, 4 skip the final reduction+store
 };
@@ -94,10 +95,15 @@ __device__ __forceinline__ void tr_issue(TrFrag& f, unsigned addr) {      // add
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.a) : "v"(addr));
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:128" : "=v"(f.b) : "v"(addr));
 }
+#ifdef WG_EXPERIMENT_PLAIN_READS      /* timing experiment only (wrong data): ordinary 8-byte reads instead of transpose reads */
+#define WG_TR_OP "ds_read_b64"
+#else
+#define WG_TR_OP "ds_read_b64_tr_b16"
+#endif
 template <int OFF>
 __device__ __forceinline__ void tr_issue_pair(TrFrag& f, unsigned oa, unsigned ob) {      // two pre-computed addresses + immediate
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.a) : "v"(oa), "n"(OFF));
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.b) : "v"(ob), "n"(OFF));
+    asm volatile(WG_TR_OP " %0, %1 offset:%2" : "=v"(f.a) : "v"(oa), "n"(OFF));
+    asm volatile(WG_TR_OP " %0, %1 offset:%2" : "=v"(f.b) : "v"(ob), "n"(OFF));
 }
 template <class F, int... S>
 __device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, S...>) {
@@ -667,6 +673,280 @@ wgrad3x3_db_kernel(const WgradKArgs a) {
     }
 }
 
+constexpr int R3_SEG = 16;     // rolling-row kernel (side builds): pixel rows per column segment
+#if BINHIP_TUNING
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 layers, ROLLING-ROW kernel — an experiment kept in BINHIP_TUNING side builds (flag 128), NOT the product path: correct
+// (tests/test_gpu_backward.py passes against it) but slower than the eight-wave kernel above, see the numbers at the end.  Both kernels above load a halo patch
+// and a gY tile per (pixel tile, channel pair): 76 KB of LDS traffic for 32 ci x 32 co x 9 taps x 256 pixels, the gY tile
+// once per channel pair, the X rows 1.25x — 0.97 GB through L2 -> LDS for 0.39 GB of operands in a 160 -> 32 layer at
+// 40 x 128 x 128, and that path (~9 TB/s with nothing else running), not HBM and not the matrix cores, set their time
+// (tools/bench_wgrad.py: DMA alone 108 us, fragment reads + MFMAs alone 132 us, together 217-254 us).
+// Here one workgroup owns ALL channel pairs of its group (<= 6 = 192 channels) and walks DOWN a 32-pixel-wide column
+// segment of one image, one pixel row per stage:
+//   * LDS holds a ring of four X rows (34 pixels x all chunks x hi/lo, a flat list of 16-byte units so that the DMA pieces are
+//     dense: unit u = chunk u / 68, pixel (u % 68) / 2 - 1) and two gY rows; stage y multiplies gY row y with X rows y-1, y, y+1
+//     while X row y + 2 and gY row y + 1 land.  Every operand byte enters LDS once per column segment (+ 2 halo rows per 16).
+//   * wave w owns the (pair, tap) output tiles w * TPW .. w * TPW + TPW - 1 of the group's ppg * 9: no K-split, no
+//     cross-wave reduction, 16 * TPW accumulator registers; per K-step it reads the gY fragment once and one X fragment per
+//     tile (tap (dy, dx) = ring slot y + dy - 1, pixel offset dx — per-tile lane addresses are loop invariants).
+//   * chunk offsets ride in the 32-bit buffer offset (one descriptor per plane), hence r3_usable(): contiguous chunks and
+//     cin_chunks * plane bytes < 4 GiB; everything else takes the eight-wave kernel above.
+// Measured (tools/bench_wgrad.py, 40 x 128 x 128, f16x3, us per layer incl. ~24 us of reduction; lean / eight-wave / rolling):
+//     96 -> 32: 145 / 129 / 186      160 -> 32: 217 / 206 / 284      192 -> 32: 264 / 252 / 324      96 -> 96: 342 / 365 / 518
+// HBM-side and L2 -> LDS traffic are 2.5x lower, but a stage is ONE pixel row = 36 MFMAs per wave between barriers, and the
+// per-stage costs (barrier skew, the first two fragment loads that cannot be issued before the barrier, DMA issue) take
+// ~40 % of it: fragment reads + MFMAs alone run 174 us against 123 us for the eight-wave kernel.  Two rows per stage would
+// need a 6-row ring = 168 KB of LDS at 192 channels.
+
+template <int NT, int TPW>
+struct R3Cfg {
+    static constexpr int NPL = (NT == 3) ? 2 : 1;
+    static constexpr int PPG = (8 * TPW) / 9;                                   // channel pairs per workgroup
+    static_assert((PPG * 9 + 7) / 8 == TPW && PPG >= 1 && PPG <= 6, "tiles per wave <-> pairs per group");
+    static constexpr int CU = 72;                                               // 16-byte units per chunk row: 68 (34 pixels) + 4 of
+                                                                                // padding, so that the chunk stride is 128 mod 256 B
+                                                                                // (the two halves of a transpose read on disjoint banks)
+    static constexpr int UNITS = CU * 2 * PPG;                                  // units of one plane row
+    static constexpr int XP = (UNITS + 63) / 64;                                // DMA pieces per plane row
+    static constexpr int XROW = XP * 1024;
+    static constexpr int XSLOT = NPL * XROW;                                    // one ring slot: hi row, lo row
+    static constexpr int GCH = 1024 + 128;                                      // gY chunk stride (bank offset)
+    static constexpr int GSLOT = NPL * 2 * GCH;
+    static constexpr int NXS = 5, NGS = 3;                                      // ring depths: X rows y-1..y+1 in use + 2 landing
+    static constexpr int G_BASE = NXS * XSLOT;
+    static constexpr int LDS_BYTES = G_BASE + NGS * GSLOT;
+    static constexpr int NXJ = (NPL * XP + 7) / 8;                              // X pieces per wave and row (upper bound)
+    static constexpr int NX_MIN = (NPL * XP) / 8;                               // ... lower bound: what every wave issues per stage
+    static_assert(XROW + 512 + 128 < 65536 && 2 * GCH + 512 + 128 < 65536, "plane / K-step offsets fit the DS immediate");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+// DMA of X row y0 - 1 + q into ring slot q % 5 (this wave's pieces) / of gY row y0 + j into slot j % 3 (waves 0..3)
+template <int NT, int TPW>
+__device__ __forceinline__ void r3_issue_x(char* smem, int q, int wave, int y0, int H, int W, unsigned imgrow,
+                                           __amdgpu_buffer_rsrc_t rs0, __amdgpu_buffer_rsrc_t rs1, const bool* xok,
+                                           const unsigned* xcol) {
+    using R = R3Cfg<NT, TPW>;
+    const int y = y0 - 1 + q;
+    const bool rowok = (unsigned)y < (unsigned)H;
+    const unsigned rowbase = (imgrow + (unsigned)y) * (unsigned)W * 32u;
+    char* slot = smem + (q % R::NXS) * R::XSLOT;
+#pragma unroll
+    for (int j = 0; j < R::NXJ; ++j) {
+        const int piece = wave + 8 * j;
+        if (piece < R::NPL * R::XP) {
+            const unsigned vo = (rowok && xok[j]) ? rowbase + xcol[j] : 0xfffffff0u;
+            if (NT == 3 && piece >= R::XP)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_void_t*)(slot + piece * 1024), 16, vo, 0, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_void_t*)(slot + piece * 1024), 16, vo, 0, 0, 0);
+        }
+    }
+}
+template <int NT, int TPW>
+__device__ __forceinline__ void r3_issue_g(char* smem, int j, int wave, int y0, int H, int W, unsigned imgrow,
+                                           __amdgpu_buffer_rsrc_t rs, bool gcol, unsigned gcolsrc, int piece) {
+    using R = R3Cfg<NT, TPW>;
+    if (wave < 2 * R::NPL) {
+        const int y = y0 + j;
+        const unsigned vo = ((y < H) && gcol) ? (imgrow + (unsigned)y) * (unsigned)W * 32u + gcolsrc : 0xfffffff0u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(smem + R::G_BASE + (j % R::NGS) * R::GSLOT + piece * R::GCH), 16, vo, 0, 0, 0);
+    }
+}
+
+template <int NT, int TPW>
+__global__ void __launch_bounds__(512)
+wgrad3x3_roll_kernel(const WgradKArgs a) {
+    using R = R3Cfg<NT, TPW>;
+    constexpr int NSTEP = 2 * TPW;
+    constexpr int NA = (NT == 3) ? 4 : 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pb = blockIdx.x;
+    const int cgroups = a.cgroups;
+    const int cg = blockIdx.y % cgroups, cot = blockIdx.y / cgroups;
+    const int cp0 = cg * R::PPG;
+    const int H = a.H, W = a.W;
+    const long long plane_elems = (long long)a.N * H * W * 16;
+    const unsigned plane_bytes = (unsigned)(plane_elems * 2);
+    const bool bias_wave = (cg == 0) && (wave == 7);
+
+    // ---- this wave's output tiles
+    int t_dy[TPW];
+    bool t_ok[TPW];
+    unsigned xa[TPW], xb[TPW];                          // per-lane LDS offsets (within a ring slot) of the two 4-pixel reads, K-step 0, hi
+    {
+        const int tt = lane & 15, ch = (lane >> 4) & 1, kg = lane >> 5;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int k = wave * TPW + i;
+            const int pr = k / 9, tap = k % 9;
+            t_ok[i] = (k < R::PPG * 9) && (cp0 + pr < a.ncp);
+            t_dy[i] = tap / 3;
+            const int dx = tap % 3;
+            const int pa = dx + kg * 8 + (tt >> 2), pb4 = pa + 4;      // pixel slot 0..33 of the row (slot 0 = column tx0 - 1)
+            const unsigned base = (unsigned)(((t_ok[i] ? pr : 0) * 2 + ch) * (R::CU * 16) + ((tt & 1) << 3));
+            xa[i] = base + pa * 32 + ((((tt & 3) >> 1) ^ ((pa >> 3) & 1)) << 4);
+            xb[i] = base + pb4 * 32 + ((((tt & 3) >> 1) ^ ((pb4 >> 3) & 1)) << 4);
+        }
+    }
+    const unsigned g_off = tr_lane_off(R::GCH, lane);
+    const int* dyp = t_dy;                              // (lambdas below capture pointers: arrays with template-dependent
+                                                        //  bounds captured by reference break hipcc's host pass)
+    const unsigned *xap = xa, *xbp = xb;
+
+    floatx16 acc[TPW];
+    floatx16* accp = acc;
+    float bsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    // ---- tile-invariant DMA state: X pieces wave, wave + 8, ... of the NPL * XP pieces of a ring slot; gY pieces on waves 0..3
+    int x_px[R::NXJ];                                   // pixel slot, or a large negative = no such unit
+    unsigned x_src[R::NXJ];                             // chunk offset + pixel-slot part of the source offset
+#pragma unroll
+    for (int j = 0; j < R::NXJ; ++j) {
+        const int piece = wave + 8 * j;
+        const int u = (piece % R::XP) * 64 + lane;
+        const int cl = u / R::CU, within = u % R::CU;
+        const int pp = within >> 1, sh = within & 1;
+        const int c = 2 * cp0 + cl;
+        const bool have = (piece < R::NPL * R::XP) && (within < 68) && (cl < 2 * R::PPG) && (c < a.cin_chunks);
+        x_px[j] = have ? pp : -(1 << 20);
+        x_src[j] = (unsigned)c * plane_bytes + (unsigned)(pp * 32 + ((sh ^ ((pp >> 3) & 1)) << 4));
+    }
+    const int g_px = lane >> 1;
+    const unsigned g_src = (unsigned)(g_px * 32 + (((lane & 1) ^ ((g_px >> 3) & 1)) << 4));
+    const int g_pl = (wave >> 1) & 1, g_h = wave & 1;   // gY piece of waves 0..3: plane, chunk of the output tile
+    const int g_c = 2 * cot + g_h;
+    const bool g_have = (wave < 2 * R::NPL) && (g_c < a.cout_chunks);
+
+    const unsigned xbytes = (unsigned)a.cin_chunks * plane_bytes;              // < 4 GiB - 16 (r3_usable)
+    __amdgpu_buffer_rsrc_t x_rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x_hi, 0, xbytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t x_rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(NT == 3 ? a.x_lo : a.x_hi), 0, xbytes, 0x00020000);
+    const _Float16* g_ptr = (g_pl ? a.g_lo : a.g_hi) + (long long)(g_have ? g_c : 0) * plane_elems;
+    __amdgpu_buffer_rsrc_t g_rs = __builtin_amdgcn_make_buffer_rsrc((void*)g_ptr, 0, g_have ? plane_bytes : 0u, 0x00020000);
+
+    for (int unit = pb; unit < a.ntiles; unit += a.PB) {
+        int b = unit;
+        const int seg = b % a.tiles_y; b /= a.tiles_y;
+        const int tx = b % a.tiles_x;
+        const int img = b / a.tiles_x;
+        const int tx0 = tx * 32, y0 = seg * R3_SEG;
+        const int rows = (H - y0 < R3_SEG) ? H - y0 : R3_SEG;
+        // column part of the source offsets of this unit (modular unsigned arithmetic: tx0 - 1 may be -1)
+        unsigned xcol[R::NXJ];
+        bool xok[R::NXJ];
+#pragma unroll
+        for (int j = 0; j < R::NXJ; ++j) {
+            xok[j] = (unsigned)(tx0 - 1 + x_px[j]) < (unsigned)W;
+            xcol[j] = x_src[j] + (unsigned)((tx0 - 1) * 32);
+        }
+        const bool gcol = tx0 + g_px < W;
+        const unsigned gcolsrc = g_src + (unsigned)(tx0 * 32);
+        const unsigned imgrow = (unsigned)img * (unsigned)H;
+        // X row y0 - 1 + q lives in ring slot q % 5, gY row y0 + j in slot j % 3.  Stage j multiplies rows q = j, j+1, j+2 while
+        // q = j+3 (issued during stage j-1) and q = j+4 (issued now) land: two stages of flight time per row.
+        if (!(a.dbg & 1)) {
+            for (int q = 0; q < 4; ++q) r3_issue_x<NT, TPW>(smem, q, wave, y0, H, W, imgrow, x_rs0, x_rs1, xok, xcol);
+            r3_issue_g<NT, TPW>(smem, 0, wave, y0, H, W, imgrow, g_rs, gcol, gcolsrc, g_pl * 2 + g_h);
+            r3_issue_g<NT, TPW>(smem, 1, wave, y0, H, W, imgrow, g_rs, gcol, gcolsrc, g_pl * 2 + g_h);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int j = 0; j < rows; ++j) {
+            if (!(a.dbg & 1)) {
+                r3_issue_x<NT, TPW>(smem, j + 4, wave, y0, H, W, imgrow, x_rs0, x_rs1, xok, xcol);
+                if (j + 2 < rows) r3_issue_g<NT, TPW>(smem, j + 2, wave, y0, H, W, imgrow, g_rs, gcol, gcolsrc, g_pl * 2 + g_h);
+            }
+            if (!(a.dbg & 2)) {
+                const unsigned x0s = lds_addr(smem);
+                unsigned sb[3];
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) sb[dy] = x0s + ((j + dy) % R::NXS) * R::XSLOT;
+                const unsigned gs = x0s + R::G_BASE + (j % R::NGS) * R::GSLOT + g_off;
+                TrFrag Bh[2], Bl[2], Ah[3], Al[3];
+                auto load = [&](auto SC) {
+                    constexpr int s = decltype(SC)::value, ks = s / TPW, i = s % TPW, q = s % 3;
+                    if constexpr (i == 0) {
+                        tr_issue_pair<ks * 512>(Bh[ks], gs, gs + 128);
+                        if constexpr (NT == 3) tr_issue_pair<ks * 512 + 2 * R::GCH>(Bl[ks], gs, gs + 128);
+                    }
+                    const unsigned rb = dyp[i] == 0 ? sb[0] : (dyp[i] == 1 ? sb[1] : sb[2]);
+                    tr_issue_pair<ks * 512>(Ah[q], rb + xap[i], rb + xbp[i]);
+                    if constexpr (NT == 3) tr_issue_pair<ks * 512 + R::XROW>(Al[q], rb + xap[i], rb + xbp[i]);
+                };
+                load(std::integral_constant<int, 0>{});
+                load(std::integral_constant<int, 1>{});
+                static_for([&](auto SC) {
+                    constexpr int s = decltype(SC)::value, ks = s / TPW, i = s % TPW, q = s % 3;
+                    constexpr int later = (s + 1 < NSTEP) ? NA + (((s + 1) % TPW == 0) ? NA : 0) : 0;
+                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(later) : "memory");
+                    tr_tie(Ah[q]);
+                    if constexpr (NT == 3) tr_tie(Al[q]);
+                    if constexpr (i == 0) {
+                        tr_tie(Bh[ks]);
+                        if constexpr (NT == 3) tr_tie(Bl[ks]);
+                    }
+                    if constexpr (s + 2 < NSTEP) load(std::integral_constant<int, s + 2>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    const half8 bh = tr_value(Bh[ks]);
+                    half8 bl;
+                    if constexpr (NT == 3) bl = tr_value(Bl[ks]);
+                    if (i == 0 && bias_wave) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            bsum += (float)bh[e];
+                            if constexpr (NT == 3) bsum += (float)bl[e];
+                        }
+                    }
+                    {   // unused tile slots multiply too (never stored): no branch in the MFMA stream
+                        const half8 ah = tr_value(Ah[q]);
+                        if constexpr (NT == 3) {
+                            const half8 al = tr_value(Al[q]);
+                            accp[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accp[i], 0, 0, 0);
+                            accp[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accp[i], 0, 0, 0);
+                        }
+                        accp[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accp[i], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }, std::make_integer_sequence<int, NSTEP>{});
+            }
+            // what the NEXT stage reads was issued one stage ago: leave this stage's own pieces in flight.  Every wave issues at
+            // least NX_MIN X pieces per stage and they are its newest requests, so vmcnt(NX_MIN) covers all older ones.
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R::NX_MIN) : "memory");
+            __syncthreads();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // rows beyond the segment: drain before the ring is refilled
+        __syncthreads();
+    }
+
+    if (a.dbg & 4) { if (acc[0][0] == 12345.f) a.partial[0] = bsum; return; }
+    // ---- every tile is complete in its wave: straight to the partial buffer (layout of the other 3x3 kernels: block
+    // (z = cot, cp, pb), 9 taps of [32 ci][32 co])
+    const int n = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        if (!t_ok[i]) continue;
+        const int k = wave * TPW + i;
+        const int cp = cp0 + k / 9, tap = k % 9;
+        float* dst = a.partial + ((((long long)cot * a.ncp + cp) * a.PB + pb) * 9 + tap) * 1024 + n;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2) + 4 * hi) * 32] = acc[i][e];
+    }
+    if (bias_wave) {
+        const float t = bsum + __shfl_xor(bsum, 32);
+        if (lane < 32) a.partial_b[((long long)cot * a.PB + pb) * 32 + lane] = t;
+    }
+}
+
+#endif  // BINHIP_TUNING (rolling-row experiment)
+
 // ---------------------------------------------------------------------------------------------------------------
 // 1x1 convolutions (LFF 224->96, GFF.0 1152->96).  A 1x1 weight gradient does 2*Cin*Cout flops per pixel for
 // (Cin + Cout) * 2 B of operands per plane: 77 flop/B in f16x3 — four times below the machine balance, so this is a
@@ -958,7 +1238,7 @@ struct WgGeom { int ncp, ncot, ndyg, tr, ntap, tiles_x, tiles_y, ntiles, PB; siz
 
 #if BINHIP_TUNING
 // side builds only: ablation switches (1 skip DMA, 2 skip MFMA, 4 skip reduce/store; 3x3 kernel choice: 16 = the generic
-// double-buffered 4-wave kernel, 32 = the lean single-stage kernel at two workgroups per CU, bits 8..15 = its start stagger)
+// double-buffered 4-wave kernel, 32 = the lean single-stage kernel at two workgroups per CU, bits 8..15 = its start stagger, 128 = the rolling-row kernel)
 int g_wg_dbg = 0;
 #define WG_DBG g_wg_dbg
 #else
@@ -967,8 +1247,37 @@ int g_wg_dbg = 0;
 #define WG3_LEAN ((WG_DBG & 32) != 0)
 bool use_w1(int ksize, int cout) { return ksize == 1 && cout <= 32 * W1_NCOT; }
 
-WgGeom wg_geom(int ksize, int N, int H, int W, int cin_chunks, int cout, int cus) {
+// rolling-row 3x3 kernel: channel pairs per workgroup (<= 6), tiles per wave, and whether its 32-bit chunk addressing fits
+struct R3Plan { int cgroups, ppg, tpw; };
+static inline R3Plan r3_plan(int ncp) {
+    R3Plan p;
+    p.cgroups = (ncp + 5) / 6;
+    p.ppg = (ncp + p.cgroups - 1) / p.cgroups;
+    p.tpw = (9 * p.ppg + 7) / 8;
+    return p;
+}
+static inline bool r3_usable(int ksize, int N, int H, int W, int cin_chunks, int x_cpg) {
+    return ksize == 3 && x_cpg == 0 && (unsigned long long)cin_chunks * N * H * W * 32ull < 0xfffffff0ull;
+}
+
+WgGeom wg_geom(int ksize, int N, int H, int W, int cin_chunks, int cout, int cus, bool roll = false) {
     WgGeom g;
+    if (roll) {
+        g.tr = 3; g.ndyg = 1; g.ntap = 9;
+        g.ncp = (cin_chunks + 1) / 2;
+        g.ncot = (cout + 31) / 32;
+        const R3Plan rp = r3_plan(g.ncp);
+        g.tiles_x = (W + 31) / 32;
+        g.tiles_y = (H + R3_SEG - 1) / R3_SEG;              // column segments per image
+        g.ntiles = g.tiles_x * g.tiles_y * N;
+        int pb = (cus > 0 ? cus : 256) / (rp.cgroups * g.ncot);
+        if (pb < 1) pb = 1;
+        if (pb > g.ntiles) pb = g.ntiles;
+        g.PB = pb;
+        g.partial_floats = (size_t)g.ncp * g.ncot * pb * 9 * 1024;
+        g.bias_floats = (size_t)g.ncot * pb * 32;
+        return g;
+    }
     if (use_w1(ksize, cout)) {
         g.tr = 1; g.ndyg = 1; g.ntap = 1;
         g.ncp = (cin_chunks + 1) / 2;
@@ -1038,6 +1347,30 @@ int launch_wg3(const WgradKArgs& a, const WgGeom& g, hipStream_t s) {
     return 0;
 }
 
+#if BINHIP_TUNING
+template <int NT, int TPW>
+int launch_r3_t(const WgradKArgs& a, const WgGeom& g, const R3Plan& rp, hipStream_t s) {
+    using R = R3Cfg<NT, TPW>;
+    static std::atomic<unsigned long long> lds_set{0};
+    if (int rc = bh_set_max_lds(&wgrad3x3_roll_kernel<NT, TPW>, R::LDS_BYTES, lds_set)) return rc;
+    wgrad3x3_roll_kernel<NT, TPW><<<dim3((unsigned)g.PB, (unsigned)(rp.cgroups * g.ncot)), dim3(512), R::LDS_BYTES, s>>>(a);
+    BH_CHECK_LAUNCH();
+    return 0;
+}
+template <int NT>
+int launch_r3(const WgradKArgs& a, const WgGeom& g, const R3Plan& rp, hipStream_t s) {
+    switch (rp.tpw) {
+        case 2: return launch_r3_t<NT, 2>(a, g, rp, s);
+        case 3: return launch_r3_t<NT, 3>(a, g, rp, s);
+        case 4: return launch_r3_t<NT, 4>(a, g, rp, s);
+        case 5: return launch_r3_t<NT, 5>(a, g, rp, s);
+        case 6: return launch_r3_t<NT, 6>(a, g, rp, s);
+        case 7: return launch_r3_t<NT, 7>(a, g, rp, s);
+    }
+    return BINHIP_E_SHAPE;
+}
+#endif
+
 template <int NT, int PPW, int TR>
 int launch_w1(const WgradKArgs& a, const WgGeom& g, const W1Plan& wp, hipStream_t s) {
     static std::atomic<unsigned long long> lds_set{0};
@@ -1065,7 +1398,12 @@ int binhip_wgrad_set_debug(int flags) { g_wg_dbg = flags; return 0; }
 size_t binhip_wgrad_workspace_bytes(int ksize, int N, int H, int W, int cin_chunks, int cout) {
     if (N <= 0 || H <= 0 || W <= 0 || cin_chunks <= 0 || cout <= 0) return 0;
     const WgGeom g = wg_geom(ksize, N, H, W, cin_chunks, cout, cus());
-    return (g.partial_floats + g.bias_floats) * sizeof(float) + 256;
+    size_t fl = g.partial_floats + g.bias_floats;
+    if (BINHIP_TUNING && r3_usable(ksize, N, H, W, cin_chunks, 0)) {   // the rolling-row experiment keeps more partials
+        const WgGeom r = wg_geom(ksize, N, H, W, cin_chunks, cout, cus(), true);
+        if (r.partial_floats + r.bias_floats > fl) fl = r.partial_floats + r.bias_floats;
+    }
+    return fl * sizeof(float) + 256;
 }
 
 }  // extern "C"
@@ -1083,7 +1421,8 @@ int bh_wgrad_partials(const BinConvDesc* d, const void* x_hi, const void* x_lo, 
     if ((long long)d->N * d->H * d->W >= (1ll << 26)) return BINHIP_E_SHAPE;
     if (cin <= 0 || cin > d->cin_chunks * 16) return BINHIP_E_SHAPE;
     if (shuffle_perm && d->cout % 4) return BINHIP_E_SHAPE;
-    const WgGeom g = wg_geom(d->ksize, d->N, d->H, d->W, d->cin_chunks, d->cout, cus());
+    const bool roll = (WG_DBG & 128) && r3_usable(d->ksize, d->N, d->H, d->W, d->cin_chunks, d->x_cpg);   // side builds only
+    const WgGeom g = wg_geom(d->ksize, d->N, d->H, d->W, d->cin_chunks, d->cout, cus(), roll);
     const size_t need = (g.partial_floats + g.bias_floats) * sizeof(float) + 256;
     if (workspace_bytes < need) return BINHIP_E_WORKSPACE;
     float* part = (float*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
@@ -1095,7 +1434,7 @@ int bh_wgrad_partials(const BinConvDesc* d, const void* x_hi, const void* x_lo, 
     a.N = d->N; a.H = d->H; a.W = d->W;
     a.cin_chunks = d->cin_chunks; a.cout_chunks = (d->cout + 15) / 16;
     a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.ntiles = g.ntiles;
-    a.PB = g.PB; a.ncp = g.ncp; a.ncot = g.ncot; a.ppg = 0; a.nz = g.ncot * g.ndyg;
+    a.PB = g.PB; a.ncp = g.ncp; a.ncot = g.ncot; a.ppg = 0; a.nz = g.ncot * g.ndyg; a.cgroups = 1;
     a.dbg = WG_DBG & 0xff0f;      // bits 8..15: start stagger of the lean kernel in units of s_sleep 16 (experiment)
     hipStream_t s = (hipStream_t)stream;
     int rc = BINHIP_E_SHAPE;
@@ -1110,6 +1449,12 @@ int bh_wgrad_partials(const BinConvDesc* d, const void* x_hi, const void* x_lo, 
         rc = (d->nterms == 1) ? launch_wg<3, 3, 1>(a, g, s) : launch_wg<3, 3, 3>(a, g, s);
     } else if (d->ksize == 3 && WG3_LEAN) {         // side builds: the lean single-stage kernel, two workgroups per CU
         rc = (d->nterms == 1) ? launch_wg_sb<3, 3, 1>(a, g, s) : launch_wg_sb<3, 3, 3>(a, g, s);
+#endif
+#if BINHIP_TUNING
+    } else if (roll) {                              // 3x3, rolling rows (experiment)
+        const R3Plan rp = r3_plan(g.ncp);
+        a.cgroups = rp.cgroups;
+        rc = (d->nterms == 1) ? launch_r3<1>(a, g, rp, s) : launch_r3<3>(a, g, rp, s);
 #endif
     } else if (d->ksize == 3) {                     // eight waves, two LDS stages, one workgroup per CU
         rc = (d->nterms == 1) ? launch_wg3<1>(a, g, s) : launch_wg3<3>(a, g, s);

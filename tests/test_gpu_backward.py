@@ -60,6 +60,29 @@ def test_wgrad_ragged(nterms, shape):
 
 
 @pytest.mark.parametrize("nterms", [3, 1])
+@pytest.mark.parametrize("cfg", [(2, 33, 70, 192, 32), (1, 16, 32, 96, 96), (3, 17, 40, 224, 35), (1, 40, 33, 16, 32),
+                                 (2, 64, 64, 160, 32), (1, 130, 31, 128, 64)])
+def test_wgrad_3x3_shapes(nterms, cfg):
+    """the 3x3 weight-gradient kernel (eight waves, two LDS stages) over 1-7 channel pairs, 1-3 output tiles, tiles that hang
+    over the right / bottom edge, more workgroups than tiles, several images (reference: autograd of F.conv2d(padding=1),
+    RDN.py:141,187-207).  The same shapes validated the rolling-row experiment of the tuning build."""
+    from bin_amd import ops
+    n, h, w, cin, cout = cfg
+    gen = torch.Generator().manual_seed(h * 1000 + w + cin)
+    x = torch.randn(n, cin, h, w, generator=gen, dtype=torch.float64)
+    gy = torch.randn(n, cout, h, w, generator=gen, dtype=torch.float64)
+    wt = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(x, wt, b, padding=1).backward(gy)
+    xp, gp = ops.nchw_to_planes(x.float().cuda(), nterms), ops.nchw_to_planes(gy.float().cuda(), nterms)
+    dw, db = ops.conv2d_bwd_weight(xp, gp, cout, cin, 3, nterms)
+    assert _rel(dw.cpu().double(), wt.grad) <= TOL[nterms]
+    assert _rel(db.cpu().double(), b.grad) <= TOL[nterms]
+    dw2, db2 = ops.conv2d_bwd_weight(xp, gp, cout, cin, 3, nterms)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2), "fixed summation order"
+
+
+@pytest.mark.parametrize("nterms", [3, 1])
 @pytest.mark.parametrize("cfg", [(1, 5, 7, 40, 35), (2, 19, 45, 224, 96), (1, 8, 32, 16, 96), (1, 33, 70, 600, 64),
                                  (3, 6, 40, 272, 96), (1, 130, 64, 1152, 96)])
 def test_wgrad_1x1_ragged(nterms, cfg):
