@@ -95,11 +95,8 @@ __device__ __forceinline__ void tr_issue(TrFrag& f, unsigned addr) {      // add
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.a) : "v"(addr));
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:128" : "=v"(f.b) : "v"(addr));
 }
-#ifdef WG_EXPERIMENT_PLAIN_READS      /* timing experiment only (wrong data): ordinary 8-byte reads instead of transpose reads */
-#define WG_TR_OP "ds_read_b64"
-#else
+// (ordinary ds_read_b64 in place of the transpose reads, timing-only build: 209.8 vs 204.9 us — the transpose unit is free)
 #define WG_TR_OP "ds_read_b64_tr_b16"
-#endif
 template <int OFF>
 __device__ __forceinline__ void tr_issue_pair(TrFrag& f, unsigned oa, unsigned ob) {      // two pre-computed addresses + immediate
     asm volatile(WG_TR_OP " %0, %1 offset:%2" : "=v"(f.a) : "v"(oa), "n"(OFF));
@@ -624,13 +621,10 @@ wgrad3x3_db_kernel(const WgradKArgs a) {
                 const half8 ah = tr_value(Ah[q]);
                 if constexpr (NT == 3) {
                     const half8 al = tr_value(Al[q]);
-#ifdef WG3_EXPERIMENT_INDEP      /* timing experiment only (wrong sums): the three products of a step on three accumulators */
-                    acc[(t + 1) % NTAP] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[(t + 1) % NTAP], 0, 0, 0);
-                    acc[(t + 2) % NTAP] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[(t + 2) % NTAP], 0, 0, 0);
-#else
+                    // (the three products of a tap chain on one accumulator; spreading them over three accumulators in a
+                    //  timing-only build changed nothing: 237.6 vs 241.8 us — the chain is not what stalls the waves)
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
-#endif
                 }
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
