@@ -206,13 +206,17 @@ conv_mfma_kernel(const ConvKArgs a) {
     const int kg = lane >> 5;    // which 8-channel half of the 16-channel chunk
 
     if (BH_DBG(a, 16)) return;   // timing experiments: empty kernel (launch + boundary only)
+    // 1-D grid of tiles x output-channel blocks, block index fastest: the workgroups that share an input patch are
+    // neighbours on ONE XCD after the banding and fetch it into that L2 once (as a (tiles, blocks) grid every block was a
+    // separate sweep: GFF.0's backward-data read its 214 MB gradient six times from HBM, profiles/r02_train_kernel_stats.md)
     int bid = blockIdx.x;
     if (a.xcd_remap) bid = xcd_band(bid, gridDim.x);
+    const int z = bid % a.ncol;
+    bid /= a.ncol;
     const int tx = bid % a.tiles_x;
     bid /= a.tiles_x;
     const int ty = bid % a.tiles_y;
     const int img = bid / a.tiles_y;
-    const int z = blockIdx.y;
     const int tx0 = tx * 32, ty0 = ty * C::TH;
     const int H = a.H, W = a.W;
     const long long plane_elems = (long long)a.N * H * W * 16;
@@ -301,7 +305,8 @@ static int launch_cfg(const ConvKArgs& ka, int cout_pad, hipStream_t s) {
     ConvKArgs a = ka;
     a.tiles_x = (a.W + 31) / 32;
     a.tiles_y = (a.H + C::TH - 1) / C::TH;
-    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N), (unsigned)(cout_pad / C::COUTB));
+    a.ncol = cout_pad / C::COUTB;
+    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N * a.ncol));
     conv_mfma_kernel<KS, MT, WM, R, WN, KC, NT, NBUF, EPI><<<grid, dim3(64 * C::NW), C::LDS_BYTES, s>>>(a);
     BH_CHECK_LAUNCH();
     return 0;
