@@ -5,6 +5,8 @@
 //   2  32x32x16, all-zero operands                        3  32x32x16, B half zeros (post-ReLU), A = weights (+-1/38)
 //   4  32x32x16, B = "lo plane" data (2^-11 x U[-1,1))    5  16x16x32, all-zero operands
 //   6  32x32x16, both operands change on every MFMA (mode 0 keeps B for 4 consecutive MFMAs)
+//   7  32x32x16, A half zeros (post-ReLU), B = weights (+-1/38): mode 3 with the operands swapped
+//   8  32x32x16, both operands half zeros
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
@@ -24,6 +26,8 @@ __device__ __forceinline__ half8 frag(unsigned seed, int mode, bool is_b) {
         float r = 2.f * u01(seed * 8u + e) - 1.f;
         if (mode == 2 || mode == 5) r = 0.f;
         if (mode == 3) r = is_b ? fmaxf(r, 0.f) : r * (1.f / 38.f);
+        if (mode == 7) r = is_b ? r * (1.f / 38.f) : fmaxf(r, 0.f);
+        if (mode == 8) r = fmaxf(r, 0.f);
         if (mode == 4 && is_b) r *= (1.f / 2048.f);
         v[e] = (_Float16)r;
     }
@@ -97,7 +101,9 @@ int main(int argc, char** argv) {
             case 3: probe<3><<<blocks, 256>>>(iters, out); break;
             case 4: probe<4><<<blocks, 256>>>(iters, out); break;
             case 5: probe<5><<<blocks, 256>>>(iters, out); break;
-            default: probe<6><<<blocks, 256>>>(iters, out); break;
+            case 6: probe<6><<<blocks, 256>>>(iters, out); break;
+            case 7: probe<7><<<blocks, 256>>>(iters, out); break;
+            default: probe<8><<<blocks, 256>>>(iters, out); break;
         }
     };
     launch();
