@@ -38,3 +38,43 @@ def test_asm_transpose_reads_are_waited_for(tmp_path):
             if l.startswith("ds_read_b64_tr_b16"):
                 prev = [p for p in lines[max(0, i - 6):i] if p.startswith("s_waitcnt")]
                 assert not any("vmcnt" in p for p in prev), (name, lines[max(0, i - 6):i + 1])
+
+
+def _write_kernel(tmp_path, body):
+    f = tmp_path / "k.s"
+    f.write_text("_Z6kernelv:\n" + body + "\ts_endpgm\n.Lfunc_end0:\n")
+    return str(f)
+
+
+def test_hazard_checker_on_handwritten_streams(tmp_path):
+    """the checker itself: counted lgkmcnt retires reads in issue order, in-flight state follows branches, barriers and
+    address reuse are flagged."""
+    from check_asm_lds_hazard import check
+    ok = """\tds_read_b64_tr_b16 v[10:11], v2
+\tds_read_b64_tr_b16 v[12:13], v2 offset:128
+\tds_read_b64_tr_b16 v[14:15], v3
+\ts_waitcnt lgkmcnt(1)
+\tv_mfma_f32_32x32x16_f16 v[20:35], v[10:13], v[40:43], v[20:35]
+\ts_waitcnt lgkmcnt(0)
+\tv_mov_b32_e32 v16, v14
+"""
+    bad, kernels, reads = check(_write_kernel(tmp_path, ok))
+    assert kernels == 1 and reads == 3 and not bad, bad
+    early = ok.replace("lgkmcnt(1)", "lgkmcnt(2)")                      # the MFMA now reads v[12:13] while it is in flight
+    bad, _, _ = check(_write_kernel(tmp_path, early))
+    assert len(bad) == 1 and "v_mfma" in bad[0][3]
+    branchy = """\tds_read_b64_tr_b16 v[10:11], v2
+\ts_cbranch_scc1 .LBB0_2
+\tv_add_u32_e32 v5, v6, v7
+.LBB0_2:
+\tv_mov_b32_e32 v8, v10
+\ts_waitcnt lgkmcnt(0)
+"""
+    bad, _, _ = check(_write_kernel(tmp_path, branchy))                    # reached with the read in flight on BOTH paths
+    assert len(bad) == 1 and "v_mov_b32_e32 v8, v10" in bad[0][3]
+    barrier = "\tds_read_b64_tr_b16 v[10:11], v2\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)\n"
+    bad, _, _ = check(_write_kernel(tmp_path, barrier))
+    assert len(bad) == 1 and "barrier" in bad[0][2]
+    reuse = "\tds_read_b64_tr_b16 v[10:11], v2\n\tds_read_b64_tr_b16 v[12:13], v10\n\ts_waitcnt lgkmcnt(0)\n"
+    bad, _, _ = check(_write_kernel(tmp_path, reuse))
+    assert len(bad) == 1 and "in-flight destination" in bad[0][2]
