@@ -183,6 +183,26 @@ def test_training_step_matches_reference_golden(tmp_path):
     assert float(named["clstm_4_prime.Gates.weight"].grad[:, 3:].abs().max()) == 0.0
 
 
+def test_three_training_steps_match_reference_golden(tmp_path):
+    """Three consecutive optimize_parameters() through OUR wrapper (CPU generator) vs the reference wrapper
+    (g9_train_steps, tests/golden/make_golden_steps.py): the loss before each update and sampled parameters after the third —
+    steps 2 and 3 see the weights Adam changed."""
+    g = load_golden("g9_train_steps")
+    m = _cpu_model(tmp_path)
+    batch = {"LQs": T(g["LQs"]), "GTenh": T(g["GTenh"]), "GTinp": T(g["GTinp"]), "key": "x"}
+    got = []
+    for step in (1, 2, 3):
+        m.feed_data(batch)
+        m.optimize_parameters(step)
+        got.append(float(m.loss))
+    assert np.abs(np.array(got) - g["losses"]).max() <= 2e-6, (got, g["losses"])
+    assert abs(got[1] - got[0]) > 1e-3, "the second step must see updated weights"
+    named = dict(m.netG.module.named_parameters())
+    for key in g.files:
+        if key.startswith("after3."):
+            assert float((named[key[7:]].detach() - T(g[key])).abs().max()) <= 5e-6, key
+
+
 def test_wrapper_api_surface(tmp_path):
     m = _cpu_model(tmp_path)
     for name in ("feed_data", "test_set_input", "test", "forward", "test_forward", "optimize_parameters", "get_loss",
