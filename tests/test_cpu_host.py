@@ -272,6 +272,33 @@ def test_lr_schedulers_match_reference():
         assert np.allclose(np.array(lrs), g[tag], rtol=1e-12, atol=0), tag
 
 
+def test_lr_schedulers_in_the_training_loop_match_reference():
+    """g6b_lr (tests/golden/make_golden_lr.py): two parameter groups, warm-up overriding the rates between scheduler steps,
+    gamma = 0.1, restarts listed out of order, cleared optimizer state, and a state_dict round trip mid-curve."""
+    from bin_amd.models import lr_scheduler as LRS
+    import lr_cases
+    g = load_golden("g6b_lr")
+    for tag, (kind, kw, warm) in lr_cases.CASES.items():
+        for resume in (False, True):
+            got = lr_cases.drive(LRS, kind, kw, warm, resume)
+            assert np.allclose(got, g[tag], rtol=1e-12, atol=0), (tag, resume, np.abs(got / g[tag] - 1).max())
+
+
+def test_lr_closed_form_equals_the_stepped_curve():
+    """Without outside interference the stepped rates ARE the closed form initial_lr * shape(e) (floor-corrected)."""
+    from bin_amd.models import lr_scheduler as LRS
+    for mk in (lambda o: LRS.MultiStepLR_Restart(o, [5, 12, 20, 20], restarts=[15], weights=[0.5], gamma=0.1),
+               lambda o: LRS.CosineAnnealingLR_Restart(o, [10, 7, 10], restarts=[10, 24], weights=[1, 0.5], eta_min=1e-7)):
+        p = torch.nn.Parameter(torch.zeros(1))
+        o = torch.optim.Adam([p], lr=1e-4)
+        s = mk(o)
+        for e in range(1, 35):          # (past the floor of a WEIGHTED cycle the reference re-enters from the unweighted rate)
+            o.step(); s.step()
+            cyc, start, wgt = s._cycle(e)
+            want = s.floor + (1e-4 * wgt - s.floor) * s.curve(cyc, e - start, start)
+            assert abs(o.param_groups[0]["lr"] / want - 1) < 1e-9, (type(s).__name__, e)
+
+
 def test_warmup_lr(tmp_path):
     m = _cpu_model(tmp_path)
     m.optimizer_G.step()
