@@ -370,11 +370,11 @@ def main():
             handle = ctypes.c_void_p(0)
             L.check(lib.binhip_profiler_create(3, 32, L.EPI_PLANES, prof_steps * launches_per_step,
                                                ctypes.byref(handle)), "profiler_create")
-            rdn_plan.PROFILER = handle
+            net.set_profiler(handle)
             for _ in range(prof_steps):
                 out = net(*frames)
             torch.cuda.synchronize()
-            rdn_plan.PROFILER = None
+            net.set_profiler(None)
             L.check(lib.binhip_profiler_read(handle, ctypes.byref(kern_ms), ctypes.byref(kern_n)), "profiler_read")
             lib.binhip_profiler_destroy(handle)
             net.n_streams = saved_streams

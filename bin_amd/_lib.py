@@ -105,7 +105,8 @@ _TUNING_SIGNATURES = {
     "binhip_set_tail_depth": (C.c_int, [C.c_int]),
     "binhip_wgrad_set_debug": (C.c_int, [C.c_int]),
 }
-STATUS_SATURATED = 1
+STATUS_SATURATED = 1            # BINHIP_STATUS_SATURATED
+STATUS_SYNC_TIMEOUT = 2         # BINHIP_STATUS_SYNC_TIMEOUT
 
 _lib = None
 

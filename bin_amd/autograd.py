@@ -10,7 +10,7 @@
 Training precision defaults to "f16x3" (fp32-class gradients, ~5e-6 relative vs torch autograd of the oracle).
 BIN_AMD_TRAIN_PRECISION=f16 (single fp16 product in forward AND backward) is NOT a training mode to rely on: its forward's
 ~1e-3 activation error flips ReLU masks, and individual parameter gradients come out 1-25 % off
-(tests/test_gpu_backward.py, tolerance 2.5e-1).  The supported speed/accuracy trade is BACKWARD_PRECISION = "f16" behind the
+(tests/test_gpu_backward.py, tolerance 2.5e-1).  The supported speed/accuracy trade is `backward_precision = "f16"` (a per-network attribute) behind the
 f16x3 forward (exact loss and masks, ~2e-3 relative gradient error).
 """
 import ctypes as C
@@ -23,12 +23,17 @@ from .ops import _ptr, _stream, on_device, status_word
 from .rdn_plan import layer_names, rdn_forward, workspace
 
 
-# When True (bin_model.optimize_parameters turns it on around backward()), an RDN's weight gradients are written /
-# accumulated by the kernels DIRECTLY into the parameters' .grad buffers (BINHIP_BWD_ACCUMULATE) and autograd gets None
-# for them: the four weight sets are shared by 4/3/2/1 calls, so the default path costs ~1.7 k elementwise adds per
-# step in autograd's AccumulateGrad.  Off by default: torch.autograd.grad() / gradient hooks see the parameter grads
-# only through the regular path.
-DIRECT_PARAM_GRADS = False
+# Per-module switches (attributes of the RDN sub-network objects, models/archs/RDN.py::_RDNBase — nothing here is a mutable
+# module global, so two models in one process, or two host threads, never share them):
+#   module.direct_param_grads  (the wrappers turn it on around backward() through net.direct_param_grads()): the RDN's
+#       weight gradients are written / accumulated by the kernels DIRECTLY into the parameters' .grad buffers
+#       (BINHIP_BWD_ACCUMULATE) and autograd gets None for them: the four weight sets are shared by 4/3/2/1 calls, so the
+#       default path costs ~1.7 k elementwise adds per step in autograd's AccumulateGrad.  Off by default:
+#       torch.autograd.grad() / gradient hooks see the parameter grads only through the regular path.
+#   module.backward_precision  ("f16": with an f16x3 (fp32-class) forward, run the RDN backward single-product on the hi
+#       planes of the saved activations (BINHIP_BWD_SAVED_X3) — loss and ReLU masks stay exact, gradients carry ~1e-3
+#       relative rounding noise, the step is ~1.4x faster.  From network_G.backward_precision /
+#       BIN_AMD_BACKWARD_PRECISION; None = same as forward).
 
 # Weight gradients on a side stream, overlapping the backward-data chain (BinRdnBwdPlan.aux_stream; one side stream per
 # device, the library orders and joins it with events inside each call).  BIN_AMD_WGRAD_STREAM=0 turns it off.
@@ -44,10 +49,8 @@ def _aux_stream(device):
     return s
 
 
-# "f16": with an f16x3 (fp32-class) forward, run the RDN backward single-product on the hi planes of the saved
-# activations (BINHIP_BWD_SAVED_X3) — loss and ReLU masks stay exact, gradients carry ~1e-3 relative rounding noise,
-# the step is ~1.4x faster.  Set from network_G.backward_precision / BIN_AMD_BACKWARD_PRECISION; None = same as forward.
-BACKWARD_PRECISION = os.environ.get("BIN_AMD_BACKWARD_PRECISION") or None
+def default_backward_precision():
+    return os.environ.get("BIN_AMD_BACKWARD_PRECISION") or None
 
 
 def train_precision(module):
@@ -67,8 +70,7 @@ class _RdnFn(torch.autograd.Function):
         if nbytes == 0:
             raise RuntimeError(f"bin_amd: unsupported RDN shape N={n} H={h} W={w}")
         saved = torch.empty(nbytes, dtype=torch.uint8, device=frames[0].device)
-        from . import rdn_plan
-        out = rdn_forward(weights, frames, ws=saved, flags=rdn_plan.PLAN_FLAGS | L.PLAN_KEEP_ACTS)
+        out = rdn_forward(weights, frames, ws=saved, flags=module.plan_flags | L.PLAN_KEEP_ACTS, profiler=module.profiler)
         ctx.module, ctx.nterms, ctx.n_frames = module, nterms, n_frames
         ctx.saved_ws = saved
         ctx.dims = (n, h, w)
@@ -96,7 +98,7 @@ class _RdnFn(torch.autograd.Function):
             raise RuntimeError("bin_amd: a parameter of this RDN was modified in place between its forward and its backward "
                                "(optimizer step, load_state_dict, broadcast ...): the gradient would be computed with "
                                "weights the forward did not use")
-        nt_bwd = 1 if (BACKWARD_PRECISION == "f16" and nterms == 3) else nterms
+        nt_bwd = 1 if (module.backward_precision == "f16" and nterms == 3) else nterms
         dgw = module.kernel_weights(nterms).dgrad(module, nt_bwd)
         plan = L.BinRdnBwdPlan()
         plan.N, plan.H, plan.W, plan.n_inputs, plan.nterms = n, h, w, k, nt_bwd
@@ -107,7 +109,7 @@ class _RdnFn(torch.autograd.Function):
         plan.aux_stream = (_aux_stream(dev).cuda_stream
                            if WGRAD_SIDE_STREAM and not torch.cuda.is_current_stream_capturing() else None)
         params = ctx.params
-        direct = DIRECT_PARAM_GRADS and all(ctx.needs_input_grad[3 + k:])
+        direct = module.direct_param_grads and all(ctx.needs_input_grad[3 + k:])
         have = False
         if direct:
             states = [p.grad is not None for p in params]

@@ -13,6 +13,17 @@ SOURCES = ["binhip_conv.hip", "binhip_conv_x3.hip", "binhip_fused.hip", "binhip_
 LIB_PATH = os.path.join(CSRC, "libbinhip.so")
 
 
+HEADER = os.path.join(os.path.dirname(HERE), "include", "binhip.h")
+TUNING_SYMBOLS = ("binhip_set_variant", "binhip_set_tail_depth", "binhip_wgrad_set_debug")
+
+
+def abi_symbols():
+    """The entry points include/binhip.h declares (every BINHIP_API declaration), in header order."""
+    import re
+    with open(HEADER) as f:
+        return re.findall(r"(?m)^BINHIP_API\s+[\w\s\*]+?\b(binhip_\w+)\s*\(", f.read())
+
+
 def _stale():
     if not os.path.exists(LIB_PATH):
         return True
@@ -38,7 +49,7 @@ def build_library(force=False, verbose=True, defines=(), out=None):
     procs, objs = [], []
     for src in SOURCES:
         obj = os.path.join(objdir, src.replace(".hip", tag + ".o"))
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + [f"-D{d}" for d in defines] + \
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"] + [f"-D{d}" for d in defines] + \
               ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
@@ -47,8 +58,15 @@ def build_library(force=False, verbose=True, defines=(), out=None):
     for cmd, p in procs:
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
+    # Dynamic symbols = exactly the entry points include/binhip.h declares (sources are compiled -fvisibility=hidden; the
+    # version script also makes the host-side kernel handles hipcc emits with default visibility local).
+    vmap = os.path.join(objdir, "binhip_exports" + tag + ".map")
+    names = abi_symbols() + (list(TUNING_SYMBOLS) if any(d.startswith("BINHIP_TUNING") for d in defines) else [])
+    with open(vmap, "w") as f:
+        f.write("{\n  global:\n" + "".join(f"    {n};\n" for n in names) + "  local: *;\n};\n")
     # -z defs: a kernel template the host pass silently failed to instantiate shows up as an undefined symbol HERE, not at dlopen
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-z,defs", "-o", lib_path] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-z,defs", f"-Wl,--version-script={vmap}",
+           "-o", lib_path] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

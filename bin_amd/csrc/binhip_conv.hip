@@ -661,7 +661,7 @@ int binhip_conv2d_bwd_data(const BinConvDesc* d, const void* gy_hi, const void* 
 }
 
 #if BINHIP_TUNING
-int binhip_set_variant(int layer_class, int variant) {
+BINHIP_API int binhip_set_variant(int layer_class, int variant) {
     if (layer_class == -1) { g_xcd_remap = variant; return 0; }
     if (layer_class == -2) { g_dbg = variant; return 0; }
     if (layer_class == -3) { g_wt = variant; return 0; }

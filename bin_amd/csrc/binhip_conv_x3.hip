@@ -250,7 +250,6 @@ struct Rdb3Args {
     unsigned epoch;           // value that means "done" in this launch (flags are reused by later launches)
     int T;                    // tiles per phase = tiles_x * tiles_y * N
 };
-#define BINHIP_FLAG_SYNC_TIMEOUT 2u
 constexpr unsigned RDB3_SPIN_LIMIT = 1u << 22;
 
 template <int R, int WN>
@@ -280,7 +279,7 @@ conv_x3_rdb3_kernel(const Rdb3Args a) {
                     while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
                         __builtin_amdgcn_s_sleep(2);
                         if (++spins > RDB3_SPIN_LIMIT) {
-                            if (a.conv[0].flags) atomicOr(a.conv[0].flags, BINHIP_FLAG_SYNC_TIMEOUT);
+                            if (a.conv[0].flags) atomicOr(a.conv[0].flags, BINHIP_STATUS_SYNC_TIMEOUT);
                             break;
                         }
                     }

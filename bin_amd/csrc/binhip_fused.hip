@@ -392,7 +392,7 @@ int binhip_rdb_tail_fwd(int N, int H, int W, int nterms, const void* blk_hi, con
 }
 
 #if BINHIP_TUNING
-int binhip_set_tail_depth(int depth) { g_tail_depth = depth; return 0; }
+BINHIP_API int binhip_set_tail_depth(int depth) { g_tail_depth = depth; return 0; }
 #endif
 
 }  // extern "C"

@@ -1386,7 +1386,7 @@ int cus() {
 extern "C" {
 
 #if BINHIP_TUNING
-int binhip_wgrad_set_debug(int flags) { g_wg_dbg = flags; return 0; }
+BINHIP_API int binhip_wgrad_set_debug(int flags) { g_wg_dbg = flags; return 0; }
 #endif
 
 size_t binhip_wgrad_workspace_bytes(int ksize, int N, int H, int W, int cin_chunks, int cout) {

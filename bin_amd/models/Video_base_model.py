@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import lr_scheduler, networks
-from .base_model import BaseModel
+from .base_model import BaseModel, _direct_param_grads
 from .bin_model import FlatGradAllReduce, SingleProcessParallel, _get
 from .loss import CharbonnierLoss
 from ..utils import util
@@ -119,12 +119,8 @@ class VideoBaseModel(BaseModel):
         self.fake_H = self._net(self.var_L)
         loss, parts = self._pix_loss()
         l_pix = self.l_pix_w * loss
-        from .. import autograd as _ag
-        _ag.DIRECT_PARAM_GRADS = True
-        try:
+        with _direct_param_grads(self.netG):       # weight gradients land in .grad straight from the kernels
             l_pix.backward()
-        finally:
-            _ag.DIRECT_PARAM_GRADS = False
         if self.grad_sync is not None:
             self.grad_sync()
         self.optimizer_G.step()

@@ -40,6 +40,24 @@ class _nullctx:
         return False
 
 
+class _DirectParamGrads:
+    """Context manager behind `net.direct_param_grads()`: flips the per-module flag of the given RDN modules."""
+
+    def __init__(self, mods, on):
+        self.mods, self.on = mods, bool(on)
+
+    def __enter__(self):
+        self.prev = [m.direct_param_grads for m in self.mods]
+        for m in self.mods:
+            m.direct_param_grads = self.on
+        return self
+
+    def __exit__(self, *a):
+        for m, v in zip(self.mods, self.prev):
+            m.direct_param_grads = v
+        return False
+
+
 class ConvLSTMCell(nn.Module):
     """reference RDN.py:9-95.  (input_size, hidden_size) = (3, 3) on the live path."""
 
@@ -107,6 +125,13 @@ class _RDNBase(nn.Module):
         self.UPNet = nn.Sequential(nn.Conv2d(G0, 256, kSize, padding=1, stride=1), nn.PixelShuffle(2),
                                    nn.Conv2d(64, 3, kSize, padding=1, stride=1))
         self.precision = None          # None -> inherit default_precision()
+        # per-object switches of the HIP path (see bin_amd/autograd.py; deliberately NOT module globals)
+        from ...autograd import default_backward_precision
+        from ...rdn_plan import default_plan_flags
+        self.backward_precision = default_backward_precision()   # "f16" = single-product backward behind an f16x3 forward
+        self.direct_param_grads = False                          # kernels accumulate weight gradients straight into .grad
+        self.plan_flags = default_plan_flags()                   # BINHIP_PLAN_* bits of every call of this sub-network
+        self.profiler = None                                     # BinhipProfiler handle (bench.py's roofline leg)
         self._wcache = None            # (key, RdnWeights)
         self._wgen = 0                 # bumped by invalidate_kernel_weights()
 
@@ -139,7 +164,7 @@ class _RDNBase(nn.Module):
                 from ...autograd import rdn_apply        # training path (HIP backward)
                 return rdn_apply(self, frames)
             nterms = PRECISIONS[self.precision or default_precision()]
-            return rdn_forward(self.kernel_weights(nterms), list(frames))
+            return rdn_forward(self.kernel_weights(nterms), list(frames), flags=self.plan_flags, profiler=self.profiler)
 
 
 class RDN_residual_interp_2_input(_RDNBase):
@@ -253,6 +278,34 @@ class RDN_residual_interp_5_input_ConvLSTM_L(nn.Module):
             if isinstance(m, _RDNBase):
                 m.precision = precision
         return self
+
+    def rdn_modules(self):
+        """The four RDN weight sets (model1_1 .. model4_1), each once."""
+        seen, out = set(), []
+        for m in self.modules():
+            if isinstance(m, _RDNBase) and id(m) not in seen:
+                seen.add(id(m))
+                out.append(m)
+        return out
+
+    def set_backward_precision(self, precision):
+        """"f16": single-product backward behind an f16x3 forward (bin_amd/autograd.py); None = same as the forward."""
+        if precision not in (None, "f16", "f16x3"):
+            raise ValueError("backward_precision must be None, 'f16' or 'f16x3'")
+        for m in self.rdn_modules():
+            m.backward_precision = None if precision == "f16x3" else precision
+        return self
+
+    def set_profiler(self, handle):
+        """Attach (or, with None, detach) a BinhipProfiler handle to every RDN call of THIS network."""
+        for m in self.rdn_modules():
+            m.profiler = handle
+        return self
+
+    def direct_param_grads(self, on=True):
+        """Context: while active, the backward kernels of THIS network's RDN calls write / accumulate their weight
+        gradients straight into the parameters' .grad buffers (bin_amd/autograd.py)."""
+        return _DirectParamGrads(self.rdn_modules(), on)
 
     def forward(self, B1, B3, B5, B7, B9, B11, stage1_cache=None, input_events=None):
         """`input_events` (bin_amd extension, inference only): a list of torch.cuda.Event after which the six frames are
@@ -392,19 +445,21 @@ def _forward_streams(self, B, stage1_cache=None, input_events=None):
             # layout / dtype conversions (no-ops for the usual contiguous fp32 frames) run on the call's own stream,
             # after its waits on the producers — not on the caller's stream, where nothing would order them
             ws = workspace(nb, dev, key=f"fwd-stream{si % len(streams)}")
-            return rdn_forward(kw[k], [t.contiguous().float() for t in ins], ws=ws)
+            return rdn_forward(kw[k], [t.contiguous().float() for t in ins], ws=ws, flags=mods[k].plan_flags,
+                               profiler=mods[k].profiler)
         return launch(si, fn, ins)
 
     for s in streams:
+        # every stream that runs a first consumer waits for the frames' own events — including the caller's stream in
+        # the serial schedule (the frames may have been produced on a copy / decode stream the caller never joined)
+        for ev in (input_events or ()):
+            s.wait_event(ev)
         if s is main:
             continue
-        # the side streams always wait for what the caller's stream has queued so far: besides the frames that is the
-        # weight relayouts kernel_weights() may just have issued there (first call / after an optimizer step)
+        # without events the side streams wait for what the caller's stream has queued so far (the frames); they also
+        # do so for the weight relayouts kernel_weights() may just have issued there (first call / after an optimizer step)
         if input_events is None or relayout_pending:
             s.wait_stream(main)
-        else:                            # pipelined: only the frames' own events, not everything queued on `main`
-            for ev in input_events:
-                s.wait_event(ev)
     cells = (self.clstm_4_prime, self.clstm_6_prime, self.clstm_8_prime, self.clstm_5_prime_prime,
              self.clstm_7_prime_prime, self.clstm_6_prime_prime_prime)
 

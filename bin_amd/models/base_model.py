@@ -21,6 +21,21 @@ def unwrap(network):
     return inner if isinstance(inner, nn.Module) else network
 
 
+class _NoCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def _direct_param_grads(network):
+    """The generator's own `direct_param_grads()` context (bin_amd/models/archs/RDN.py) when it has one — an injected
+    CPU test generator does not — else a no-op."""
+    net = unwrap(network)
+    return net.direct_param_grads() if hasattr(net, "direct_param_grads") else _NoCtx()
+
+
 def clean_state_dict_keys(loaded, strict):
     """Key clean-up of the reference's load_network (base_model.py:93-102): a leading 'module.' or
     'InterpNet.' is stripped.  The reference also keeps a 'module.'-prefixed key under its original name

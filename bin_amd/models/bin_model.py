@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from . import lr_scheduler
 from . import networks
-from .base_model import BaseModel, unwrap
+from .base_model import BaseModel, unwrap, _direct_param_grads
 from .loss import CharbonnierLoss
 from ..utils import util
 from ..utils.util import AverageMeter
@@ -284,12 +284,8 @@ class bin_model(BaseModel):
         self.Ft_p = self.forward()
         self.loss, self.loss_list = self.get_loss(ret=1)
         l_pix = self.l_pix_w * self.loss
-        from .. import autograd as _ag
-        _ag.DIRECT_PARAM_GRADS = True          # weight gradients land in .grad straight from the kernels
-        try:
+        with _direct_param_grads(self.netG):       # weight gradients land in .grad straight from the kernels
             l_pix.backward()
-        finally:
-            _ag.DIRECT_PARAM_GRADS = False
         if self.grad_sync is not None:
             self.grad_sync()
         self.optimizer_G.step()

@@ -12,8 +12,7 @@ def define_G(opt):
             netG.set_precision(prec)           # bin_amd extension: "f16" | "f16x3"
         bwd = opt_net.get("backward_precision") if hasattr(opt_net, "get") else None
         if bwd:                                # bin_amd extension: "f16" = single-product backward behind an f16x3 forward
-            from .. import autograd
-            autograd.BACKWARD_PRECISION = bwd
+            netG.set_backward_precision(bwd)   # stored on THIS network's sub-modules, not process-wide
     else:
         raise NotImplementedError("Generator model [{:s}] not recognized".format(which_model))
     return netG

@@ -27,8 +27,7 @@ _status = {}
 
 def status_word(device):
     """Per-device uint32 status word the kernels OR into (include/binhip.h BINHIP_STATUS_*)."""
-    device = torch.device(device)
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    key = _device_key(device)
     w = _status.get(key)
     if w is None:
         w = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", key))
@@ -36,22 +35,38 @@ def status_word(device):
     return w
 
 
+def _device_key(device):
+    device = torch.device(device)
+    return device.index if device.index is not None else torch.cuda.current_device()
+
+
 def check_status(device=None, reset=True):
-    """Raise if any kernel since the last check stored a value outside the fp16 range (or a NaN).  Reads the device
-    word, i.e. synchronises: call it where the host syncs anyway (after a step, before images leave the device)."""
-    keys = list(_status) if device is None else [torch.device(device).index]
+    """Raise if any kernel since the last check reported a problem in its device status word: a stored value outside
+    the fp16 range (or a NaN), a neighbour-flag timeout of the three-phase dense-block launch, or any bit this host
+    code does not know.  Reads the device word, i.e. synchronises: call it where the host syncs anyway (after a step,
+    before images leave the device).  `device=None` checks every device that has a word; a device without an index
+    means the current one (as in `status_word`)."""
+    keys = list(_status) if device is None else [_device_key(device)]
     for k in keys:
         w = _status.get(k)
         if w is None:
             continue
-        v = int(w.item())
-        if v and reset:
+        v = int(w.item()) & 0xFFFFFFFF
+        if not v:
+            continue
+        if reset:
             w.zero_()
+        if v & L.STATUS_SYNC_TIMEOUT:
+            raise RuntimeError(
+                "bin_amd: dense-block launch on cuda:%d timed out waiting for a neighbour tile (BINHIP_STATUS_SYNC_TIMEOUT): "
+                "a tile was computed from inputs that may not have been published; results since the last check are "
+                "invalid" % k)
         if v & L.STATUS_SATURATED:
             raise RuntimeError(
                 "bin_amd: fp16 range exceeded on cuda:%d — an activation / gradient left +-65504 (or was NaN) and was "
                 "saturated; results since the last check are not those of the fp32 reference (include/binhip.h, "
                 "'Dynamic range')" % k)
+        raise RuntimeError("bin_amd: unknown status bits 0x%x on cuda:%d (library newer than this host code?)" % (v, k))
 
 
 def _ptr(t):

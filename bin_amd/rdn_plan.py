@@ -124,20 +124,20 @@ def workspace(nbytes, device, key="fwd"):
 
 import os as _os
 
-# module-level default plan flags (tests flip BINHIP_PLAN_NO_FUSE / BINHIP_PLAN_RDB3 through this).
-# BIN_AMD_RDB3=1: convs 0-2 of every dense block as three phases of one launch (fp32-class path)
-PLAN_FLAGS = L.PLAN_RDB3 if _os.environ.get("BIN_AMD_RDB3", "0") == "1" else 0
+
+def default_plan_flags():
+    """Plan flags a freshly built RDN module starts with (its `plan_flags` attribute; tests pass BINHIP_PLAN_NO_FUSE /
+    BINHIP_PLAN_RDB3 per call).  BIN_AMD_RDB3=1: convs 0-2 of every dense block as three phases of one launch."""
+    return L.PLAN_RDB3 if _os.environ.get("BIN_AMD_RDB3", "0") == "1" else 0
 
 
-def rdn_forward(weights, inputs, out=None, ws=None, flags=None, profiler=None):
-    """inputs: list of fp32 [N,3,H,W] device tensors -> fp32 [N,3,H,W].  `profiler`: optional BinhipProfiler handle
-    (bench.py's roofline leg)."""
+def rdn_forward(weights, inputs, out=None, ws=None, flags=0, profiler=None):
+    """inputs: list of fp32 [N,3,H,W] device tensors -> fp32 [N,3,H,W].  `flags`: BINHIP_PLAN_* bits; `profiler`:
+    optional BinhipProfiler handle (bench.py's roofline leg).  Both are per call — the owning module keeps its own
+    (`_RDNBase.plan_flags` / `.profiler`); there is no module-level switch."""
     _need_cuda(*inputs)
     with on_device(inputs[0]):
         return _rdn_forward(weights, inputs, out, ws, flags, profiler)
-
-
-PROFILER = None         # module-level handle bench.py sets for its roofline leg (host-side timing only)
 
 
 def _rdn_forward(weights, inputs, out, ws, flags, profiler):
@@ -147,10 +147,9 @@ def _rdn_forward(weights, inputs, out, ws, flags, profiler):
     lib = L.lib()
     plan = L.BinRdnPlan()
     plan.N, plan.H, plan.W, plan.n_inputs, plan.nterms = n, h, w, weights.n_inputs, weights.nterms
-    plan.reserved = PLAN_FLAGS if flags is None else flags
+    plan.reserved = int(flags or 0)
     plan.status = status_word(inputs[0].device).data_ptr()
-    prof = profiler if profiler is not None else PROFILER
-    plan.profiler = prof if prof else None
+    plan.profiler = profiler if profiler else None
     weights.fill_plan(plan)
     nbytes = lib.binhip_rdn_workspace_bytes(n, h, w, weights.n_inputs, weights.nterms)
     if nbytes == 0:

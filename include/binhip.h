@@ -42,11 +42,17 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: the entry points declared here (BINHIP_API) are its ONLY dynamic
+ * symbols (tests/test_cpu_host.py checks `nm -D` against this header). */
+#define BINHIP_API __attribute__((visibility("default")))
+
 #define BINHIP_E_ARG      (-1)   /* null pointer / bad enum */
 #define BINHIP_E_SHAPE    (-2)   /* unsupported shape */
 #define BINHIP_E_WORKSPACE (-3)  /* workspace too small */
 
 #define BINHIP_STATUS_SATURATED 1u   /* bit 0 of a status word: a stored value was clamped to +-65504 (or was NaN) */
+#define BINHIP_STATUS_SYNC_TIMEOUT 2u /* bit 1: a tile of the three-phase dense-block launch (BINHIP_PLAN_RDB3) gave up waiting for a
+                                        neighbour's flag and computed from inputs that may not have been published: results invalid */
 
 #define BINHIP_EPI_PLANES  0     /* y = [relu](conv + b [+ residual]) -> chunk planes            */
 #define BINHIP_EPI_SHUFFLE 1     /* conv + b -> PixelShuffle(2) -> chunk planes at 2H x 2W       */
@@ -54,10 +60,10 @@ extern "C" {
 
 #define BINHIP_RDN_LAYERS 66     /* SFE1, SFE2, 12 x (4 conv + LFF), GFF.0, GFF.1, UP.0, UP.2    */
 
-int binhip_version(void);
+BINHIP_API int binhip_version(void);
 
 /* Device properties the host needs for sizing (no allocation). */
-int binhip_device_cus(void);
+BINHIP_API int binhip_device_cus(void);
 
 /* ---- stride-1 "same" convolution on chunk planes (RDN.py:141,162,187-188,199-200,205-207) -----
  * Replaces F.conv2d(+bias)(+ReLU)(+cat)(+residual add)(+PixelShuffle)(+input mean).            */
@@ -79,18 +85,18 @@ typedef struct BinConvDesc {
 } BinConvDesc;
 
 /* Rows per weight block for a (ksize, cout_pad, nterms) configuration (relayout needs it). */
-int binhip_conv_cout_block(int ksize, int cout_pad, int nterms);
+BINHIP_API int binhip_conv_cout_block(int ksize, int cout_pad, int nterms);
 
 /* OIHW fp32 -> kernel layout fp16 [cout_pad/cb][cin_chunks][k*k][cb][16] (+lo), 16-byte slots
  * XOR-swizzled for conflict-free ds_read_b128; input channels >= cin and rows >= cout are zero.
  * shuffle_perm != 0 reorders output rows co' = (co%4)*(cout/4) + co/4 so PixelShuffle becomes a
  * plain plane store.  bias_out: fp32 [cout_pad] (same row order, zero padded).  w_lo may be NULL. */
-int binhip_weights_relayout(const float* w_oihw, const float* bias, int cout, int cin, int ksize,
+BINHIP_API int binhip_weights_relayout(const float* w_oihw, const float* bias, int cout, int cin, int ksize,
                             int cout_pad, int cin_chunks, int cout_block, int shuffle_perm,
                             void* w_hi, void* w_lo, float* bias_out, void* stream);
-size_t binhip_weights_bytes(int cout_pad, int cin_chunks, int ksize);   /* per plane (hi or lo) */
+BINHIP_API size_t binhip_weights_bytes(int cout_pad, int cin_chunks, int ksize);   /* per plane (hi or lo) */
 
-int binhip_conv2d_fwd(const BinConvDesc* d,
+BINHIP_API int binhip_conv2d_fwd(const BinConvDesc* d,
                       const void* x_hi, const void* x_lo,
                       const void* w_hi, const void* w_lo, const float* bias,
                       const void* res_hi, const void* res_lo,      /* PLANES residual or NULL   */
@@ -108,8 +114,8 @@ int binhip_conv2d_fwd(const BinConvDesc* d,
  *   mask  — saved forward activation planes: output chunks >= mask_from are zeroed where it is <= 0
  *           (ReLU backward, RDN.py:142), applied when the last contribution to that chunk lands
  *   y_cpg / y_group_stride — output chunk grouping (GFF.0 dgrad scatters to the 12 block buffers)     */
-int binhip_dgrad_rows_pad(int ksize, int cin);   /* rows_pad the library expects for a layer's dgrad weights */
-int binhip_weights_relayout_dgrad(const float* w_oihw, int cout, int cin, int ksize, int rows_pad,
+BINHIP_API int binhip_dgrad_rows_pad(int ksize, int cin);   /* rows_pad the library expects for a layer's dgrad weights */
+BINHIP_API int binhip_weights_relayout_dgrad(const float* w_oihw, int cout, int cin, int ksize, int rows_pad,
                                   int cin_chunks, int cout_block, int shuffle_perm, void* w_hi, void* w_lo,
                                   float* bias_out, void* stream);
 /* Residual dense block (RDN.py:132-165) backward-data in GATHER form.  Concat group g of a block (g = 0: its 96 input
@@ -119,9 +125,9 @@ int binhip_weights_relayout_dgrad(const float* w_oihw, int cout, int cin, int ks
  * base_g = 96 + 32 (g - 1)); rows = 96 (g = 0) or 32, input chunks = 2 (4 - g).  Every group is then written once
  * instead of being read-modified-written by each later conv.  w_oihw4 = HOST array of the block's four OIHW fp32
  * device pointers (entries < group may be NULL).                                                                  */
-int binhip_weights_relayout_rdb_gather(const float* const* w_oihw4, int group, int cout_block, void* w_hi, void* w_lo,
+BINHIP_API int binhip_weights_relayout_rdb_gather(const float* const* w_oihw4, int group, int cout_block, void* w_hi, void* w_lo,
                                        float* bias_out, void* stream);
-int binhip_conv2d_bwd_data(const BinConvDesc* d, const void* gy_hi, const void* gy_lo,
+BINHIP_API int binhip_conv2d_bwd_data(const BinConvDesc* d, const void* gy_hi, const void* gy_lo,
                            const void* wt_hi, const void* wt_lo, const float* zero_bias,
                            const void* res_hi, const void* res_lo, int res_chunks,
                            const void* acc_hi, const void* acc_lo,
@@ -131,48 +137,48 @@ int binhip_conv2d_bwd_data(const BinConvDesc* d, const void* gy_hi, const void* 
 
 /* ---- layout glue ------------------------------------------------------------------------------ */
 /* fp32 NCHW [N,C,H,W] -> chunk planes (C padded with zeros to 16).                              */
-int binhip_nchw_to_planes(const float* x, int N, int C, int H, int W, void* y_hi, void* y_lo,
+BINHIP_API int binhip_nchw_to_planes(const float* x, int N, int C, int H, int W, void* y_hi, void* y_lo,
                           void* status, void* stream);
 /* chunk planes -> fp32 NCHW (hi + lo when lo != NULL).                                           */
-int binhip_planes_to_nchw(const void* x_hi, const void* x_lo, int N, int C, int H, int W, float* y,
+BINHIP_API int binhip_planes_to_nchw(const void* x_hi, const void* x_lo, int N, int C, int H, int W, float* y,
                           void* stream);
 /* exact fp32 space-to-depth, the reference's standalone pixel_reshuffle (RDN.py:107-132)                */
-int binhip_pixel_unshuffle_f32(const float* x, int N, int C, int H, int W, int r, float* y, void* stream);
+BINHIP_API int binhip_pixel_unshuffle_f32(const float* x, int N, int C, int H, int W, int r, float* y, void* stream);
 /* K1: pixel_reshuffle(cat(images), 2) (RDN.py:107-132, 211/269/323) fused into the CP writer:
  * `n_images` fp32 [N,3,H,W] -> CP [N, H/2, W/2, pad16(12*n_images)].                            */
-int binhip_pack_inputs(const float* const* images, int n_images, int N, int H, int W,
+BINHIP_API int binhip_pack_inputs(const float* const* images, int n_images, int N, int H, int W,
                        void* y_hi, void* y_lo, void* status, void* stream);
 
 /* ---- harness glue: test.py's per-frame host work on the device --------------------
  * u8_to_frame: HWC BGR uint8 -> fp32 CHW RGB /255 (read_image, test.py:44-56) + ReplicationPad2d
  * (test.py:348-371) -> [3, H+pt+pb, W+pl+pr].   frame_to_u8: tensor2img (utils/util.py:113-137: clamp,
  * x255, round half to even, RGB->BGR) + the crop of test.py:394-402 -> HWC BGR uint8 [H, W, 3].      */
-int binhip_u8_to_frame(const unsigned char* bgr_hwc, int H, int W, int pad_left, int pad_right,
+BINHIP_API int binhip_u8_to_frame(const unsigned char* bgr_hwc, int H, int W, int pad_left, int pad_right,
                        int pad_top, int pad_bottom, float* out_chw, void* stream);
-int binhip_frame_to_u8(const float* chw, int Hp, int Wp, int top, int left, int H, int W,
+BINHIP_API int binhip_frame_to_u8(const float* chw, int Hp, int Wp, int top, int left, int H, int W,
                        unsigned char* bgr_hwc, void* stream);
 
 /* ---- ConvLSTM cell (RDN.py:50-95): gates = conv3x3(cat(x,h)) 6->12, i,j,f,o = chunk(4);
  * c' = c*sigmoid(f+forget_bias) + sigmoid(i)*tanh(j); h' = tanh(c')*sigmoid(o).  fp32 NCHW.
  * c_prev/h_prev may both be NULL (zero state, RDN.py:57-68).                                      */
-int binhip_convlstm_fwd(const float* x, const float* c_prev, const float* h_prev,
+BINHIP_API int binhip_convlstm_fwd(const float* x, const float* c_prev, const float* h_prev,
                         const float* w /*[12,6,3,3]*/, const float* b /*[12]*/, float forget_bias,
                         int N, int H, int W, float* c_new, float* h_new, void* stream);
 
 /* ---- Charbonnier loss (loss.py:137-141): mean(sqrt((x-y)^2 + eps)).  Deterministic two-pass
  * reduction; `partials` is a caller workspace of binhip_charbonnier_partials() floats.           */
-int binhip_charbonnier_partials(int64_t numel);
-int binhip_charbonnier_fwd(const float* x, const float* y, int64_t numel, float eps,
+BINHIP_API int binhip_charbonnier_partials(int64_t numel);
+BINHIP_API int binhip_charbonnier_fwd(const float* x, const float* y, int64_t numel, float eps,
                            float* partials, float* loss, void* stream);
 /* gx = gloss * (x-y)/sqrt((x-y)^2+eps)/numel ; gy = -gx (either may be NULL).                    */
-int binhip_charbonnier_bwd(const float* x, const float* y, int64_t numel, float eps,
+BINHIP_API int binhip_charbonnier_bwd(const float* x, const float* y, int64_t numel, float eps,
                            const float* gloss, float* gx, float* gy, void* stream);
 
 /* ---- fused tail of a residual dense block: o3 = relu(conv3x3(blk[0:192])), y = LFF(cat(blk[0:192], o3)) + blk[0:96]
  * (RDN.py:141-147 for conv #3, :162-165 for LFF + residual) in one kernel; blk = 14-chunk dense-block buffer,
  * wc/wl = binhip_weights_relayout outputs of conv #3 (cout_block 32) and LFF (cout_block 96); y = 6 planes.
  * store_o3 != 0 also writes o3 to blk planes 12, 13 (needed by the backward pass only).               */
-int binhip_rdb_tail_fwd(int N, int H, int W, int nterms, const void* blk_hi, const void* blk_lo,
+BINHIP_API int binhip_rdb_tail_fwd(int N, int H, int W, int nterms, const void* blk_hi, const void* blk_lo,
                         const void* wc_hi, const void* wc_lo, const float* bias_c,
                         const void* wl_hi, const void* wl_lo, const float* bias_l,
                         void* y_hi, void* y_lo, int store_o3, void* status, void* stream);
@@ -195,8 +201,8 @@ typedef struct BinRdnPlan {
     struct BinhipProfiler* profiler;       /* optional live kernel timing (below) or NULL         */
 } BinRdnPlan;
 
-size_t binhip_rdn_workspace_bytes(int N, int H, int W, int n_inputs, int nterms);
-int binhip_rdn_forward(const BinRdnPlan* plan, const float* const* inputs /* host array of
+BINHIP_API size_t binhip_rdn_workspace_bytes(int N, int H, int W, int n_inputs, int nterms);
+BINHIP_API int binhip_rdn_forward(const BinRdnPlan* plan, const float* const* inputs /* host array of
                        n_inputs device ptrs, fp32 [N,3,H,W] */, float* out /* fp32 [N,3,H,W] */,
                        void* workspace, size_t workspace_bytes, void* stream);
 
@@ -206,8 +212,8 @@ int binhip_rdn_forward(const BinRdnPlan* plan, const float* const* inputs /* hos
  * (N,H,W, ksize, cin_chunks, cout, nterms, x_cpg/x_group_stride).  The result is multiplied by
  * inv_scale[0] (device scalar, may be NULL) and written (or added, accumulate != 0) to OIHW fp32.
  * shuffle_perm != 0: gY's channels are in UPNet.0's PixelShuffle-permuted order.                      */
-size_t binhip_wgrad_workspace_bytes(int ksize, int N, int H, int W, int cin_chunks, int cout);
-int binhip_conv2d_bwd_weight(const BinConvDesc* d, const void* x_hi, const void* x_lo,
+BINHIP_API size_t binhip_wgrad_workspace_bytes(int ksize, int N, int H, int W, int cin_chunks, int cout);
+BINHIP_API int binhip_conv2d_bwd_weight(const BinConvDesc* d, const void* x_hi, const void* x_lo,
                              const void* gy_hi, const void* gy_lo, const float* inv_scale,
                              void* workspace, size_t workspace_bytes, float* dw_oihw, float* dbias,
                              int cin, int shuffle_perm, int accumulate, void* stream);
@@ -215,24 +221,24 @@ int binhip_conv2d_bwd_weight(const BinConvDesc* d, const void* x_hi, const void*
 /* ---- backward glue -------------------------------------------------------------------------------- */
 /* scale_out[0] = 2^floor(log2(target/amax|g|)), scale_out[1] = 1/scale_out[0] (fp16 gradient planes
  * are stored multiplied by scale_out[0]); partials: binhip_charbonnier_partials() floats.            */
-int binhip_grad_scale(const float* g, int64_t numel, float target, float* partials, float* scale_out,
+BINHIP_API int binhip_grad_scale(const float* g, int64_t numel, float target, float* partials, float* scale_out,
                       void* stream);
-int binhip_nchw_to_planes_scaled(const float* x, int N, int C, int H, int W, const float* scale,
+BINHIP_API int binhip_nchw_to_planes_scaled(const float* x, int N, int C, int H, int W, const float* scale,
                                  void* y_hi, void* y_lo, void* status, void* stream);
 /* inverse PixelShuffle(2) on planes: nchunks planes at 2H x 2W -> 4*nchunks planes at H x W           */
-int binhip_unshuffle_planes(const void* x_hi, const void* x_lo, int N, int H, int W, int nchunks,
+BINHIP_API int binhip_unshuffle_planes(const void* x_hi, const void* x_lo, int N, int H, int W, int nchunks,
                             void* y_hi, void* y_lo, void* stream);
 /* input-frame gradients of one RDN: outs[i] = unshuffle(gX0)[frame i] * scale[1] + gout / n_images
  * (gx0 may be NULL: skip path only; outs[i] may be NULL: frame i needs no gradient)                   */
-int binhip_unpack_input_grads(const void* gx0_hi, const void* gx0_lo, const float* gout,
+BINHIP_API int binhip_unpack_input_grads(const void* gx0_hi, const void* gx0_lo, const float* gout,
                               const float* scale, int n_images, int N, int H, int W,
                               float* const* outs, void* stream);
 
 /* ---- ConvLSTM cell backward (autograd of RDN.py:74-82) ---------------------------------------------
  * Inputs as forward + g_h (grad of h', may be NULL) and g_c (grad of c', may be NULL); any output
  * pointer may be NULL.  dw [12,6,3,3], db [12] fp32 are overwritten.                                   */
-size_t binhip_convlstm_bwd_workspace_bytes(int N, int H, int W);
-int binhip_convlstm_bwd(const float* x, const float* c_prev, const float* h_prev, const float* w,
+BINHIP_API size_t binhip_convlstm_bwd_workspace_bytes(int N, int H, int W);
+BINHIP_API int binhip_convlstm_bwd(const float* x, const float* c_prev, const float* h_prev, const float* w,
                         const float* b, float forget_bias, int N, int H, int W, const float* g_h,
                         const float* g_c, void* workspace, size_t workspace_bytes, float* gx,
                         float* g_hprev, float* g_cprev, float* dw, float* db, void* stream);
@@ -260,8 +266,8 @@ typedef struct BinRdnBwdPlan {
                                             /* overlapping the backward-data chain (event-ordered inside the call;  */
                                             /* joined into `stream` before return).  NULL: everything on `stream`   */
 } BinRdnBwdPlan;
-size_t binhip_rdn_backward_workspace_bytes(int N, int H, int W, int n_inputs, int nterms);
-int binhip_rdn_backward(const BinRdnBwdPlan* plan, const void* saved, size_t saved_bytes,
+BINHIP_API size_t binhip_rdn_backward_workspace_bytes(int N, int H, int W, int n_inputs, int nterms);
+BINHIP_API int binhip_rdn_backward(const BinRdnBwdPlan* plan, const void* saved, size_t saved_bytes,
                         const float* gout, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- live kernel timing (bench.py roofline leg) --------------------------------------------------
@@ -271,9 +277,9 @@ int binhip_rdn_backward(const BinRdnBwdPlan* plan, const void* saved, size_t sav
  * kernel time and the launch count, and rewinds the handle.  Not thread-safe per handle (use one per
  * host thread); the library itself keeps no global timing state.                                   */
 typedef struct BinhipProfiler BinhipProfiler;
-int binhip_profiler_create(int ksize, int cout_pad, int epilogue, int max_launches, BinhipProfiler** out);
-int binhip_profiler_read(BinhipProfiler* p, double* total_ms, int* launches);
-void binhip_profiler_destroy(BinhipProfiler* p);
+BINHIP_API int binhip_profiler_create(int ksize, int cout_pad, int epilogue, int max_launches, BinhipProfiler** out);
+BINHIP_API int binhip_profiler_read(BinhipProfiler* p, double* total_ms, int* launches);
+BINHIP_API void binhip_profiler_destroy(BinhipProfiler* p);
 
 #ifdef __cplusplus
 }

@@ -34,6 +34,16 @@ def test_library_exports_every_header_symbol():
     assert "binhip_profile_begin" not in declared and "set_variant" not in hdr
 
 
+def test_library_exports_nothing_but_the_abi():
+    """-fvisibility=hidden + a version script generated from the header: the dynamic symbol table is EXACTLY the entry
+    points of include/binhip.h — no bh_* launch helpers, no kernel handles / device stubs."""
+    import subprocess
+    from bin_amd import _lib, build
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    dyn = {ln.split()[-1].split("@")[0] for ln in out.splitlines() if ln.strip()}
+    assert dyn == set(build.abi_symbols()) == set(_lib.exported_symbols()), dyn ^ set(build.abi_symbols())
+
+
 def test_library_host_queries():
     from bin_amd import _lib
     lib = _lib.lib()

@@ -146,11 +146,9 @@ def test_rdn_backward_vs_oracle_autograd(set_name, k, prec, tol, canon_cpu, monk
     rounding noise of the operands remains, measured ~1e-3 relative."""
     from bin_amd import autograd as ag
     from bin_amd.models.archs import RDN as A
+    bwd = None
     if prec == "mixed":
-        monkeypatch.setattr(ag, "BACKWARD_PRECISION", "f16")
-        prec = "f16x3"
-    else:
-        monkeypatch.setattr(ag, "BACKWARD_PRECISION", None)
+        bwd, prec = "f16", "f16x3"
     from bin_amd.weights import rdn_param_shapes
     from oracle import rdn_oracle as O
     cls = {2: A.RDN_residual_interp_2_input, 3: A.RDN_residual_interp_2_1_input, 5: A.RDN_residual_interp_4_1_input}[k]
@@ -158,6 +156,7 @@ def test_rdn_backward_vs_oracle_autograd(set_name, k, prec, tol, canon_cpu, monk
     mod.load_state_dict({n: canon_cpu[f"{set_name}.{n}"] for n in rdn_param_shapes(k)})
     mod = mod.cuda()
     mod.precision = prec
+    mod.backward_precision = bwd           # a per-module attribute (not a process-wide switch)
     gen = torch.Generator().manual_seed(11)
     ins = [torch.rand(1, 3, 32, 48, generator=gen) for _ in range(k)]
     gout = torch.randn(1, 3, 32, 48, generator=gen) * 1e-3
@@ -176,7 +175,7 @@ def test_rdn_backward_vs_oracle_autograd(set_name, k, prec, tol, canon_cpu, monk
     assert ins_gpu[0].grad is None
     for a, b in zip(ins_gpu[1:], ins_cpu[1:]):
         assert _rel(a.grad.cpu(), b.grad) <= tol
-    print(f"{set_name} {prec} backward={ag.BACKWARD_PRECISION}: worst relative parameter-gradient error {worst:.2e}")
+    print(f"{set_name} {prec} backward={mod.backward_precision}: worst relative parameter-gradient error {worst:.2e}")
 
 
 def test_training_step_matches_reference_golden(tmp_path):
@@ -247,7 +246,7 @@ def test_three_training_steps_match_reference_golden(tmp_path):
 
 
 def test_direct_param_grads_equal_autograd_accumulation():
-    """bin_amd.autograd.DIRECT_PARAM_GRADS: the kernels write / accumulate weight gradients straight into .grad
+    """net.direct_param_grads(): the kernels write / accumulate weight gradients straight into .grad
     (BINHIP_BWD_ACCUMULATE) instead of returning them to autograd's AccumulateGrad.  Same values added in the same order
     => every gradient of the whole net is bit-identical, with and without pre-existing (flat-view) .grad buffers."""
     from bin_amd import autograd as ag
@@ -264,11 +263,9 @@ def test_direct_param_grads_equal_autograd_accumulation():
             FlatGradAllReduce(net.parameters()).attach()
         out = net(*frames)
         loss = sum((o * o).mean() for o in out)
-        ag.DIRECT_PARAM_GRADS = direct
-        try:
+        with net.direct_param_grads(direct):
             loss.backward()
-        finally:
-            ag.DIRECT_PARAM_GRADS = False
+        assert not any(m.direct_param_grads for m in net.rdn_modules())
         return {n: p.grad.clone() for n, p in net.named_parameters()}
 
     base = run(False, False)
