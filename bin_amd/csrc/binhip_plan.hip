@@ -347,77 +347,84 @@ int binhip_rdn_backward(const BinRdnBwdPlan* p, const void* saved, size_t saved_
         return bh_launch_conv(c, s);
     };
 
-    // ---- UPNet.2 (64 -> 3 at full res): X = U
-    if ((rc = wgrad(65, 3, H, W, 4, 64, 3, w.u, w.s_u, 0, 0, b.gout, b.s_gout, 0))) return rc;
-    if ((rc = dgrad(65, 3, H, W, 1, 64, b.gout, b.s_gout, b.gu, b.s_gu, -1, 0, 0, false, -1, 0, 0, 0))) return rc;
-    // ---- PixelShuffle backward, then UPNet.0 (96 -> 256): X = G1
-    if ((rc = binhip_unshuffle_planes(GH(b.gu), GL(b.gu, b.s_gu), N, h, ww, 4, GH(b.guu), GL(b.guu, b.s_guu), stream))) return rc;
-    if ((rc = wgrad(64, 3, h, ww, 6, 96, 256, w.g1, w.s_g, 0, 0, b.guu, b.s_guu, 1))) return rc;
-    if ((rc = dgrad(64, 3, h, ww, 16, 96, b.guu, b.s_guu, b.gg1, b.s_g, -1, 0, 0, false, -1, 0, 0, 0))) return rc;
-    // ---- GFF.1 (+ f__1 skip): X = G0
-    if ((rc = wgrad(63, 3, h, ww, 6, 96, 96, w.g0, w.s_g, 0, 0, b.gg1, b.s_g, 0))) return rc;
-    if ((rc = dgrad(63, 3, h, ww, 6, 96, b.gg1, b.s_g, b.gg0, b.s_g, -1, 0, 0, false, -1, 0, 0, 0))) return rc;
-    // ---- GFF.0 over cat(RDB outputs): X = BLK[1..12][0:6]; gradient scattered to GY[1..12]
-    if ((rc = wgrad(62, 1, h, ww, 72, 1152, 96, w.blk + 14 * P, w.s_blk, 6, 14 * P, b.gg0, b.s_g, 0))) return rc;
-    if ((rc = dgrad(62, 1, h, ww, 6, 1152, b.gg0, b.s_g, b.gy + 6 * P, b.s_gy, -1, 0, 0, false, -1, 0, 6, 6 * P))) return rc;
-    // ---- the 12 residual dense blocks, last to first
+    // Everything below may have work in flight on the side stream: every exit — error or not — goes through ONE epilogue
+    // that destroys the pending per-block events and joins the side stream into the main stream (the caller reuses
+    // `workspace` / frees `saved` in main-stream order, also after a failed call).
     hipEvent_t b_done[12] = {};
-    for (int d = 11; d >= 0; --d) {
-        const int64_t blk = w.blk + (int64_t)d * 14 * P;      // saved forward buffer of RDB d
-        const int64_t gy = b.gy + (int64_t)(d + 1) * 6 * P;   // grad of RDB d's output
-        const int64_t gcat = (d & 1) ? b.gcat2 : b.gcat;      // this block's gradient-concat buffer
-        const int L = 2 + 5 * d;
-        // LFF 1x1 224 -> 96 (+x): gcat = W'^T gy (+ gy on the first 6 chunks); ReLU mask of conv 3's output
-        if ((rc = wgrad(L + 4, 1, h, ww, 14, 224, 96, blk, w.s_blk, 0, 0, gy, b.s_gy, 0, 4))) return rc;
-        // block d+2 used this gcat buffer: its weight gradients (side stream) must have read it before it is refilled.
-        // Everything queued on the side stream up to here is older than block d+1's wgrads, so a plain join suffices
-        // only every other block would over-serialise; the side stream is in order, so "block d+2 done" = an event
-        // recorded there right after block d+2's last wgrad.
-        if (two && d + 2 <= 11 && b_done[d + 2]) {
-            hipError_t r = hipStreamWaitEvent(s, b_done[d + 2], 0);
-            (void)hipEventDestroy(b_done[d + 2]);
-            b_done[d + 2] = nullptr;
-            if (r != hipSuccess) return (int)r;
-        }
-        if ((rc = dgrad(L + 4, 1, h, ww, 6, 224, gy, b.s_gy, gcat, b.s_gcat, gy, b.s_gy, 6, false, blk, 12, 0, 0))) return rc;
-        // The four 3x3 convs in gather form (binhip_weights_relayout_rdb_gather): every group of gcat is produced
-        // ONCE as L_g + conv(stacked G_c of the later convs) instead of being read-modified-written by each of them.
-        for (int c = 3; c >= 0; --c) {
-            const int64_t gyc = gcat + (int64_t)(6 + 2 * c) * P;       // G_c .. G_3, contiguous chunks
-            if ((rc = wgrad(L + c, 3, h, ww, 6 + 2 * c, 96 + 32 * c, 32, blk, w.s_blk, 0, 0, gyc, b.s_gcat, 0, c))) return rc;
-            if (c > 0) {
-                // group c = conv c-1's output slot (chunks 4+2c, 5+2c): G_{c-1} = relu'( L_c + sum_{c' >= c} dgrad_c' )
-                const int64_t slot = gcat + (int64_t)(4 + 2 * c) * P;
-                if ((rc = dgrad(L + c, 3, h, ww, 2 * (4 - c), 32, gyc, b.s_gcat, slot, b.s_gcat, slot, b.s_gcat, 0, false,
-                                blk + (int64_t)(4 + 2 * c) * P, 0, 0, 0))) return rc;
-            } else {
-                // group 0: L_0 + all four convs -> grad of the block input = GY[d] (already holds GFF.0's share when d >= 1)
-                if ((rc = dgrad(L, 3, h, ww, 8, 96, gyc, b.s_gcat, b.gy + (int64_t)d * 6 * P, b.s_gy, gcat, b.s_gcat, 0,
-                                d >= 1, -1, 0, 0, 0))) return rc;
+    auto chain = [&]() -> int {
+        // ---- UPNet.2 (64 -> 3 at full res): X = U
+        if ((rc = wgrad(65, 3, H, W, 4, 64, 3, w.u, w.s_u, 0, 0, b.gout, b.s_gout, 0))) return rc;
+        if ((rc = dgrad(65, 3, H, W, 1, 64, b.gout, b.s_gout, b.gu, b.s_gu, -1, 0, 0, false, -1, 0, 0, 0))) return rc;
+        // ---- PixelShuffle backward, then UPNet.0 (96 -> 256): X = G1
+        if ((rc = binhip_unshuffle_planes(GH(b.gu), GL(b.gu, b.s_gu), N, h, ww, 4, GH(b.guu), GL(b.guu, b.s_guu), stream))) return rc;
+        if ((rc = wgrad(64, 3, h, ww, 6, 96, 256, w.g1, w.s_g, 0, 0, b.guu, b.s_guu, 1))) return rc;
+        if ((rc = dgrad(64, 3, h, ww, 16, 96, b.guu, b.s_guu, b.gg1, b.s_g, -1, 0, 0, false, -1, 0, 0, 0))) return rc;
+        // ---- GFF.1 (+ f__1 skip): X = G0
+        if ((rc = wgrad(63, 3, h, ww, 6, 96, 96, w.g0, w.s_g, 0, 0, b.gg1, b.s_g, 0))) return rc;
+        if ((rc = dgrad(63, 3, h, ww, 6, 96, b.gg1, b.s_g, b.gg0, b.s_g, -1, 0, 0, false, -1, 0, 0, 0))) return rc;
+        // ---- GFF.0 over cat(RDB outputs): X = BLK[1..12][0:6]; gradient scattered to GY[1..12]
+        if ((rc = wgrad(62, 1, h, ww, 72, 1152, 96, w.blk + 14 * P, w.s_blk, 6, 14 * P, b.gg0, b.s_g, 0))) return rc;
+        if ((rc = dgrad(62, 1, h, ww, 6, 1152, b.gg0, b.s_g, b.gy + 6 * P, b.s_gy, -1, 0, 0, false, -1, 0, 6, 6 * P))) return rc;
+        // ---- the 12 residual dense blocks, last to first
+        for (int d = 11; d >= 0; --d) {
+            const int64_t blk = w.blk + (int64_t)d * 14 * P;      // saved forward buffer of RDB d
+            const int64_t gy = b.gy + (int64_t)(d + 1) * 6 * P;   // grad of RDB d's output
+            const int64_t gcat = (d & 1) ? b.gcat2 : b.gcat;      // this block's gradient-concat buffer
+            const int L = 2 + 5 * d;
+            // LFF 1x1 224 -> 96 (+x): gcat = W'^T gy (+ gy on the first 6 chunks); ReLU mask of conv 3's output
+            if ((rc = wgrad(L + 4, 1, h, ww, 14, 224, 96, blk, w.s_blk, 0, 0, gy, b.s_gy, 0, 4))) return rc;
+            // block d+2 used this gcat buffer: its weight gradients (side stream) must have read it before it is refilled.
+            // Everything queued on the side stream up to here is older than block d+1's wgrads, so a plain join suffices
+            // only every other block would over-serialise; the side stream is in order, so "block d+2 done" = an event
+            // recorded there right after block d+2's last wgrad.
+            if (two && d + 2 <= 11 && b_done[d + 2]) {
+                hipError_t r = hipStreamWaitEvent(s, b_done[d + 2], 0);
+                (void)hipEventDestroy(b_done[d + 2]);
+                b_done[d + 2] = nullptr;
+                if (r != hipSuccess) return (int)r;
+            }
+            if ((rc = dgrad(L + 4, 1, h, ww, 6, 224, gy, b.s_gy, gcat, b.s_gcat, gy, b.s_gy, 6, false, blk, 12, 0, 0))) return rc;
+            // The four 3x3 convs in gather form (binhip_weights_relayout_rdb_gather): every group of gcat is produced
+            // ONCE as L_g + conv(stacked G_c of the later convs) instead of being read-modified-written by each of them.
+            for (int c = 3; c >= 0; --c) {
+                const int64_t gyc = gcat + (int64_t)(6 + 2 * c) * P;       // G_c .. G_3, contiguous chunks
+                if ((rc = wgrad(L + c, 3, h, ww, 6 + 2 * c, 96 + 32 * c, 32, blk, w.s_blk, 0, 0, gyc, b.s_gcat, 0, c))) return rc;
+                if (c > 0) {
+                    // group c = conv c-1's output slot (chunks 4+2c, 5+2c): G_{c-1} = relu'( L_c + sum_{c' >= c} dgrad_c' )
+                    const int64_t slot = gcat + (int64_t)(4 + 2 * c) * P;
+                    if ((rc = dgrad(L + c, 3, h, ww, 2 * (4 - c), 32, gyc, b.s_gcat, slot, b.s_gcat, slot, b.s_gcat, 0, false,
+                                    blk + (int64_t)(4 + 2 * c) * P, 0, 0, 0))) return rc;
+                } else {
+                    // group 0: L_0 + all four convs -> grad of the block input = GY[d] (already holds GFF.0's share when d >= 1)
+                    if ((rc = dgrad(L, 3, h, ww, 8, 96, gyc, b.s_gcat, b.gy + (int64_t)d * 6 * P, b.s_gy, gcat, b.s_gcat, 0,
+                                    d >= 1, -1, 0, 0, 0))) return rc;
+                }
+            }
+            if ((rc = flush_reduces())) return rc;                       // the block's five layers in one reduce launch
+            if (two) {
+                hipError_t r = hipEventCreateWithFlags(&b_done[d], hipEventDisableTiming);
+                if (r == hipSuccess) r = hipEventRecord(b_done[d], sb);
+                if (r != hipSuccess) return (int)r;
             }
         }
-        if ((rc = flush_reduces())) return rc;                       // the block's five layers in one reduce launch
-        if (two) {
-            hipError_t r = hipEventCreateWithFlags(&b_done[d], hipEventDisableTiming);
-            if (r == hipSuccess) r = hipEventRecord(b_done[d], sb);
-            if (r != hipSuccess) return (int)r;
+        // ---- SFENet2: X = F1; gF1 = dgrad + gG1 (the `x += f__1` skip)
+        if ((rc = wgrad(1, 3, h, ww, 6, 96, 96, w.f1, w.s_f1, 0, 0, b.gy, b.s_gy, 0))) return rc;
+        if ((rc = dgrad(1, 3, h, ww, 6, 96, b.gy, b.s_gy, b.gf1, b.s_g, b.gg1, b.s_g, 0, false, -1, 0, 0, 0))) return rc;
+        // ---- SFENet1 5x5: X = X0
+        if ((rc = wgrad(0, 5, h, ww, w.kc0, 12 * nin, 96, w.x0, w.s_x0, 0, 0, b.gf1, b.s_g, 0))) return rc;
+        bool need_in = false;
+        for (int i = 0; i < nin; ++i) need_in = need_in || (p->gin[i] != nullptr);
+        if (need_in) {
+            if ((rc = dgrad(0, 5, h, ww, 6, 12 * nin, b.gf1, b.s_g, b.gx0, b.s_gx0, -1, 0, 0, false, -1, 0, 0, 0))) return rc;
+            if ((rc = binhip_unpack_input_grads(GH(b.gx0), GL(b.gx0, b.s_gx0), gout, sc, nin, N, H, W, p->gin, stream))) return rc;
         }
-    }
+        return 0;
+    };
+    rc = chain();
     for (int d = 0; d < 12; ++d)
         if (b_done[d]) { (void)hipEventDestroy(b_done[d]); b_done[d] = nullptr; }
-    // ---- SFENet2: X = F1; gF1 = dgrad + gG1 (the `x += f__1` skip)
-    if ((rc = wgrad(1, 3, h, ww, 6, 96, 96, w.f1, w.s_f1, 0, 0, b.gy, b.s_gy, 0))) return rc;
-    if ((rc = dgrad(1, 3, h, ww, 6, 96, b.gy, b.s_gy, b.gf1, b.s_g, b.gg1, b.s_g, 0, false, -1, 0, 0, 0))) return rc;
-    // ---- SFENet1 5x5: X = X0
-    if ((rc = wgrad(0, 5, h, ww, w.kc0, 12 * nin, 96, w.x0, w.s_x0, 0, 0, b.gf1, b.s_g, 0))) return rc;
-    bool need_in = false;
-    for (int i = 0; i < nin; ++i) need_in = need_in || (p->gin[i] != nullptr);
-    if (need_in) {
-        if ((rc = dgrad(0, 5, h, ww, 6, 12 * nin, b.gf1, b.s_g, b.gx0, b.s_gx0, -1, 0, 0, false, -1, 0, 0, 0))) return rc;
-        if ((rc = binhip_unpack_input_grads(GH(b.gx0), GL(b.gx0, b.s_gx0), gout, sc, nin, N, H, W, p->gin, stream))) return rc;
-    }
-    // the caller reuses `workspace` / frees `saved` in main-stream order: join the side stream before returning
-    return order(sb, s);
+    const int rj = order(sb, s);
+    return rc ? rc : rj;
 }
 
 }  // extern "C"

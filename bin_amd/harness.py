@@ -114,6 +114,8 @@ class GraphedNet:
                     netG(*self.static_in)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
+            from .rdn_plan import release_workspaces
+            release_workspaces(side)                     # the warm-up stream dies here: do not keep its workspace
             if self.multi_stream:
                 self.inner._graph_mode = "capture"
                 try:

@@ -404,6 +404,7 @@ def _forward_streams(self, B, stage1_cache=None, input_events=None):
     mode = getattr(self, "_graph_mode", None)                           # None | "capture" | "replay" (harness.GraphedNet)
     if mode == "capture":
         self._call_graphs = []
+    pools = {}
     counter = [0]
 
     def launch(si, fn, ins):
@@ -420,8 +421,12 @@ def _forward_streams(self, B, stage1_cache=None, input_events=None):
             # Capturing the WHOLE multi-stream forward into one graph crashes hipStreamEndCapture on ROCm 7.2 as soon
             # as two captured streams depend on each other in both directions (tools/probe_graph.py), so the
             # cross-stream edges stay eager events and only the launch-heavy bodies are graphs.
+            # Graphs captured on ONE stream replay in order, so they share a memory pool (a call's workspace, freed when
+            # its capture ends, is reused by the next call's); graphs of different streams replay concurrently and
+            # must not.
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=s):
+            pool = pools.setdefault(si % len(streams), torch.cuda.graph_pool_handle())
+            with torch.cuda.graph(g, stream=s, pool=pool):
                 out = fn()
             self._call_graphs.append((g, out))
         elif mode == "replay":

@@ -147,34 +147,68 @@ class FlatGradAllReduce:
         if (start, end) not in self._reduced:
             self._reduce_slice(start, end, overlap=True)
 
+    def _join(self):
+        """Order the caller's stream after everything queued on the side stream (the early bucket all-reduces)."""
+        if self._stream is not None and self.flat is not None and self.flat.is_cuda:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self._stream)
+
     def __call__(self):
         import torch.distributed as dist
         if not self._active():
             return
         world = dist.get_world_size()
         if not self._views_intact():
-            self._gather()                       # somebody replaced a .grad (or attach() was skipped): copy in
-            self._reduced = []
+            # Somebody replaced a .grad (or attach() was skipped).  The early all-reduces may still be in flight on the
+            # side stream: join it BEFORE touching the buffer, then copy the strays in and take THEIR ranges out of the
+            # already-reduced set (a slice summed before its stray arrived holds stale data for that parameter; the rest
+            # of the slice is already a sum over ranks and must not be reduced a second time).
+            self._join()
+            self._reduced = _subtract(self._reduced, self._gather())
         # the remainder: maximal runs of the buffer not covered by an early bucket
         pos = 0
         for start, end in sorted(self._reduced) + [(self.numel, self.numel)]:
             if start > pos:
                 self._reduce_slice(pos, start, overlap=False)
             pos = max(pos, end)
-        if self._stream is not None and self.flat.is_cuda:
-            torch.cuda.current_stream(self.flat.device).wait_stream(self._stream)
+        self._join()
         self._reduced = []
         if world > 1:
             self.flat.div_(world)
 
     def _gather(self):
+        """Re-point every stray .grad at its slice of the flat buffer (copying its values in); returns the strays' ranges."""
         dev = self.params[0].device
-        flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        if self.flat is None or self.flat.device != dev:
+            self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        base = self.flat.data_ptr()
+        strays = []
         for p, o in zip(self.params, self._offsets()):
-            if p.grad is not None:
-                flat[o:o + p.numel()].copy_(p.grad.reshape(-1))
-            p.grad = flat[o:o + p.numel()].view_as(p)
-        self.flat = flat
+            view = self.flat[o:o + p.numel()].view_as(p)
+            if p.grad is None:
+                view.zero_()
+            elif p.grad.data_ptr() == base + 4 * o:
+                continue
+            else:
+                view.copy_(p.grad.reshape(p.shape))
+            p.grad = view
+            strays.append((o, o + p.numel()))
+        return strays
+
+
+def _subtract(ranges, holes):
+    """Intervals of `ranges` not covered by any of `holes` (half-open [start, end) pairs)."""
+    out = []
+    for s, e in sorted(ranges):
+        pos = s
+        for hs, he in sorted(holes):
+            if he <= pos or hs >= e:
+                continue
+            if hs > pos:
+                out.append((pos, hs))
+            pos = max(pos, he)
+        if pos < e:
+            out.append((pos, e))
+    return out
 
 
 class bin_model(BaseModel):

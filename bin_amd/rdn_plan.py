@@ -107,19 +107,42 @@ class RdnDgradWeights:
         plan.zero_bias = self.zero_bias.data_ptr()
 
 
-_workspaces = {}
+from collections import OrderedDict as _OrderedDict
+
+_workspaces = _OrderedDict()          # (device type, index, stream handle, purpose) -> uint8 tensor, least recently used first
+WORKSPACE_CACHE_ENTRIES = 12          # per process; an evicted entry is simply re-allocated by its next user
 
 
 def workspace(nbytes, device, key="fwd"):
     """One cached workspace per (device, CURRENT STREAM, purpose), grown on demand.  The stream is part of the key
     because a workspace is only ordered against its own stream's work: two host threads (or two networks) driving
-    different streams of one device must never share one."""
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream, key)
+    different streams of one device must never share one.
+    Lifetime: the cache is a small LRU (a stream that stops calling loses its multi-GB workspace once
+    WORKSPACE_CACHE_ENTRIES other (stream, purpose) pairs have been used; `release_workspaces(stream)` drops a dead
+    stream's entries at once), and a workspace allocated DURING graph capture is never cached: it belongs to the
+    graph's private pool, which keeps the memory alive for the graph's replays and for nobody else."""
+    stream = torch.cuda.current_stream(device)
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+    key = (device.type, device.index, stream.cuda_stream, key)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         _workspaces[key] = ws
+        while len(_workspaces) > WORKSPACE_CACHE_ENTRIES:
+            _workspaces.popitem(last=False)
+    _workspaces.move_to_end(key)
     return ws
+
+
+def release_workspaces(stream=None):
+    """Drop the cached workspaces of `stream` (a torch.cuda.Stream about to die — its raw handle may be recycled for an
+    unrelated stream), or all of them.  The caching allocator keeps the memory ordered against the stream it was used on."""
+    if stream is None:
+        _workspaces.clear()
+        return
+    for k in [k for k in _workspaces if k[2] == stream.cuda_stream and k[1] == stream.device.index]:
+        del _workspaces[k]
 
 
 import os as _os

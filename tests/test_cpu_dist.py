@@ -97,3 +97,57 @@ def test_flat_grad_views_accumulate_in_place():
     assert torch.equal(ref, sync.flat) and float(sync.flat.abs().sum()) > 0
     sync.attach()                                       # next step: zeroed, same storage
     assert float(sync.flat.abs().sum()) == 0 and [p.grad.data_ptr() for p in net.parameters()] == ptrs
+
+
+def test_interval_subtraction():
+    from bin_amd.models.bin_model import _subtract
+    assert _subtract([(0, 10)], []) == [(0, 10)]
+    assert _subtract([(0, 10)], [(3, 5)]) == [(0, 3), (5, 10)]
+    assert _subtract([(0, 10), (20, 30)], [(8, 22), (25, 26)]) == [(0, 8), (22, 25), (26, 30)]
+    assert _subtract([(0, 10)], [(0, 10)]) == []
+    assert _subtract([(5, 7)], [(0, 100)]) == []
+
+
+def _stray_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from bin_amd.models.bin_model import FlatGradAllReduce
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2), torch.nn.Linear(2, 1))
+        params = list(net.parameters())
+        sync = FlatGradAllReduce(params)
+        sync.attach()
+        local = [torch.full_like(p, float(rank + 1) * (i + 1)) for i, p in enumerate(params)]
+        for p, g in zip(params, local):
+            p.grad.copy_(g)
+        # an "early bucket": the first two layers' slice is reduced before the rest of the backward ...
+        end = sum(p.numel() for p in params[:4])
+        sync._reduce_slice(0, end, overlap=False)
+        # ... and afterwards somebody REPLACES one of its gradients by a fresh (local, unreduced) tensor
+        params[1].grad = local[1].clone() * 10
+        sync()
+        want = [(g * 10 if i == 1 else g) for i, g in enumerate(local)]
+        # mean over ranks of rank-local values: local_r = (r + 1) * c  ->  mean = 1.5 * c for world 2
+        ok = all(torch.allclose(p.grad, w / float(rank + 1) * 1.5) for p, w in zip(params, want))
+        views = sync._views_intact()
+        q.put((rank, ok, views))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_replaced_grad_after_an_early_bucket_reduce_is_averaged_once():
+    """a .grad replaced after its bucket was already all-reduced must be reduced exactly once more (that
+    parameter only), the rest of the bucket must NOT be summed a second time."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_stray_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == [(0, True, True), (1, True, True)], got
