@@ -63,16 +63,60 @@ def rdb_conv_flops(n, h2, w2):
     return sum(per) / len(per)
 
 
+def rdn_call_model(n_inputs, px):
+    """(algorithmic FLOPs, algorithmic bytes at 4 B/element) of ONE RDN call over `px` half-resolution pixels, layer by
+    layer as SURVEY.md §8(d) counts them: 2*Cin*Cout*k*k per output pixel; every conv reads its input once and writes
+    its output once (concat free, elementwise fused), weights once.  At px = 258 048 this reproduces SURVEY's
+    1450.7 / 1465.5 / 1495.3 GFLOP and 15.14 / 15.16 / 15.18 GB."""
+    convs = [(5, 12 * n_inputs, 96, 1), (3, 96, 96, 1)]                       # SFENet1, SFENet2   (k, cin, cout, px multiplier)
+    for _ in range(12):
+        convs += [(3, 96 + 32 * c, 32, 1) for c in range(4)] + [(1, 224, 96, 1)]
+    convs += [(1, 1152, 96, 1), (3, 96, 96, 1), (3, 96, 256, 1), (3, 64, 3, 4)]      # GFF.0, GFF.1, UPNet.0, UPNet.2 (full res)
+    flops = sum(2.0 * k * k * ci * co * px * m for k, ci, co, m in convs)
+    byts = sum(4.0 * (ci + co) * px * m + 4.0 * k * k * ci * co for k, ci, co, m in convs)
+    return flops, byts
+
+
+CALLS_17 = ((2, 5), (3, 6), (5, 6))          # (input frames, calls per 6-frame window) of the exact 17-call schedule
+
+
+def window_model(px):
+    """(FLOPs, bytes) of one 6-frame forward in the 17-call schedule (the ConvLSTM cells' 6 x 1.34 GFLOP at 720p excluded)."""
+    f = b = 0.0
+    for nin, calls in CALLS_17:
+        cf, cb = rdn_call_model(nin, px)
+        f += calls * cf
+        b += calls * cb
+    return f, b
+
+
+def wgrad3x3_launch_model(batch, h2, w2):
+    """Mean algorithmic (FLOPs, bytes at 4 B/element) of ONE launch of the 3x3 weight-gradient kernel in the training mix:
+    the four-call schedule runs model1..4 with N = 5B, 6B, 4B, 2B images; each call has 12 x 4 dense-block convs
+    (Cin = 96, 128, 160, 192 -> 32): the kernel reads X (Cin planes) and gY (32 planes) once and writes dW."""
+    fl = by = 0.0
+    cnt = 0
+    for n in (5 * batch, 6 * batch, 4 * batch, 2 * batch):
+        px = n * h2 * w2
+        for cin in (96, 128, 160, 192):
+            fl += 2.0 * 9 * cin * 32 * px
+            by += 4.0 * (cin + 32) * px + 4.0 * 9 * cin * 32
+            cnt += 1
+    return fl / cnt, by / cnt
+
+
 def pmc_traffic(precision):
     """HBM bytes per launch of the dominant kernel IN THIS PRECISION MODE from the committed rocprofv3 PMC passes of
-    this same command (profiles/r02_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs per precision, FETCH
+    this same command (profiles/r03_pmc_traffic.json, else r02_: separate FETCH_SIZE / WRITE_SIZE runs per precision, FETCH
     doubled per the gfx950 calibration).  PMC counters cannot be read from inside the process, so bench.py reports the
     profiled figure, or null when no pass for this precision is committed."""
-    try:
-        with open(os.path.join(REPO, "profiles", "r02_pmc_traffic.json")) as f:
-            return int(json.load(f)[precision]["traffic_bytes_per_launch"])
-    except Exception:
-        return None
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        try:
+            with open(os.path.join(REPO, "profiles", name)) as f:
+                return int(json.load(f)[precision]["traffic_bytes_per_launch"])
+        except Exception:
+            pass
+    return None
 
 
 def cpu_model():
@@ -206,17 +250,40 @@ def train_bench(args, rank, world, dev, steps=None, warmup=None, standalone=True
             dist.barrier()
         torch.cuda.synchronize()
 
-    from bin_amd import ops
+    from bin_amd import ops, _lib as L
+    from bin_amd.utils.smi import Sampler
     torch.cuda.reset_peak_memory_stats()
     for i in range(warmup):
         m.optimize_parameters(i + 1)
     sync_all()
+    smi = Sampler(dev.index or 0).start()
     t0 = time.perf_counter()
     for i in range(steps):
         m.optimize_parameters(warmup + i + 1)
     sync_all()
     dt = time.perf_counter() - t0
+    power = smi.stop()
     ops.check_status()                       # no activation / gradient left the fp16 storage range
+    # ---- roofline of the step and of its dominant kernel (3x3 weight gradient): two more steps AFTER the timed region
+    # with the weight-gradient launches bracketed by HIP events on the stream they run on (BINHIP_PROF_WGRAD)
+    kern = None
+    lib = L.lib()
+    handle = ctypes.c_void_p(0)
+    prof_steps = 2
+    net = m.netG.module
+    if rank == 0:                            # every rank runs the two extra steps (collectives stay matched); rank 0 times them
+        L.check(lib.binhip_profiler_create(3, 32, L.PROF_WGRAD, prof_steps * 4 * 48, ctypes.byref(handle)), "profiler_create")
+        net.set_profiler(handle, backward=True)
+    for i in range(prof_steps):
+        m.optimize_parameters(warmup + steps + i + 1)
+    torch.cuda.synchronize()
+    if rank == 0:
+        net.set_profiler(None, backward=True)
+        kms, kn = ctypes.c_double(0), ctypes.c_int(0)
+        L.check(lib.binhip_profiler_read(handle, ctypes.byref(kms), ctypes.byref(kn)), "profiler_read")
+        lib.binhip_profiler_destroy(handle)
+        if kn.value:
+            kern = (kms.value / kn.value * 1e-3, kn.value)
     t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
@@ -228,6 +295,9 @@ def train_bench(args, rank, world, dev, steps=None, warmup=None, standalone=True
         "vs_baseline": None, "dtype": DTYPE[prec] + (" forward; single-product backward on the hi planes" if bwd_prec else ""),
         "data": "synthetic", "loss": float(m.loss.detach()),
         "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2),
+        "nccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1),
+        "power": power,
+        "roofline": train_roofline(B, S, dt / steps, prec, bwd_prec, kern),
         "config": {"workload": f"Adobe240 training, 256x256 crops, batch {B} per GPU, Charbonnier x17, Adam, "
                                f"DP flat gradient all-reduce (45.77 MB)", "precision": prec,
                    "backward_precision": bwd_prec or prec}}
@@ -240,6 +310,91 @@ def train_bench(args, rank, world, dev, steps=None, warmup=None, standalone=True
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def kernel_roofline(prec, kern_ms, kern_n, hp, wp, ms, reuse_schedule):
+    """`roofline` object of the inference window in precision `prec`: the dominant kernel (dense-block 3x3 conv,
+    Cin -> 32) from its event-timed mean duration, plus the whole forward's algorithmic rates.  Every `frac` can be
+    recomputed from the fields beside it."""
+    if kern_n <= 0:
+        return None
+    flops = FLOP_17 if reuse_schedule else FLOP_20
+    abytes = (BYTES_17 if reuse_schedule else BYTES_20) * BYTES_PER_ELEM[prec] / 4.0
+    whole_gbs = abytes / (ms * 1e-3) / 1e9
+    avg_s = kern_ms / kern_n * 1e-3
+    ab = rdb_conv_algorithmic_bytes(1, hp // 2, wp // 2, prec)
+    ach = ab / avg_s / 1e9
+    mf = rdb_conv_flops(1, hp // 2, wp // 2) * PRODUCTS[prec] / avg_s / 1e12
+    assert ach <= HBM_PEAK_GBS, f"kernel algorithmic rate {ach:.0f} GB/s exceeds the HBM peak"
+    assert whole_gbs <= HBM_PEAK_GBS, f"whole-forward algorithmic rate {whole_gbs:.0f} GB/s exceeds the HBM peak"
+    kname = ("conv_x3_kernel<3,2,8,0,0>" if prec == "f16x3" else "conv_mfma_kernel<3,1,1,2,8,1,1,2,0>")
+    return {"bound": "hbm", "kernel": kname + " (RDB conv3x3 Cin->32 +ReLU, convs 0-2 of each dense block)",
+            "precision": prec, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4),
+            "traffic": pmc_traffic(prec), "avg_kernel_us": round(avg_s * 1e6, 2), "launches": kern_n,
+            "algorithmic_bytes_per_launch": int(ab), "bytes_per_element": BYTES_PER_ELEM[prec],
+            "mfma": {"achieved": round(mf, 1), "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(mf / MFMA_PEAK_TF, 4),
+                     "note": f"executed MFMA FLOPs = {PRODUCTS[prec]} x the conv's algorithmic FLOPs; peak = nominal dense fp16 "
+                             "at 2.4 GHz — scale by power.clock_mhz / 2400 for the peak at the clock this run held",
+                     "reference_sustained_at_power_cap": {
+                         "random_fp16": 1663.0, "zeros": 2473.0, "unit": "TFLOP/s",
+                         "source": "profiles/r02_power_cap.md (register-resident v_mfma_f32_32x32x16_f16 alone, "
+                                   "tools/probe_mfma_power.hip); a round-2 measurement, NOT taken in this run — this run's "
+                                   "own clock and package power are in `power`"}},
+            "whole_forward": {"algorithmic_GB": round(abytes / 1e9, 1), "achieved_GBs": round(whole_gbs, 1),
+                              "frac_hbm": round(whole_gbs / HBM_PEAK_GBS, 4),
+                              "algorithmic_TFLOP": round(flops / 1e12, 3),
+                              "achieved_TFLOPs": round(flops / (ms * 1e-3) / 1e12, 1),
+                              "mfma_frac": round(flops * PRODUCTS[prec] / (ms * 1e-3) / 1e12 / MFMA_PEAK_TF, 4)}}
+
+
+def train_roofline(batch, size, step_s, prec, bwd_prec, kern):
+    """Roofline object of the training step: algorithmic work = 3 x the forward's (forward + backward-data + backward-
+    weight, each the same MACs and the same activation bytes; SURVEY §8d "training step ~ 3 x forward"), executed MFMA
+    FLOPs = products x algorithmic (the single-product backward of the mixed mode executes 1 x on two thirds of it).
+    `kern` = (mean seconds, launches) of the dominant kernel, the 3x3 weight gradient, from HIP events."""
+    h2 = w2 = size // 2
+    f_fwd, b_fwd = window_model(h2 * w2)
+    flops = 3.0 * f_fwd * batch
+    byts = 3.0 * b_fwd * batch * BYTES_PER_ELEM[prec] / 4.0
+    prod_f, prod_b = PRODUCTS[prec], (1 if bwd_prec else PRODUCTS[prec])
+    executed = (prod_f + 2.0 * prod_b) / 3.0 * flops
+    out = {"algorithmic_TFLOP_per_step": round(flops / 1e12, 2), "algorithmic_GB_per_step": round(byts / 1e9, 1),
+           "note": "3 x the 17-call forward of one 6-frame sample (SURVEY 8d layer model) x batch; bytes at the storage width",
+           "mfma": {"achieved": round(executed / step_s / 1e12, 1), "peak": MFMA_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": round(executed / step_s / 1e12 / MFMA_PEAK_TF, 4),
+                    "algorithmic_TFLOPs": round(flops / step_s / 1e12, 1)},
+           "hbm": {"achieved": round(byts / step_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": round(byts / step_s / 1e9 / HBM_PEAK_GBS, 4)}}
+    if kern:
+        avg_s, n = kern
+        kf, kb = wgrad3x3_launch_model(batch, h2, w2)
+        kb *= BYTES_PER_ELEM[prec] / 4.0
+        out["dominant_kernel"] = {
+            "kernel": "wgrad3x3_db_kernel (3x3 weight gradient of the dense-block convs, Cin = 96..192 -> 32)",
+            "avg_kernel_us": round(avg_s * 1e6, 2), "launches": n, "launches_per_step": 4 * 48,
+            "share_of_step": round(avg_s * 4 * 48 / step_s, 4),
+            "algorithmic_bytes_per_launch": int(kb), "bound": "hbm", "achieved": round(kb / avg_s / 1e9, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(kb / avg_s / 1e9 / HBM_PEAK_GBS, 4),
+            "traffic": pmc_wgrad_traffic(),
+            "mfma": {"achieved": round(kf * prod_b / avg_s / 1e12, 1), "peak": MFMA_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": round(kf * prod_b / avg_s / 1e12 / MFMA_PEAK_TF, 4)},
+            "timing": "HIP event pairs on the side stream the weight gradients run on, 2 steps right after the timed region "
+                      "(the kernel shares the chip with the backward-data chain of the main stream, as in the timed steps)"}
+    return out
+
+
+def pmc_wgrad_traffic():
+    """HBM-side bytes per launch of the 3x3 weight-gradient kernel from the committed PMC passes (profiles/), or null."""
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        try:
+            with open(os.path.join(REPO, "profiles", name)) as f:
+                v = json.load(f).get("wgrad3x3")
+            if v:
+                return int(v["traffic_bytes_per_launch"])
+        except Exception:
+            pass
+    return None
 
 
 def main():
@@ -348,11 +503,15 @@ def main():
         # still runs.  Measured +0.4 % (31.43 vs 31.30 frames/s): every kernel already fills both workgroup slots of
         # every CU, so another stream's kernels only slip into the ramp/drain.  Off by default.
         kw_in = {"input_events": []} if (net.resolved_streams() > 1 and not args.four_calls and args.pipeline) else {}
+        from bin_amd.utils.smi import Sampler
+        smi = Sampler(local_rank)               # shader clock / package power DURING the timed region (host thread)
+        smi.start()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             out = net(*frames, **kw_in)
         sync_all()
         dt = time.perf_counter() - t0
+        power = smi.stop()
         # ---- roofline leg: the dominant kernel's mean duration, HIP events on the launch stream.  With several
         # streams kernels of different RDN calls overlap and a per-kernel duration is not meaningful, so this pass
         # re-runs the same forward serially (n_streams = 1) right after the timed region; `value` is unaffected.
@@ -361,23 +520,29 @@ def main():
         launches_per_step = (17 if net.reuse_schedule else 20) * 36
         prof_steps = min(args.steps, 5)
         prof = rank == 0 and prof_steps * launches_per_step <= 16384
-        kern_ms, kern_n = ctypes.c_double(0), ctypes.c_int(0)
-        if prof:
+
+        def dominant_kernel_pass():
+            """(summed ms, launches) of the dense-block conv class (3x3, 32 outputs, plane epilogue) over `prof_steps`
+            serial forwards of the CURRENT precision, HIP event pairs on the launch stream."""
+            ms_, n_ = ctypes.c_double(0), ctypes.c_int(0)
             saved_streams = net.n_streams
             net.n_streams = 1
-            out = net(*frames)
+            net(*frames)
             torch.cuda.synchronize()
             handle = ctypes.c_void_p(0)
             L.check(lib.binhip_profiler_create(3, 32, L.EPI_PLANES, prof_steps * launches_per_step,
                                                ctypes.byref(handle)), "profiler_create")
             net.set_profiler(handle)
             for _ in range(prof_steps):
-                out = net(*frames)
+                net(*frames)
             torch.cuda.synchronize()
             net.set_profiler(None)
-            L.check(lib.binhip_profiler_read(handle, ctypes.byref(kern_ms), ctypes.byref(kern_n)), "profiler_read")
+            L.check(lib.binhip_profiler_read(handle, ctypes.byref(ms_), ctypes.byref(n_)), "profiler_read")
             lib.binhip_profiler_destroy(handle)
             net.n_streams = saved_streams
+            return ms_.value, n_.value
+
+        kern_ms, kern_n = dominant_kernel_pass() if prof else (0.0, 0)
         extras = rank == 0 and not args.no_extras
         # ---- streaming leg (SURVEY §8f N3, reported beside `value`, never instead of it): consecutive windows of
         # one clip, sliding by one frame, with the exact stage-1 reuse -> 13 instead of 17 RDN calls per window
@@ -406,14 +571,19 @@ def main():
             for _ in range(2):
                 net(*frames)
             torch.cuda.synchronize()
+            smi.start()
             ta = time.perf_counter()
             n_alt = max(3, args.steps // 2)
             for _ in range(n_alt):
                 net(*frames)
             torch.cuda.synchronize()
             t_alt = (time.perf_counter() - ta) / n_alt
+            alt_power = smi.stop()
+            alt_ms, alt_n = dominant_kernel_pass() if prof else (0.0, 0)
             alt = {"precision": other, "dtype": DTYPE[other], "value": round(1.0 / t_alt, 4),
                    "unit": "interpolated frames/s", "n_gpus": 1, "ms_per_step": round(t_alt * 1e3, 3),
+                   "power": alt_power,
+                   "roofline": kernel_roofline(other, alt_ms, alt_n, hp, wp, t_alt * 1e3, net.reuse_schedule),
                    "parity": "f16: max-abs <= 1e-3 / |dPSNR| <= 0.01 dB, f16x3: max-abs <= 2e-5 vs the fp32 reference "
                              "(tests/test_gpu_net.py incl. the full-size 720p fixture tests/golden/g8_720p.npz)"}
             net.set_precision(args.precision)
@@ -439,35 +609,9 @@ def main():
     if rank == 0:
         value = world * args.steps / dt
         prec = args.precision
-        flops = FLOP_17 if net.reuse_schedule else FLOP_20
-        # whole-forward algorithmic bytes at the storage width of the timed mode (SURVEY's figure is the 4-byte one)
-        abytes = (BYTES_17 if net.reuse_schedule else BYTES_20) * BYTES_PER_ELEM[prec] / 4.0
         ms = dt / args.steps * 1e3
-        whole_gbs = abytes / (ms * 1e-3) / 1e9
-        # a byte yardstick wider than what the mode really moves could exceed the peak (round 1's f16 line did): refuse
-        assert whole_gbs <= HBM_PEAK_GBS, f"whole-forward algorithmic rate {whole_gbs:.0f} GB/s exceeds the HBM peak"
-        roof = None
-        if prof and kern_n.value > 0:
-            avg_s = kern_ms.value / kern_n.value * 1e-3
-            ab = rdb_conv_algorithmic_bytes(1, hp // 2, wp // 2, prec)
-            ach = ab / avg_s / 1e9
-            mf = rdb_conv_flops(1, hp // 2, wp // 2) * PRODUCTS[prec] / avg_s / 1e12
-            assert ach <= HBM_PEAK_GBS, f"kernel algorithmic rate {ach:.0f} GB/s exceeds the HBM peak"
-            kname = ("conv_x3_kernel<3,2,8,0,0>" if prec == "f16x3" else "conv_mfma_kernel<3,1,1,2,8,1,1,2,0>")
-            roof = {"bound": "hbm", "kernel": kname + " (RDB conv3x3 Cin->32 +ReLU, convs 0-2 of each dense block)",
-                    "precision": prec, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": pmc_traffic(prec), "avg_kernel_us": round(avg_s * 1e6, 2), "launches": kern_n.value,
-                    "algorithmic_bytes_per_launch": int(ab), "bytes_per_element": BYTES_PER_ELEM[prec],
-                    "mfma": {"achieved": round(mf, 1), "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(mf / MFMA_PEAK_TF, 4),
-                             "note": f"executed MFMA FLOPs = {PRODUCTS[prec]} x the conv's algorithmic FLOPs",
-                             "sustained_at_power_cap": {"random_fp16": 1663.0, "zeros": 2473.0, "unit": "TFLOP/s",
-                                                        "source": "profiles/r02_power_cap.md: register-resident v_mfma_f32_32x32x16_f16 "
-                                                                  "alone, tools/probe_mfma_power.hip (not measured in this run)"}},
-                    "whole_forward": {"algorithmic_GB": round(abytes / 1e9, 1), "achieved_GBs": round(whole_gbs, 1),
-                                      "frac_hbm": round(whole_gbs / HBM_PEAK_GBS, 4),
-                                      "achieved_TFLOPs": round(flops / (ms * 1e-3) / 1e12, 1),
-                                      "mfma_frac": round(flops * PRODUCTS[prec] / (ms * 1e-3) / 1e12 / MFMA_PEAK_TF, 4)}}
+        # (kernel_roofline refuses a byte yardstick that would exceed the HBM peak: round 1's f16 line did)
+        roof = kernel_roofline(prec, kern_ms, kern_n, hp, wp, ms, net.reuse_schedule) if prof else None
         line = {
             "metric": "interpolated frames/sec at 1280x720", "value": round(value, 4),
             "unit": "interpolated frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -483,6 +627,8 @@ def main():
                        "parity": "max-abs <= 2e-5 (f16x3) vs the fp32 reference (tests/)" if prec == "f16x3"
                                  else "max-abs <= 1e-3 (f16) vs the fp32 reference (tests/)"},
             "roofline": roof,
+            "power": power,
+            "nccl_ranks": (dist.get_world_size() if world > 1 else 1),
             "tolerance_mode" if other == "f16" else "fp32_class": alt,
             "streaming": None if stream_fps is None else {
                 "value": round(stream_fps, 3), "unit": "interpolated frames/s",

@@ -10,6 +10,8 @@ PLAN_KEEP_ACTS, PLAN_NO_FUSE, PLAN_RDB3 = 1, 2, 4
 BWD_ACCUMULATE = 1          # BinRdnBwdPlan.reserved flag (BINHIP_BWD_ACCUMULATE)
 BWD_SAVED_X3 = 2            # BINHIP_BWD_SAVED_X3
 EPI_PLANES, EPI_SHUFFLE, EPI_FINAL = 0, 1, 2
+PROF_WGRAD = 16             # BINHIP_PROF_WGRAD
+RDN_LAYOUT_WORDS, RDN_BWD_LAYOUT_WORDS = 16, 24
 
 
 class BinConvDesc(C.Structure):
@@ -33,7 +35,7 @@ class BinRdnBwdPlan(C.Structure):
                 ("wt_hi", C.c_void_p * RDN_LAYERS), ("wt_lo", C.c_void_p * RDN_LAYERS),
                 ("zero_bias", C.c_void_p),
                 ("dw", C.c_void_p * RDN_LAYERS), ("db", C.c_void_p * RDN_LAYERS), ("gin", C.c_void_p * 5),
-                ("status", C.c_void_p), ("aux_stream", C.c_void_p)]
+                ("status", C.c_void_p), ("aux_stream", C.c_void_p), ("profiler", C.c_void_p)]
 
 
 _SIGNATURES = {
@@ -94,6 +96,8 @@ _SIGNATURES = {
     "binhip_rdb_tail_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 10 +
                             [C.c_int, C.c_void_p, C.c_void_p]),
     "binhip_rdn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "binhip_rdn_workspace_layout": (C.c_int, [C.c_int] * 5 + [C.POINTER(C.c_int64), C.c_int]),
+    "binhip_rdn_backward_workspace_layout": (C.c_int, [C.c_int] * 5 + [C.POINTER(C.c_int64), C.c_int]),
     "binhip_rdn_forward": (C.c_int, [C.POINTER(BinRdnPlan), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p,
                                      C.c_size_t, C.c_void_p]),
 }

@@ -71,6 +71,8 @@ class _RdnFn(torch.autograd.Function):
             raise RuntimeError(f"bin_amd: unsupported RDN shape N={n} H={h} W={w}")
         saved = torch.empty(nbytes, dtype=torch.uint8, device=frames[0].device)
         out = rdn_forward(weights, frames, ws=saved, flags=module.plan_flags | L.PLAN_KEEP_ACTS, profiler=module.profiler)
+        if module.debug_hook is not None:
+            module.debug_hook("forward", module, (n, h, w, n_frames, nterms), saved, {})
         ctx.module, ctx.nterms, ctx.n_frames = module, nterms, n_frames
         ctx.saved_ws = saved
         ctx.dims = (n, h, w)
@@ -108,6 +110,7 @@ class _RdnFn(torch.autograd.Function):
         plan.status = status_word(dev).data_ptr()
         plan.aux_stream = (_aux_stream(dev).cuda_stream
                            if WGRAD_SIDE_STREAM and not torch.cuda.is_current_stream_capturing() else None)
+        plan.profiler = module.bwd_profiler if module.bwd_profiler else None
         params = ctx.params
         direct = module.direct_param_grads and all(ctx.needs_input_grad[3 + k:])
         have = False
@@ -139,6 +142,8 @@ class _RdnFn(torch.autograd.Function):
         with on_device(gout):
             L.check(lib.binhip_rdn_backward(C.byref(plan), _ptr(ctx.saved_ws), ctx.saved_ws.numel(), _ptr(gout),
                                             _ptr(ws), ws.numel(), _stream()), "rdn_backward")
+        if module.debug_hook is not None:          # tools/fp16_headroom.py, tests: inspect the planes of this call
+            module.debug_hook("backward", module, (n, h, w, k, nt_bwd), ws, {"input_grads": any(g is not None for g in gins)})
         ctx.saved_ws = None
         module._bwd_pending = getattr(module, "_bwd_pending", 1) - 1
         if module._bwd_pending == 0 and direct:

@@ -403,18 +403,25 @@ int bh_prepare_conv(const BhConvCall& c, ConvKArgs* out) {
     return 0;
 }
 
+// shared by the conv launcher and the RDN backward plan (weight-gradient launches: epi == BINHIP_PROF_WGRAD)
+bool bh_prof_begin(BinhipProfiler* pr, int ks, int cout_pad, int epi, hipStream_t s) {
+    if (!pr || ks != pr->ks || cout_pad != pr->cout_pad || epi != pr->epi || pr->used + 2 > pr->ev.size()) return false;
+    (void)hipEventRecord(pr->ev[pr->used], s);
+    return true;
+}
+void bh_prof_end(BinhipProfiler* pr, hipStream_t s) {
+    (void)hipEventRecord(pr->ev[pr->used + 1], s);
+    pr->used += 2;
+}
+
 int bh_launch_conv(const BhConvCall& c, hipStream_t s) {
     ConvKArgs a;
     if (int rc = bh_prepare_conv(c, &a)) return rc;
     const BinConvDesc& d = c.d;
     const int k = d.ksize, cp = d.cout_pad, nt = d.nterms, e = d.epilogue;
-    BinhipProfiler* pr = c.prof;
-    if (pr && k == pr->ks && cp == pr->cout_pad && e == pr->epi && pr->used + 2 <= pr->ev.size()) {
-        hipEvent_t e0 = pr->ev[pr->used], e1 = pr->ev[pr->used + 1];
-        (void)hipEventRecord(e0, s);
+    if (bh_prof_begin(c.prof, k, cp, e, s)) {
         const int rc = bh_dispatch_conv(a, k, cp, nt, e, s);
-        (void)hipEventRecord(e1, s);
-        pr->used += 2;
+        bh_prof_end(c.prof, s);
         return rc;
     }
     return bh_dispatch_conv(a, k, cp, nt, e, s);

@@ -4,7 +4,7 @@
 #include <stdint.h>
 #include "../../include/binhip.h"
 
-#define BINHIP_VERSION 200
+#define BINHIP_VERSION 300
 
 // BINHIP_TUNING (side builds for tools/: kernel-variant sweeps and ablations; 0 in the product): compiles the
 // alternative tile configurations and the process-global switches that select them.  The product library has neither.
@@ -64,6 +64,10 @@ struct BhConvCall {
     BinhipProfiler* prof = nullptr;                  // optional live-timing handle (binhip_profiler_create)
 };
 int bh_launch_conv(const BhConvCall& c, hipStream_t s);
+// live-timing handle (binhip_profiler_create): begin() records the start event and returns true when the launch matches
+// the handle's (ksize, cout_pad, epilogue) class and a pair is free; end() records the stop event
+bool bh_prof_begin(BinhipProfiler* pr, int ks, int cout_pad, int epi, hipStream_t s);
+void bh_prof_end(BinhipProfiler* pr, hipStream_t s);
 struct ConvKArgs;
 int bh_prepare_conv(const BhConvCall& c, ConvKArgs* out);
 // convs 0-2 of a residual dense block as three phases of one launch (binhip_conv_x3.hip); nterms = 3 only

@@ -58,6 +58,16 @@ size_t binhip_rdn_workspace_bytes(int N, int H, int W, int n_inputs, int nterms)
     return (size_t)make_ws(N, H, W, n_inputs, nterms).total * 2 + 256;
 }
 
+int binhip_rdn_workspace_layout(int N, int H, int W, int n_inputs, int nterms, int64_t* out, int n_out) {
+    if (!out || n_out < BINHIP_RDN_LAYOUT_WORDS) return BINHIP_E_ARG;
+    if (binhip_rdn_workspace_bytes(N, H, W, n_inputs, nterms) == 0) return BINHIP_E_SHAPE;
+    const Ws w = make_ws(N, H, W, n_inputs, nterms);
+    const int64_t v[BINHIP_RDN_LAYOUT_WORDS] = {w.P, w.PF, w.kc0, w.x0, w.s_x0, w.f1, w.s_f1, w.blk, w.s_blk,
+                                                 w.g0, w.s_g, w.g1, w.s_g, w.u, w.s_u, nterms == 3 ? 1 : 0};
+    for (int i = 0; i < BINHIP_RDN_LAYOUT_WORDS; ++i) out[i] = v[i];
+    return 0;
+}
+
 int binhip_rdn_forward(const BinRdnPlan* p, const float* const* inputs, float* out, void* workspace,
                        size_t workspace_bytes, void* stream) {
     if (!p || !inputs || !out || !workspace) return BINHIP_E_ARG;
@@ -242,6 +252,17 @@ size_t binhip_rdn_backward_workspace_bytes(int N, int H, int W, int n_inputs, in
     return make_bws(N, H, W, n_inputs, nterms).total_bytes;
 }
 
+int binhip_rdn_backward_workspace_layout(int N, int H, int W, int n_inputs, int nterms, int64_t* out, int n_out) {
+    if (!out || n_out < BINHIP_RDN_BWD_LAYOUT_WORDS) return BINHIP_E_ARG;
+    if (binhip_rdn_backward_workspace_bytes(N, H, W, n_inputs, nterms) == 0) return BINHIP_E_SHAPE;
+    const Bws b = make_bws(N, H, W, n_inputs, nterms);
+    const int64_t v[BINHIP_RDN_BWD_LAYOUT_WORDS] = {b.P, b.PF, b.gx0_chunks, b.gout, b.s_gout, b.gu, b.s_gu, b.guu, b.s_guu,
+                                                     b.gg1, b.s_g, b.gg0, b.s_g, b.gf1, b.s_g, b.gy, b.s_gy, b.gcat, b.s_gcat,
+                                                     b.gcat2, b.s_gcat, b.gx0, b.s_gx0, (int64_t)b.sc_off_bytes};
+    for (int i = 0; i < BINHIP_RDN_BWD_LAYOUT_WORDS; ++i) out[i] = v[i];
+    return 0;
+}
+
 int binhip_rdn_backward(const BinRdnBwdPlan* p, const void* saved, size_t saved_bytes, const float* gout,
                         void* workspace, size_t workspace_bytes, void* stream) {
     if (!p || !saved || !gout || !workspace || !p->zero_bias) return BINHIP_E_ARG;
@@ -314,8 +335,11 @@ int binhip_rdn_backward(const BinRdnBwdPlan* p, const void* saved, size_t saved_
         if (int rf = order(s, sb)) return rf;                        // its gY (and the scale) are queued on the main stream
         BhWgradReduce r;
         char* region = (char*)wgws + (size_t)(slot < 0 ? 0 : slot) * b.wg_bytes;
-        if (int rw = bh_wgrad_partials(&d, SH(x_off), SL(x_off, x_size), GH(g_off), GL(g_off, g_size), region, b.wg_bytes,
-                                       p->dw[layer], p->db[layer], cin, shuffle, &r, (void*)sb)) return rw;
+        const bool timed = bh_prof_begin(p->profiler, ks, cout, BINHIP_PROF_WGRAD, sb);
+        const int rw = bh_wgrad_partials(&d, SH(x_off), SL(x_off, x_size), GH(g_off), GL(g_off, g_size), region, b.wg_bytes,
+                                         p->dw[layer], p->db[layer], cin, shuffle, &r, (void*)sb);
+        if (timed) bh_prof_end(p->profiler, sb);
+        if (rw) return rw;
         if (slot < 0) return bh_wgrad_reduce_batch(&r, 1, inv, accumulate, (void*)sb);
         pending[npending++] = r;
         return 0;

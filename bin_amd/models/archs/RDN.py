@@ -132,6 +132,9 @@ class _RDNBase(nn.Module):
         self.direct_param_grads = False                          # kernels accumulate weight gradients straight into .grad
         self.plan_flags = default_plan_flags()                   # BINHIP_PLAN_* bits of every call of this sub-network
         self.profiler = None                                     # BinhipProfiler handle (bench.py's roofline leg)
+        self.bwd_profiler = None                                 # same, for the weight-gradient launches of the backward
+        self.debug_hook = None                                   # callable(kind, module, dims, workspace, info) after a training
+                                                                 # forward / backward (tools/fp16_headroom.py)
         self._wcache = None            # (key, RdnWeights)
         self._wgen = 0                 # bumped by invalidate_kernel_weights()
 
@@ -296,10 +299,14 @@ class RDN_residual_interp_5_input_ConvLSTM_L(nn.Module):
             m.backward_precision = None if precision == "f16x3" else precision
         return self
 
-    def set_profiler(self, handle):
-        """Attach (or, with None, detach) a BinhipProfiler handle to every RDN call of THIS network."""
+    def set_profiler(self, handle, backward=False):
+        """Attach (or, with None, detach) a BinhipProfiler handle to every RDN call of THIS network (`backward`: to the
+        weight-gradient launches of its backward calls instead)."""
         for m in self.rdn_modules():
-            m.profiler = handle
+            if backward:
+                m.bwd_profiler = handle
+            else:
+                m.profiler = handle
         return self
 
     def direct_param_grads(self, on=True):

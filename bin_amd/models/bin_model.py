@@ -20,7 +20,7 @@ from . import lr_scheduler
 from . import networks
 from .base_model import BaseModel, unwrap, _direct_param_grads
 from .loss import CharbonnierLoss
-from ..utils import util
+from ..utils import dist_util, util
 from ..utils.util import AverageMeter
 
 logger = logging.getLogger("base")
@@ -134,9 +134,9 @@ class FlatGradAllReduce:
             ev.record(main)                          # everything that wrote this slice is queued before this point
             self._stream.wait_event(ev)
             with torch.cuda.stream(self._stream):
-                dist.all_reduce(piece, op=dist.ReduceOp.SUM)
+                dist_util.all_reduce(piece)
         else:
-            dist.all_reduce(piece, op=dist.ReduceOp.SUM)
+            dist_util.all_reduce(piece)
         self._reduced.append((start, end))
 
     def _bucket_ready(self, idx):
@@ -296,7 +296,7 @@ class bin_model(BaseModel):
         params = list(self.netG.parameters())
         with torch.no_grad():
             flat = torch.cat([p.detach().reshape(-1) for p in params])
-            dist.broadcast(flat, src=0)
+            dist_util.broadcast(flat, src=0)
             o = 0
             for p in params:
                 p.copy_(flat[o:o + p.numel()].view_as(p))

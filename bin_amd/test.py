@@ -31,7 +31,7 @@ from . import harness, ops
 from .data import util as data_util
 from .models import create_model
 from .options import options as option
-from .utils import util
+from .utils import dist_util, util
 from .utils.util import AverageMeter
 
 OUT_KEYS = (13, 8, 12)         # interpolated, first deblurred, second deblurred (test.py:380-382)
@@ -53,6 +53,10 @@ def parse_args(argv=None):
     p.add_argument("--batch", type=int, default=1, help="windows per forward (small frames: 8 fills the chip; no "
                    "cross-window stage-1 reuse when > 1)")
     p.add_argument("--no_reuse", action="store_true", help="recompute the stage-1 calls shared by consecutive windows")
+    p.add_argument("--backend", default=None, help="torch.distributed backend for --launcher pytorch (default: nccl = "
+                   "RCCL on a GPU box; gloo lets several ranks share one device)")
+    p.add_argument("--manifest", action="store_true", help="each rank also writes written.rank<R>.txt under the result "
+                   "folder: the files IT saved (shard-ownership audit)")
     p.add_argument("--ssim", action="store_true", help="also compute SSIM (host, ~0.2 s per 720p frame)")
     return p.parse_args(argv)
 
@@ -107,7 +111,7 @@ def main(argv=None):
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
         if not dist.is_initialized():
-            dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+            dist.init_process_group(args.backend or dist_util.default_backend())
         rank, world = dist.get_rank(), dist.get_world_size()
         opt["gpu_ids"] = [local]
     else:
@@ -163,12 +167,15 @@ def main(argv=None):
                 continue
             if mine:
                 util.save_img(img, os.path.join(clip_dir, name))
+                with written_lock:
+                    written.append(os.path.join(clip, name))
             if mine or kind == "interp":           # the reference scores a deblurred frame when it writes it
                 _score(sums, clip, kind, img, args.gt_path and os.path.join(args.gt_path, clip, name), args.ssim)
         if args.gt_path:
             _score(sums, clip, "blurry", data_util.imread_u8(blurry_path)[:, :, :3],
                    os.path.join(args.gt_path, clip, names[0]), args.ssim)
 
+    written, written_lock = [], threading.Lock()       # files THIS rank saved (--manifest)
     group = []                                         # windows of one clip waiting to go through the net together
 
     def flush():
@@ -252,12 +259,16 @@ def main(argv=None):
     ops.check_status(dev)                 # a frame that left the fp16 storage range is an error, not a result
     wall = time.time() - t_all
     pool.shutdown()
+    if args.manifest:
+        with open(os.path.join(result_root, f"written.rank{rank}.txt"), "w") as f:
+            f.write("".join(sorted(w + "\n" for w in written)))
 
     # ---- combine the ranks' sums (one small all-reduce) and report like test.py:466-502
     vec = torch.tensor([v for k in METRICS for v in sums.total[k]] + [end - begin, wall], dtype=torch.float64)
     if world > 1:
         import torch.distributed as dist
-        vec = vec.to(dev)
+        if dist.get_backend() != "gloo":      # nccl reduces device tensors; gloo takes the host vector as it is
+            vec = vec.to(dev)
         wall_t = vec[-1:].clone()
         dist.all_reduce(vec, op=dist.ReduceOp.SUM)
         dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)

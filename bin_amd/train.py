@@ -28,7 +28,8 @@ def init_dist(backend=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if torch.cuda.is_available():
         torch.cuda.set_device(local)
-    dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"))
+    from .utils import dist_util
+    dist.init_process_group(backend or dist_util.default_backend())
     return dist.get_rank(), dist.get_world_size()
 
 

@@ -202,6 +202,15 @@ typedef struct BinRdnPlan {
 } BinRdnPlan;
 
 BINHIP_API size_t binhip_rdn_workspace_bytes(int N, int H, int W, int n_inputs, int nterms);
+/* Where the activations of a call live inside its workspace (the caller owns it, and with BINHIP_PLAN_KEEP_ACTS it is
+ * the saved state of the call): fp16-ELEMENT offsets from the workspace pointer rounded up to 256 B.  A tensor's hi
+ * planes start at its offset, its lo planes (nterms == 3) at offset + size.  out[0..15] =
+ *   P (elements of one half-resolution plane: N*H/2*W/2*16), PF (full resolution), kc0 (chunks of the packed input),
+ *   x0, size | f1, size | blk, size (13 blocks x 14 planes: block d input = planes [14d, 14d+6), conv c output =
+ *   planes 14d + 6 + 2c, + 7 + 2c) | g0, size | g1, size | u, size (4 full-resolution planes) | has_lo.
+ * Used by tools/fp16_headroom.py and the GPU tests to measure the stored dynamic range; no device work.            */
+#define BINHIP_RDN_LAYOUT_WORDS 16
+BINHIP_API int binhip_rdn_workspace_layout(int N, int H, int W, int n_inputs, int nterms, int64_t* out, int n_out);
 BINHIP_API int binhip_rdn_forward(const BinRdnPlan* plan, const float* const* inputs /* host array of
                        n_inputs device ptrs, fp32 [N,3,H,W] */, float* out /* fp32 [N,3,H,W] */,
                        void* workspace, size_t workspace_bytes, void* stream);
@@ -265,8 +274,18 @@ typedef struct BinRdnBwdPlan {
     void* aux_stream;                       /* optional second hipStream_t: the weight-gradient kernels run on it,  */
                                             /* overlapping the backward-data chain (event-ordered inside the call;  */
                                             /* joined into `stream` before return).  NULL: everything on `stream`   */
+    struct BinhipProfiler* profiler;        /* optional live timing of the weight-gradient launches (epilogue class  */
+                                            /* BINHIP_PROF_WGRAD) or NULL                                            */
 } BinRdnBwdPlan;
 BINHIP_API size_t binhip_rdn_backward_workspace_bytes(int N, int H, int W, int n_inputs, int nterms);
+/* Gradient planes inside the backward workspace after a call (same conventions as binhip_rdn_workspace_layout; all
+ * stored multiplied by the call's power-of-two scale).  out[0..23] = P, PF, gx0_chunks,
+ *   gout, size (1 full-res plane) | gu, size (4 full-res) | guu, size (16) | gg1, size | gg0, size | gf1, size (6 each) |
+ *   gy, size (13 x 6: gradient of SFENet2's output and of every dense block's output) | gcat, size | gcat2, size (14 each:
+ *   gradient-concat buffers of the last even / odd dense block processed) | gx0, size | byte offset of the float pair
+ *   {scale, 1/scale}.                                                                                                */
+#define BINHIP_RDN_BWD_LAYOUT_WORDS 24
+BINHIP_API int binhip_rdn_backward_workspace_layout(int N, int H, int W, int n_inputs, int nterms, int64_t* out, int n_out);
 BINHIP_API int binhip_rdn_backward(const BinRdnBwdPlan* plan, const void* saved, size_t saved_bytes,
                         const float* gout, void* workspace, size_t workspace_bytes, void* stream);
 
@@ -275,7 +294,10 @@ BINHIP_API int binhip_rdn_backward(const BinRdnBwdPlan* plan, const void* saved,
  * cout_pad, epilogue) matches is bracketed by a hipEvent pair recorded on the launch stream (at most
  * `max_launches` <= 16384 pairs); read() synchronises on the recorded pairs, returns their summed
  * kernel time and the launch count, and rewinds the handle.  Not thread-safe per handle (use one per
- * host thread); the library itself keeps no global timing state.                                   */
+ * host thread); the library itself keeps no global timing state.
+ * epilogue == BINHIP_PROF_WGRAD: time the weight-gradient partial kernels of binhip_rdn_backward whose
+ * forward layer has this ksize and cout (= `cout_pad` argument), on the stream they are launched on.  */
+#define BINHIP_PROF_WGRAD 16
 typedef struct BinhipProfiler BinhipProfiler;
 BINHIP_API int binhip_profiler_create(int ksize, int cout_pad, int epilogue, int max_launches, BinhipProfiler** out);
 BINHIP_API int binhip_profiler_read(BinhipProfiler* p, double* total_ms, int* launches);
