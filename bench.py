@@ -266,24 +266,39 @@ def train_bench(args, rank, world, dev, steps=None, warmup=None, standalone=True
     ops.check_status()                       # no activation / gradient left the fp16 storage range
     # ---- roofline of the step and of its dominant kernel (3x3 weight gradient): two more steps AFTER the timed region
     # with the weight-gradient launches bracketed by HIP events on the stream they run on (BINHIP_PROF_WGRAD)
-    kern = None
+    # Two passes of two steps: (a) as in the timed steps (weight gradients on the side stream, sharing the chip with the
+    # backward-data chain), (b) with the side stream off, so that a kernel's duration is its own — the figure a
+    # `rocprofv3 --kernel-trace` of `BIN_AMD_WGRAD_STREAM=0 bench.py --mode train` reports (profiles/).
+    kern, kern_overlapped = None, None
     lib = L.lib()
-    handle = ctypes.c_void_p(0)
-    prof_steps = 2
     net = m.netG.module
-    if rank == 0:                            # every rank runs the two extra steps (collectives stay matched); rank 0 times them
-        L.check(lib.binhip_profiler_create(3, 32, L.PROF_WGRAD, prof_steps * 4 * 48, ctypes.byref(handle)), "profiler_create")
-        net.set_profiler(handle, backward=True)
-    for i in range(prof_steps):
-        m.optimize_parameters(warmup + steps + i + 1)
-    torch.cuda.synchronize()
-    if rank == 0:
-        net.set_profiler(None, backward=True)
-        kms, kn = ctypes.c_double(0), ctypes.c_int(0)
-        L.check(lib.binhip_profiler_read(handle, ctypes.byref(kms), ctypes.byref(kn)), "profiler_read")
-        lib.binhip_profiler_destroy(handle)
-        if kn.value:
-            kern = (kms.value / kn.value * 1e-3, kn.value)
+    prof_steps = 2
+    step_no = warmup + steps
+    for exclusive in (False, True):
+        handle = ctypes.c_void_p(0)
+        if rank == 0:                        # every rank runs the extra steps (collectives stay matched); rank 0 times them
+            L.check(lib.binhip_profiler_create(3, 32, L.PROF_WGRAD, prof_steps * 4 * 48, ctypes.byref(handle)), "profiler_create")
+            net.set_profiler(handle, backward=True)
+        saved = [mod.wgrad_side_stream for mod in net.rdn_modules()]
+        if exclusive:
+            for mod in net.rdn_modules():
+                mod.wgrad_side_stream = False
+        for i in range(prof_steps):
+            step_no += 1
+            m.optimize_parameters(step_no)
+        torch.cuda.synchronize()
+        for mod, v in zip(net.rdn_modules(), saved):
+            mod.wgrad_side_stream = v
+        if rank == 0:
+            net.set_profiler(None, backward=True)
+            kms, kn = ctypes.c_double(0), ctypes.c_int(0)
+            L.check(lib.binhip_profiler_read(handle, ctypes.byref(kms), ctypes.byref(kn)), "profiler_read")
+            lib.binhip_profiler_destroy(handle)
+            if kn.value:
+                if exclusive:
+                    kern = (kms.value / kn.value * 1e-3, kn.value)
+                else:
+                    kern_overlapped = kms.value / kn.value * 1e-3
     t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
@@ -297,7 +312,7 @@ def train_bench(args, rank, world, dev, steps=None, warmup=None, standalone=True
         "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2),
         "nccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1),
         "power": power,
-        "roofline": train_roofline(B, S, dt / steps, prec, bwd_prec, kern),
+        "roofline": train_roofline(B, S, dt / steps, prec, bwd_prec, kern, kern_overlapped),
         "config": {"workload": f"Adobe240 training, 256x256 crops, batch {B} per GPU, Charbonnier x17, Adam, "
                                f"DP flat gradient all-reduce (45.77 MB)", "precision": prec,
                    "backward_precision": bwd_prec or prec}}
@@ -348,7 +363,7 @@ def kernel_roofline(prec, kern_ms, kern_n, hp, wp, ms, reuse_schedule):
                               "mfma_frac": round(flops * PRODUCTS[prec] / (ms * 1e-3) / 1e12 / MFMA_PEAK_TF, 4)}}
 
 
-def train_roofline(batch, size, step_s, prec, bwd_prec, kern):
+def train_roofline(batch, size, step_s, prec, bwd_prec, kern, kern_overlapped=None):
     """Roofline object of the training step: algorithmic work = 3 x the forward's (forward + backward-data + backward-
     weight, each the same MACs and the same activation bytes; SURVEY §8d "training step ~ 3 x forward"), executed MFMA
     FLOPs = products x algorithmic (the single-product backward of the mixed mode executes 1 x on two thirds of it).
@@ -374,13 +389,16 @@ def train_roofline(batch, size, step_s, prec, bwd_prec, kern):
             "kernel": "wgrad3x3_db_kernel (3x3 weight gradient of the dense-block convs, Cin = 96..192 -> 32)",
             "avg_kernel_us": round(avg_s * 1e6, 2), "launches": n, "launches_per_step": 4 * 48,
             "share_of_step": round(avg_s * 4 * 48 / step_s, 4),
+            "avg_kernel_us_beside_backward_data": None if kern_overlapped is None else round(kern_overlapped * 1e6, 2),
             "algorithmic_bytes_per_launch": int(kb), "bound": "hbm", "achieved": round(kb / avg_s / 1e9, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(kb / avg_s / 1e9 / HBM_PEAK_GBS, 4),
             "traffic": pmc_wgrad_traffic(),
             "mfma": {"achieved": round(kf * prod_b / avg_s / 1e12, 1), "peak": MFMA_PEAK_TF, "unit": "TFLOP/s",
                      "frac": round(kf * prod_b / avg_s / 1e12 / MFMA_PEAK_TF, 4)},
-            "timing": "HIP event pairs on the side stream the weight gradients run on, 2 steps right after the timed region "
-                      "(the kernel shares the chip with the backward-data chain of the main stream, as in the timed steps)"}
+            "timing": "HIP event pairs around each launch, 2 steps right after the timed region with the weight gradients on the "
+                      "main stream (a kernel's own duration, as rocprofv3 --kernel-trace of BIN_AMD_WGRAD_STREAM=0 reports "
+                      "it); `avg_kernel_us_beside_backward_data`: the same launches on the side stream, sharing the chip with "
+                      "the backward-data chain as in the timed steps"}
     return out
 
 

@@ -36,8 +36,12 @@ from .rdn_plan import layer_names, rdn_forward, workspace
 #       BIN_AMD_BACKWARD_PRECISION; None = same as forward).
 
 # Weight gradients on a side stream, overlapping the backward-data chain (BinRdnBwdPlan.aux_stream; one side stream per
-# device, the library orders and joins it with events inside each call).  BIN_AMD_WGRAD_STREAM=0 turns it off.
-WGRAD_SIDE_STREAM = os.environ.get("BIN_AMD_WGRAD_STREAM", "1") != "0"
+# device, the library orders and joins it with events inside each call).  Per module: `module.wgrad_side_stream`
+# (default below: BIN_AMD_WGRAD_STREAM=0 turns it off; bench.py turns it off for its exclusive kernel-timing pass).
+def default_wgrad_side_stream():
+    return os.environ.get("BIN_AMD_WGRAD_STREAM", "1") != "0"
+
+
 _aux_streams = {}
 
 
@@ -109,7 +113,7 @@ class _RdnFn(torch.autograd.Function):
         dgw.fill_plan(plan)
         plan.status = status_word(dev).data_ptr()
         plan.aux_stream = (_aux_stream(dev).cuda_stream
-                           if WGRAD_SIDE_STREAM and not torch.cuda.is_current_stream_capturing() else None)
+                           if module.wgrad_side_stream and not torch.cuda.is_current_stream_capturing() else None)
         plan.profiler = module.bwd_profiler if module.bwd_profiler else None
         params = ctx.params
         direct = module.direct_param_grads and all(ctx.needs_input_grad[3 + k:])

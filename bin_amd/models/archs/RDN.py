@@ -126,10 +126,11 @@ class _RDNBase(nn.Module):
                                    nn.Conv2d(64, 3, kSize, padding=1, stride=1))
         self.precision = None          # None -> inherit default_precision()
         # per-object switches of the HIP path (see bin_amd/autograd.py; deliberately NOT module globals)
-        from ...autograd import default_backward_precision
+        from ...autograd import default_backward_precision, default_wgrad_side_stream
         from ...rdn_plan import default_plan_flags
         self.backward_precision = default_backward_precision()   # "f16" = single-product backward behind an f16x3 forward
         self.direct_param_grads = False                          # kernels accumulate weight gradients straight into .grad
+        self.wgrad_side_stream = default_wgrad_side_stream()     # weight-gradient kernels beside the backward-data chain
         self.plan_flags = default_plan_flags()                   # BINHIP_PLAN_* bits of every call of this sub-network
         self.profiler = None                                     # BinhipProfiler handle (bench.py's roofline leg)
         self.bwd_profiler = None                                 # same, for the weight-gradient launches of the backward
