@@ -139,6 +139,11 @@ def lib():
                 fn = getattr(h, name)
                 fn.restype = res
                 fn.argtypes = args
+        # developer knob, tuning side builds only (the product library has no such entry point): pick the experimental
+        # weight-gradient kernels / ablations of binhip_wgrad.hip for a whole test or bench run
+        dbg = os.environ.get("BIN_AMD_WG_DEBUG")
+        if dbg and hasattr(h, "binhip_wgrad_set_debug"):
+            h.binhip_wgrad_set_debug(int(dbg, 0))
         _lib = h
     return _lib
 

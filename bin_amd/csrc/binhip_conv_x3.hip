@@ -32,6 +32,11 @@
 #ifndef BINHIP_X3_WN
 #define BINHIP_X3_WN 8
 #endif
+// side builds only: 1 = wave priority falls with the tile's progress (s_setprio 3 .. 0 per quarter of the K loop), so of the two
+// workgroups sharing a CU the one that lags issues first and they finish together instead of one running alone at the end
+#ifndef BINHIP_X3_PRIO
+#define BINHIP_X3_PRIO 0
+#endif
 
 template <int KS, int R, int WN>
 struct X3Cfg {
@@ -191,6 +196,15 @@ __device__ __forceinline__ void x3_tile(const ConvKArgs& a, char* smem, int img,
     x3_issue_patch<C>(a, smem, 0, 0, 0, wave, voff, plane_elems, plane_bytes);
     for (int c = 0; c < nchunks; ++c) {
         const char* wb = smem + 2 * C::PATCH_BYTES + (c & 1) * C::WBUF_BYTES;
+#if BINHIP_X3_PRIO
+        {
+            const int q = (4 * c) / nchunks;
+            if (q == 0) __builtin_amdgcn_s_setprio(3);
+            else if (q == 1) __builtin_amdgcn_s_setprio(2);
+            else if (q == 2) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+#endif
         // ---- hi sub-stage (the long one: 2 products): meanwhile the lo patch plane and the NEXT chunk's weights land
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();

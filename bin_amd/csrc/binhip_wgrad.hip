@@ -939,6 +939,261 @@ wgrad3x3_roll_kernel(const WgradKArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 layers, rolling rows with TWO pixel rows per stage (round 3; BINHIP_TUNING flag 64).  Same walk and LDS images as
+// the one-row kernel above, but a stage multiplies output rows j and j + 1 (X rows j-1 .. j+2 of a six-slot ring, gY rows
+// j, j+1 of a four-slot ring) while the next stage's two X rows and two gY rows land: twice the MFMAs between barriers
+// (4 * TPW steps x 3 products) for 1.2x the ring.  The ring only fits for <= 4 channel pairs per workgroup (6 x 18 KB +
+// 4 x 4.6 KB = 126 KB), so layers with 5 / 6 pairs run as two channel groups (3 + 2 / 3 + 3) and read their gY twice —
+// against five / six times in the eight-wave kernel.
+template <int NT, int TPW>
+struct R3Cfg2 {
+    static constexpr int NPL = (NT == 3) ? 2 : 1;
+    static constexpr int PPG = (8 * TPW) / 9;
+    static_assert((PPG * 9 + 7) / 8 == TPW && PPG >= 1 && PPG <= 4, "tiles per wave <-> pairs per group");
+    static constexpr int CU = 72;
+    static constexpr int UNITS = CU * 2 * PPG;
+    static constexpr int XP = (UNITS + 63) / 64;
+    static constexpr int XROW = XP * 1024;
+    static constexpr int XSLOT = NPL * XROW;
+    static constexpr int GCH = 1024 + 128;
+    static constexpr int GSLOT = NPL * 2 * GCH;
+    static constexpr int NXS = 6, NGS = 4;
+    static constexpr int G_BASE = NXS * XSLOT;
+    static constexpr int LDS_BYTES = G_BASE + NGS * GSLOT;
+    static constexpr int NXJ = (NPL * XP + 7) / 8;
+    static_assert(XROW + 512 + 128 < 65536 && 2 * GCH + 512 + 128 < 65536, "plane / K-step offsets fit the DS immediate");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+template <class R, int NT>
+__device__ __forceinline__ void r32_issue_x(char* smem, int q, int wave, int y0, int H, int W, unsigned imgrow,
+                                            __amdgpu_buffer_rsrc_t rs0, __amdgpu_buffer_rsrc_t rs1, const bool* xok,
+                                            const unsigned* xcol) {
+    const int y = y0 - 1 + q;
+    const bool rowok = (unsigned)y < (unsigned)H;
+    const unsigned rowbase = (imgrow + (unsigned)y) * (unsigned)W * 32u;
+    char* slot = smem + (q % R::NXS) * R::XSLOT;
+#pragma unroll
+    for (int j = 0; j < R::NXJ; ++j) {
+        const int piece = wave + 8 * j;
+        if (piece < R::NPL * R::XP) {
+            const unsigned vo = (rowok && xok[j]) ? rowbase + xcol[j] : 0xfffffff0u;
+            if (NT == 3 && piece >= R::XP)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_void_t*)(slot + piece * 1024), 16, vo, 0, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_void_t*)(slot + piece * 1024), 16, vo, 0, 0, 0);
+        }
+    }
+}
+template <class R>
+__device__ __forceinline__ void r32_issue_g(char* smem, int j, int wave, int y0, int H, int W, unsigned imgrow,
+                                            __amdgpu_buffer_rsrc_t rs, bool gcol, unsigned gcolsrc, int piece) {
+    if (wave < 2 * R::NPL) {
+        const int y = y0 + j;
+        const unsigned vo = ((y < H) && gcol) ? (imgrow + (unsigned)y) * (unsigned)W * 32u + gcolsrc : 0xfffffff0u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(smem + R::G_BASE + (j % R::NGS) * R::GSLOT + piece * R::GCH), 16, vo, 0, 0, 0);
+    }
+}
+
+template <int NT, int TPW>
+__global__ void __launch_bounds__(512)
+wgrad3x3_roll2_kernel(const WgradKArgs a) {
+    using R = R3Cfg2<NT, TPW>;
+    constexpr int NSTEP = 4 * TPW;                      // 2 rows x 2 K-steps x TPW tiles
+    constexpr int NA = (NT == 3) ? 4 : 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pb = blockIdx.x;
+    const int cgroups = a.cgroups;
+    const int cg = blockIdx.y % cgroups, cot = blockIdx.y / cgroups;
+    const int cp0 = cg * a.ppg;                         // balanced groups: ppg = ceil(ncp / cgroups) <= R::PPG
+    const int H = a.H, W = a.W;
+    const long long plane_elems = (long long)a.N * H * W * 16;
+    const unsigned plane_bytes = (unsigned)(plane_elems * 2);
+    const bool bias_wave = (cg == 0) && (wave == 0);
+
+    // ---- this wave's output tiles (pair, tap): slots wave * TPW .. + TPW - 1 of the group's ppg * 9
+    int t_dy[TPW];
+    bool t_ok[TPW];
+    unsigned xa[TPW], xb[TPW];
+    {
+        const int tt = lane & 15, ch = (lane >> 4) & 1, kg = lane >> 5;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int k = wave * TPW + i;
+            const int pr = k / 9, tap = k % 9;
+            t_ok[i] = (pr < a.ppg) && (cp0 + pr < a.ncp);
+            t_dy[i] = tap / 3;
+            const int dx = tap % 3;
+            const int pa = dx + kg * 8 + (tt >> 2), pb4 = pa + 4;
+            const unsigned base = (unsigned)(((t_ok[i] ? pr : 0) * 2 + ch) * (R::CU * 16) + ((tt & 1) << 3));
+            xa[i] = base + pa * 32 + ((((tt & 3) >> 1) ^ ((pa >> 3) & 1)) << 4);
+            xb[i] = base + pb4 * 32 + ((((tt & 3) >> 1) ^ ((pb4 >> 3) & 1)) << 4);
+        }
+    }
+    const bool wave_has = t_ok[0];                      // slots are filled in order: an empty first slot = an idle wave
+    const unsigned g_off = tr_lane_off(R::GCH, lane);
+    const int* dyp = t_dy;
+    const bool* okp = t_ok;
+    const unsigned *xap = xa, *xbp = xb;
+
+    floatx16 acc[TPW];
+    floatx16* accp = acc;
+    float bsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    int x_px[R::NXJ];
+    unsigned x_src[R::NXJ];
+#pragma unroll
+    for (int j = 0; j < R::NXJ; ++j) {
+        const int piece = wave + 8 * j;
+        const int u = (piece % R::XP) * 64 + lane;
+        const int cl = u / R::CU, within = u % R::CU;
+        const int pp = within >> 1, sh = within & 1;
+        const int c = 2 * cp0 + cl;
+        const bool have = (piece < R::NPL * R::XP) && (within < 68) && (cl < 2 * a.ppg) && (c < a.cin_chunks);
+        x_px[j] = have ? pp : -(1 << 20);
+        x_src[j] = (unsigned)c * plane_bytes + (unsigned)(pp * 32 + ((sh ^ ((pp >> 3) & 1)) << 4));
+    }
+    const int g_px = lane >> 1;
+    const unsigned g_src = (unsigned)(g_px * 32 + (((lane & 1) ^ ((g_px >> 3) & 1)) << 4));
+    const int g_pl = (wave >> 1) & 1, g_h = wave & 1;
+    const int g_c = 2 * cot + g_h;
+    const bool g_have = (wave < 2 * R::NPL) && (g_c < a.cout_chunks);
+
+    const unsigned xbytes = (unsigned)a.cin_chunks * plane_bytes;
+    __amdgpu_buffer_rsrc_t x_rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x_hi, 0, xbytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t x_rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(NT == 3 ? a.x_lo : a.x_hi), 0, xbytes, 0x00020000);
+    const _Float16* g_ptr = (g_pl ? a.g_lo : a.g_hi) + (long long)(g_have ? g_c : 0) * plane_elems;
+    __amdgpu_buffer_rsrc_t g_rs = __builtin_amdgcn_make_buffer_rsrc((void*)g_ptr, 0, g_have ? plane_bytes : 0u, 0x00020000);
+
+    for (int unit = pb; unit < a.ntiles; unit += a.PB) {
+        int b = unit;
+        const int seg = b % a.tiles_y; b /= a.tiles_y;
+        const int tx = b % a.tiles_x;
+        const int img = b / a.tiles_x;
+        const int tx0 = tx * 32, y0 = seg * R3_SEG;
+        const int rows = (H - y0 < R3_SEG) ? H - y0 : R3_SEG;
+        const int nst = (rows + 1) >> 1;
+        unsigned xcol[R::NXJ];
+        bool xok[R::NXJ];
+#pragma unroll
+        for (int j = 0; j < R::NXJ; ++j) {
+            xok[j] = (unsigned)(tx0 - 1 + x_px[j]) < (unsigned)W;
+            xcol[j] = x_src[j] + (unsigned)((tx0 - 1) * 32);
+        }
+        const bool gcol = tx0 + g_px < W;
+        const unsigned gcolsrc = g_src + (unsigned)(tx0 * 32);
+        const unsigned imgrow = (unsigned)img * (unsigned)H;
+        // X row y0 - 1 + q lives in ring slot q % 6, gY row y0 + j in slot j % 4.  Stage st (rows j = 2 st, j + 1) multiplies X
+        // rows q = j .. j + 3 and gY rows j, j + 1 while q = j + 4, j + 5 and gY rows j + 2, j + 3 (issued at its start) land.
+        if (!(a.dbg & 1)) {
+            for (int q = 0; q < 4; ++q) r32_issue_x<R, NT>(smem, q, wave, y0, H, W, imgrow, x_rs0, x_rs1, xok, xcol);
+            r32_issue_g<R>(smem, 0, wave, y0, H, W, imgrow, g_rs, gcol, gcolsrc, g_pl * 2 + g_h);
+            r32_issue_g<R>(smem, 1, wave, y0, H, W, imgrow, g_rs, gcol, gcolsrc, g_pl * 2 + g_h);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int st = 0; st < nst; ++st) {
+            const int j = 2 * st;
+            if (!(a.dbg & 1) && st + 1 < nst) {
+                r32_issue_x<R, NT>(smem, j + 4, wave, y0, H, W, imgrow, x_rs0, x_rs1, xok, xcol);
+                r32_issue_x<R, NT>(smem, j + 5, wave, y0, H, W, imgrow, x_rs0, x_rs1, xok, xcol);
+                r32_issue_g<R>(smem, j + 2, wave, y0, H, W, imgrow, g_rs, gcol, gcolsrc, g_pl * 2 + g_h);
+                r32_issue_g<R>(smem, j + 3, wave, y0, H, W, imgrow, g_rs, gcol, gcolsrc, g_pl * 2 + g_h);
+            }
+            if (!(a.dbg & 2) && wave_has) {
+                const unsigned x0s = lds_addr(smem);
+                // ring slots of X rows j-1 .. j+2 (four scalars: a runtime-indexed array would live in scratch) and, per tile,
+                // the slot of its tap row for the stage's first / second output row
+                const unsigned s0 = x0s + ((j + 0) % R::NXS) * R::XSLOT, s1 = x0s + ((j + 1) % R::NXS) * R::XSLOT;
+                const unsigned s2 = x0s + ((j + 2) % R::NXS) * R::XSLOT, s3 = x0s + ((j + 3) % R::NXS) * R::XSLOT;
+                unsigned rb0[TPW], rb1[TPW];
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) {
+                    rb0[i] = dyp[i] == 0 ? s0 : (dyp[i] == 1 ? s1 : s2);
+                    rb1[i] = dyp[i] == 0 ? s1 : (dyp[i] == 1 ? s2 : s3);
+                }
+                const unsigned g0 = x0s + R::G_BASE + ((j + 0) % R::NGS) * R::GSLOT + g_off;
+                const unsigned g1 = x0s + R::G_BASE + ((j + 1) % R::NGS) * R::GSLOT + g_off;
+                const unsigned *rb0p = rb0, *rb1p = rb1;
+                TrFrag Bh[2], Bl[2], Ah[3], Al[3];
+                auto load = [&](auto SC) {
+                    constexpr int s = decltype(SC)::value, blk = s / TPW, r = blk / 2, ks = blk % 2, i = s % TPW, q = s % 3;
+                    const unsigned gs = r == 0 ? g0 : g1;
+                    if constexpr (i == 0) {
+                        tr_issue_pair<ks * 512>(Bh[blk & 1], gs, gs + 128);
+                        if constexpr (NT == 3) tr_issue_pair<ks * 512 + 2 * R::GCH>(Bl[blk & 1], gs, gs + 128);
+                    }
+                    const unsigned rb = r == 0 ? rb0p[i] : rb1p[i];
+                    tr_issue_pair<ks * 512>(Ah[q], rb + xap[i], rb + xbp[i]);
+                    if constexpr (NT == 3) tr_issue_pair<ks * 512 + R::XROW>(Al[q], rb + xap[i], rb + xbp[i]);
+                };
+                load(std::integral_constant<int, 0>{});
+                load(std::integral_constant<int, 1>{});
+                static_for([&](auto SC) {
+                    constexpr int s = decltype(SC)::value, blk = s / TPW, i = s % TPW, q = s % 3;
+                    constexpr int later = (s + 1 < NSTEP) ? NA + (((s + 1) % TPW == 0) ? NA : 0) : 0;
+                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(later) : "memory");
+                    tr_tie(Ah[q]);
+                    if constexpr (NT == 3) tr_tie(Al[q]);
+                    if constexpr (i == 0) {
+                        tr_tie(Bh[blk & 1]);
+                        if constexpr (NT == 3) tr_tie(Bl[blk & 1]);
+                    }
+                    if constexpr (s + 2 < NSTEP) load(std::integral_constant<int, s + 2>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    const half8 bh = tr_value(Bh[blk & 1]);
+                    half8 bl;
+                    if constexpr (NT == 3) bl = tr_value(Bl[blk & 1]);
+                    if (i == 0 && bias_wave) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            bsum += (float)bh[e];
+                            if constexpr (NT == 3) bsum += (float)bl[e];
+                        }
+                    }
+                    if (okp[i]) {                       // wave-uniform: empty tile slots cost their (already issued) reads only
+                        const half8 ah = tr_value(Ah[q]);
+                        if constexpr (NT == 3) {
+                            const half8 al = tr_value(Al[q]);
+                            accp[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accp[i], 0, 0, 0);
+                            accp[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accp[i], 0, 0, 0);
+                        }
+                        accp[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accp[i], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }, std::make_integer_sequence<int, NSTEP>{});
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+
+    if (a.dbg & 4) { if (acc[0][0] == 12345.f) a.partial[0] = bsum; return; }
+    const int n = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        if (!t_ok[i]) continue;
+        const int k = wave * TPW + i;
+        const int cp = cp0 + k / 9, tap = k % 9;
+        float* dst = a.partial + ((((long long)cot * a.ncp + cp) * a.PB + pb) * 9 + tap) * 1024 + n;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2) + 4 * hi) * 32] = acc[i][e];
+    }
+    if (bias_wave) {
+        const float t = bsum + __shfl_xor(bsum, 32);
+        if (lane < 32) a.partial_b[((long long)cot * a.PB + pb) * 32 + lane] = t;
+    }
+}
+
 #endif  // BINHIP_TUNING (rolling-row experiment)
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1250,17 +1505,25 @@ static inline R3Plan r3_plan(int ncp) {
     p.tpw = (9 * p.ppg + 7) / 8;
     return p;
 }
+// two-rows-per-stage variant: <= 4 pairs per workgroup, balanced groups
+static inline R3Plan r3_plan2(int ncp) {
+    R3Plan p;
+    p.cgroups = (ncp + 3) / 4;
+    p.ppg = (ncp + p.cgroups - 1) / p.cgroups;
+    p.tpw = (9 * p.ppg + 7) / 8;
+    return p;
+}
 static inline bool r3_usable(int ksize, int N, int H, int W, int cin_chunks, int x_cpg) {
     return ksize == 3 && x_cpg == 0 && (unsigned long long)cin_chunks * N * H * W * 32ull < 0xfffffff0ull;
 }
 
-WgGeom wg_geom(int ksize, int N, int H, int W, int cin_chunks, int cout, int cus, bool roll = false) {
+WgGeom wg_geom(int ksize, int N, int H, int W, int cin_chunks, int cout, int cus, int roll = 0) {
     WgGeom g;
     if (roll) {
         g.tr = 3; g.ndyg = 1; g.ntap = 9;
         g.ncp = (cin_chunks + 1) / 2;
         g.ncot = (cout + 31) / 32;
-        const R3Plan rp = r3_plan(g.ncp);
+        const R3Plan rp = (roll == 2) ? r3_plan2(g.ncp) : r3_plan(g.ncp);
         g.tiles_x = (W + 31) / 32;
         g.tiles_y = (H + R3_SEG - 1) / R3_SEG;              // column segments per image
         g.ntiles = g.tiles_x * g.tiles_y * N;
@@ -1351,6 +1614,25 @@ int launch_r3_t(const WgradKArgs& a, const WgGeom& g, const R3Plan& rp, hipStrea
     BH_CHECK_LAUNCH();
     return 0;
 }
+template <int NT, int TPW>
+int launch_r32_t(const WgradKArgs& a, const WgGeom& g, const R3Plan& rp, hipStream_t s) {
+    using R = R3Cfg2<NT, TPW>;
+    static std::atomic<unsigned long long> lds_set{0};
+    if (int rc = bh_set_max_lds(&wgrad3x3_roll2_kernel<NT, TPW>, R::LDS_BYTES, lds_set)) return rc;
+    wgrad3x3_roll2_kernel<NT, TPW><<<dim3((unsigned)g.PB, (unsigned)(rp.cgroups * g.ncot)), dim3(512), R::LDS_BYTES, s>>>(a);
+    BH_CHECK_LAUNCH();
+    return 0;
+}
+template <int NT>
+int launch_r32(const WgradKArgs& a, const WgGeom& g, const R3Plan& rp, hipStream_t s) {
+    switch (rp.tpw) {
+        case 2: return launch_r32_t<NT, 2>(a, g, rp, s);
+        case 3: return launch_r32_t<NT, 3>(a, g, rp, s);
+        case 4: return launch_r32_t<NT, 4>(a, g, rp, s);
+        case 5: return launch_r32_t<NT, 5>(a, g, rp, s);
+    }
+    return BINHIP_E_SHAPE;
+}
 template <int NT>
 int launch_r3(const WgradKArgs& a, const WgGeom& g, const R3Plan& rp, hipStream_t s) {
     switch (rp.tpw) {
@@ -1394,8 +1676,10 @@ size_t binhip_wgrad_workspace_bytes(int ksize, int N, int H, int W, int cin_chun
     const WgGeom g = wg_geom(ksize, N, H, W, cin_chunks, cout, cus());
     size_t fl = g.partial_floats + g.bias_floats;
     if (BINHIP_TUNING && r3_usable(ksize, N, H, W, cin_chunks, 0)) {   // the rolling-row experiment keeps more partials
-        const WgGeom r = wg_geom(ksize, N, H, W, cin_chunks, cout, cus(), true);
-        if (r.partial_floats + r.bias_floats > fl) fl = r.partial_floats + r.bias_floats;
+        for (int roll = 1; roll <= 2; ++roll) {
+            const WgGeom r = wg_geom(ksize, N, H, W, cin_chunks, cout, cus(), roll);
+            if (r.partial_floats + r.bias_floats > fl) fl = r.partial_floats + r.bias_floats;
+        }
     }
     return fl * sizeof(float) + 256;
 }
@@ -1415,7 +1699,8 @@ int bh_wgrad_partials(const BinConvDesc* d, const void* x_hi, const void* x_lo, 
     if ((long long)d->N * d->H * d->W >= (1ll << 26)) return BINHIP_E_SHAPE;
     if (cin <= 0 || cin > d->cin_chunks * 16) return BINHIP_E_SHAPE;
     if (shuffle_perm && d->cout % 4) return BINHIP_E_SHAPE;
-    const bool roll = (WG_DBG & 128) && r3_usable(d->ksize, d->N, d->H, d->W, d->cin_chunks, d->x_cpg);   // side builds only
+    const bool r3ok = r3_usable(d->ksize, d->N, d->H, d->W, d->cin_chunks, d->x_cpg);
+    const int roll = ((WG_DBG & 64) && r3ok) ? 2 : ((WG_DBG & 128) && r3ok) ? 1 : 0;       // side builds only
     const WgGeom g = wg_geom(d->ksize, d->N, d->H, d->W, d->cin_chunks, d->cout, cus(), roll);
     const size_t need = (g.partial_floats + g.bias_floats) * sizeof(float) + 256;
     if (workspace_bytes < need) return BINHIP_E_WORKSPACE;
@@ -1445,6 +1730,11 @@ int bh_wgrad_partials(const BinConvDesc* d, const void* x_hi, const void* x_lo, 
         rc = (d->nterms == 1) ? launch_wg_sb<3, 3, 1>(a, g, s) : launch_wg_sb<3, 3, 3>(a, g, s);
 #endif
 #if BINHIP_TUNING
+    } else if (roll == 2) {                         // 3x3, rolling rows, two rows per stage (experiment)
+        const R3Plan rp = r3_plan2(g.ncp);
+        a.cgroups = rp.cgroups;
+        a.ppg = rp.ppg;
+        rc = (d->nterms == 1) ? launch_r32<1>(a, g, rp, s) : launch_r32<3>(a, g, rp, s);
     } else if (roll) {                              // 3x3, rolling rows (experiment)
         const R3Plan rp = r3_plan(g.ncp);
         a.cgroups = rp.cgroups;
