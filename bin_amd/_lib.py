@@ -11,6 +11,7 @@ BWD_ACCUMULATE = 1          # BinRdnBwdPlan.reserved flag (BINHIP_BWD_ACCUMULATE
 BWD_SAVED_X3 = 2            # BINHIP_BWD_SAVED_X3
 EPI_PLANES, EPI_SHUFFLE, EPI_FINAL = 0, 1, 2
 PROF_WGRAD = 16             # BINHIP_PROF_WGRAD
+LOSS_CHARBONNIER, LOSS_L1_SUM, LOSS_L2_SUM = 0, 1, 2
 RDN_LAYOUT_WORDS, RDN_BWD_LAYOUT_WORDS = 16, 24
 
 
@@ -38,6 +39,15 @@ class BinRdnBwdPlan(C.Structure):
                 ("status", C.c_void_p), ("aux_stream", C.c_void_p), ("profiler", C.c_void_p)]
 
 
+class BinRelayoutItem(C.Structure):
+    _fields_ = [("w", C.c_void_p * 4), ("bias", C.c_void_p), ("w_hi", C.c_void_p), ("w_lo", C.c_void_p),
+                ("bias_out", C.c_void_p), ("kind", C.c_int32), ("cout", C.c_int32), ("cin", C.c_int32),
+                ("ksize", C.c_int32), ("rows_pad", C.c_int32), ("cin_chunks", C.c_int32), ("cout_block", C.c_int32),
+                ("shuffle_or_group", C.c_int32)]
+
+
+RELAYOUT_FWD, RELAYOUT_DGRAD, RELAYOUT_RDB_GATHER = 0, 1, 2
+
 _SIGNATURES = {
     "binhip_version": (C.c_int, []),
     "binhip_device_cus": (C.c_int, []),
@@ -45,6 +55,7 @@ _SIGNATURES = {
     "binhip_weights_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "binhip_weights_relayout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "binhip_weights_relayout_batch": (C.c_int, [C.POINTER(BinRelayoutItem), C.c_int, C.c_void_p]),
     "binhip_conv2d_fwd": (C.c_int, [C.POINTER(BinConvDesc)] + [C.c_void_p] * 10 +
                           [C.POINTER(C.c_void_p), C.c_void_p]),
     "binhip_nchw_to_planes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
@@ -66,6 +77,10 @@ _SIGNATURES = {
                                          C.c_void_p]),
     "binhip_charbonnier_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p]),
+    "binhip_pixel_loss_fwd": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
+    "binhip_pixel_loss_bwd": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]),
     "binhip_dgrad_rows_pad": (C.c_int, [C.c_int, C.c_int]),
     "binhip_weights_relayout_dgrad": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                 C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -32,8 +32,9 @@
 #ifndef BINHIP_X3_WN
 #define BINHIP_X3_WN 8
 #endif
-// side builds only: 1 = wave priority falls with the tile's progress (s_setprio 3 .. 0 per quarter of the K loop), so of the two
-// workgroups sharing a CU the one that lags issues first and they finish together instead of one running alone at the end
+// bit 0 (this kernel) / bit 1 (the fused tail, binhip_fused_x3.hip): wave priority falls with the tile's progress (s_setprio 3 .. 0
+// per quarter of the K loop), so of the two workgroups sharing a CU the one that lags issues first and they finish together
+// instead of one running alone at the end of the launch
 #ifndef BINHIP_X3_PRIO
 #define BINHIP_X3_PRIO 0
 #endif
@@ -196,7 +197,7 @@ __device__ __forceinline__ void x3_tile(const ConvKArgs& a, char* smem, int img,
     x3_issue_patch<C>(a, smem, 0, 0, 0, wave, voff, plane_elems, plane_bytes);
     for (int c = 0; c < nchunks; ++c) {
         const char* wb = smem + 2 * C::PATCH_BYTES + (c & 1) * C::WBUF_BYTES;
-#if BINHIP_X3_PRIO
+#if BINHIP_X3_PRIO & 1
         {
             const int q = (4 * c) / nchunks;
             if (q == 0) __builtin_amdgcn_s_setprio(3);

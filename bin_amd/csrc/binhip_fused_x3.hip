@@ -15,6 +15,9 @@
 // = 70 KB; registers <= 256 at one wave per SIMD.  Two such workgroups — or one of them beside a workgroup of the
 // plane-split conv kernel from another stream — share a CU, each covering the other's waits.
 #include "binhip_fused.h"
+#ifndef BINHIP_X3_PRIO
+#define BINHIP_X3_PRIO 0      // bit 1: progress-ordered wave priority in this kernel (binhip_conv_x3.hip explains)
+#endif
 
 namespace {
 
@@ -208,6 +211,15 @@ rdb_tail_x3_kernel(const TailKArgs a) {
     tx_issue_patch(a, smem, 0, 0, wave, voff, plane_elems, plane_bytes);
     for (int c = 0; c < TX::NCHUNK; ++c) {
         const char* wb = smem + TX::W_OFF + (c & 1) * TX::WBUF_BYTES;
+#if BINHIP_X3_PRIO & 2
+        {   // priority falls with progress (see binhip_conv_x3.hip): the workgroup that lags its CU neighbour issues first
+            const int q = (4 * c) / TX::NCHUNK;
+            if (q == 0) __builtin_amdgcn_s_setprio(3);
+            else if (q == 1) __builtin_amdgcn_s_setprio(2);
+            else if (q == 2) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+#endif
         // ---- hi sub-stage; meanwhile the lo plane and the next chunk's weights (last chunk: the o3 LFF weights) land
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();

@@ -179,16 +179,27 @@ convlstm_kernel(const float* __restrict__ x, const float* __restrict__ cp, const
     }
 }
 
-// ---- Charbonnier ---------------------------------------------------------------------------------
+// ---- pixel criteria (bin_model.py:52-60): Charbonnier mean (loss.py:137-141), L1 sum, L2 sum --------------------
 #define CHARB_BLOCKS 1024
+template <int KIND>
+__device__ __forceinline__ float crit_term(float d, float eps) {
+    if constexpr (KIND == BINHIP_LOSS_CHARBONNIER) return sqrtf(d * d + eps);
+    else if constexpr (KIND == BINHIP_LOSS_L1_SUM) return fabsf(d);
+    else return d * d;
+}
+template <int KIND>
+__device__ __forceinline__ float crit_grad(float d, float eps) {
+    if constexpr (KIND == BINHIP_LOSS_CHARBONNIER) return d / sqrtf(d * d + eps);
+    else if constexpr (KIND == BINHIP_LOSS_L1_SUM) return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);      // torch: sign(0) = 0
+    else return 2.f * d;
+}
+template <int KIND>
 __global__ void __launch_bounds__(256)
 charb_partial_kernel(const float* __restrict__ x, const float* __restrict__ y, long long n, float eps,
                      float* __restrict__ partials) {
     float acc = 0.f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const float d = x[i] - y[i];
-        acc += sqrtf(d * d + eps);
-    }
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        acc += crit_term<KIND>(x[i] - y[i], eps);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
     __shared__ float sm[4];
@@ -196,8 +207,9 @@ charb_partial_kernel(const float* __restrict__ x, const float* __restrict__ y, l
     __syncthreads();
     if (threadIdx.x == 0) partials[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
+// `denom`: numel for the mean criterion, 1 for the sum criteria
 __global__ void __launch_bounds__(256)
-charb_final_kernel(const float* __restrict__ partials, int nb, long long n, float* __restrict__ loss) {
+charb_final_kernel(const float* __restrict__ partials, int nb, double denom, float* __restrict__ loss) {
     double acc = 0.0;
     for (int i = threadIdx.x; i < nb; i += 256) acc += (double)partials[i];
     __shared__ double sm[256];
@@ -207,15 +219,15 @@ charb_final_kernel(const float* __restrict__ partials, int nb, long long n, floa
         if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) loss[0] = (float)(sm[0] / (double)n);
+    if (threadIdx.x == 0) loss[0] = (float)(sm[0] / denom);
 }
+template <int KIND>
 __global__ void __launch_bounds__(256)
-charb_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, long long n, float eps,
+charb_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, long long n, float eps, float inv_denom,
                  const float* __restrict__ gl, float* __restrict__ gx, float* __restrict__ gy) {
-    const float s = gl[0] / (float)n;
+    const float s = gl[0] * inv_denom;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const float d = x[i] - y[i];
-        const float g = s * d / sqrtf(d * d + eps);
+        const float g = s * crit_grad<KIND>(x[i] - y[i], eps);
         if (gx) gx[i] = g;
         if (gy) gy[i] = -g;
     }
@@ -544,30 +556,55 @@ int binhip_convlstm_fwd(const float* x, const float* c_prev, const float* h_prev
 
 int binhip_charbonnier_partials(int64_t numel) { (void)numel; return CHARB_BLOCKS; }
 
-int binhip_charbonnier_fwd(const float* x, const float* y, int64_t numel, float eps, float* partials, float* loss,
-                           void* stream) {
+int binhip_pixel_loss_fwd(int kind, const float* x, const float* y, int64_t numel, float eps, float* partials, float* loss,
+                          void* stream) {
     if (!x || !y || !partials || !loss) return BINHIP_E_ARG;
+    if (kind < BINHIP_LOSS_CHARBONNIER || kind > BINHIP_LOSS_L2_SUM) return BINHIP_E_ARG;
     if (numel <= 0) return BINHIP_E_SHAPE;
     long long nb = (numel + 255) / 256;
     if (nb > CHARB_BLOCKS) nb = CHARB_BLOCKS;
-    hipLaunchKernelGGL(charb_partial_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, y,
-                       (long long)numel, eps, partials);
-    hipLaunchKernelGGL(charb_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, (int)nb,
-                       (long long)numel, loss);
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)nb), block(256);
+    if (kind == BINHIP_LOSS_CHARBONNIER)
+        hipLaunchKernelGGL(charb_partial_kernel<BINHIP_LOSS_CHARBONNIER>, grid, block, 0, s, x, y, (long long)numel, eps, partials);
+    else if (kind == BINHIP_LOSS_L1_SUM)
+        hipLaunchKernelGGL(charb_partial_kernel<BINHIP_LOSS_L1_SUM>, grid, block, 0, s, x, y, (long long)numel, eps, partials);
+    else
+        hipLaunchKernelGGL(charb_partial_kernel<BINHIP_LOSS_L2_SUM>, grid, block, 0, s, x, y, (long long)numel, eps, partials);
+    hipLaunchKernelGGL(charb_final_kernel, dim3(1), dim3(256), 0, s, partials, (int)nb,
+                       kind == BINHIP_LOSS_CHARBONNIER ? (double)numel : 1.0, loss);
     BH_CHECK_LAUNCH();
     return 0;
 }
 
-int binhip_charbonnier_bwd(const float* x, const float* y, int64_t numel, float eps, const float* gloss, float* gx,
-                           float* gy, void* stream) {
+int binhip_pixel_loss_bwd(int kind, const float* x, const float* y, int64_t numel, float eps, const float* gloss, float* gx,
+                          float* gy, void* stream) {
     if (!x || !y || !gloss || (!gx && !gy)) return BINHIP_E_ARG;
+    if (kind < BINHIP_LOSS_CHARBONNIER || kind > BINHIP_LOSS_L2_SUM) return BINHIP_E_ARG;
     if (numel <= 0) return BINHIP_E_SHAPE;
     long long nb = (numel + 255) / 256;
     if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(charb_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, y,
-                       (long long)numel, eps, gloss, gx, gy);
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)nb), block(256);
+    const float inv = kind == BINHIP_LOSS_CHARBONNIER ? 1.f / (float)numel : 1.f;
+    if (kind == BINHIP_LOSS_CHARBONNIER)
+        hipLaunchKernelGGL(charb_bwd_kernel<BINHIP_LOSS_CHARBONNIER>, grid, block, 0, s, x, y, (long long)numel, eps, inv, gloss, gx, gy);
+    else if (kind == BINHIP_LOSS_L1_SUM)
+        hipLaunchKernelGGL(charb_bwd_kernel<BINHIP_LOSS_L1_SUM>, grid, block, 0, s, x, y, (long long)numel, eps, inv, gloss, gx, gy);
+    else
+        hipLaunchKernelGGL(charb_bwd_kernel<BINHIP_LOSS_L2_SUM>, grid, block, 0, s, x, y, (long long)numel, eps, inv, gloss, gx, gy);
     BH_CHECK_LAUNCH();
     return 0;
+}
+
+int binhip_charbonnier_fwd(const float* x, const float* y, int64_t numel, float eps, float* partials, float* loss,
+                           void* stream) {
+    return binhip_pixel_loss_fwd(BINHIP_LOSS_CHARBONNIER, x, y, numel, eps, partials, loss, stream);
+}
+
+int binhip_charbonnier_bwd(const float* x, const float* y, int64_t numel, float eps, const float* gloss, float* gx,
+                           float* gy, void* stream) {
+    return binhip_pixel_loss_bwd(BINHIP_LOSS_CHARBONNIER, x, y, numel, eps, gloss, gx, gy, stream);
 }
 
 int binhip_u8_to_frame(const unsigned char* bgr_hwc, int H, int W, int pad_left, int pad_right, int pad_top,

@@ -19,7 +19,7 @@ import torch.nn as nn
 from . import lr_scheduler, networks
 from .base_model import BaseModel, _direct_param_grads
 from .bin_model import FlatGradAllReduce, SingleProcessParallel, _get
-from .loss import CharbonnierLoss
+from .loss import CharbonnierLoss, L1SumLoss, L2SumLoss
 from ..utils import util
 
 logger = logging.getLogger("base")
@@ -55,9 +55,9 @@ class VideoBaseModel(BaseModel):
         if cri_pix is not None:
             self.cri_pix = cri_pix
         elif kind == "l1":
-            self.cri_pix = nn.L1Loss(reduction="sum").to(self.device)
+            self.cri_pix = L1SumLoss().to(self.device)
         elif kind == "l2":
-            self.cri_pix = nn.MSELoss(reduction="sum").to(self.device)
+            self.cri_pix = L2SumLoss().to(self.device)
         elif kind == "cb":
             self.cri_pix = _CbPair().to(self.device)
         else:

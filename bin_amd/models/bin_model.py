@@ -19,7 +19,7 @@ import torch.nn as nn
 from . import lr_scheduler
 from . import networks
 from .base_model import BaseModel, unwrap, _direct_param_grads
-from .loss import CharbonnierLoss
+from .loss import CharbonnierLoss, L1SumLoss, L2SumLoss
 from ..utils import dist_util, util
 from ..utils.util import AverageMeter
 
@@ -242,9 +242,9 @@ class bin_model(BaseModel):
             self.netG.train()
             self.loss_type = loss_type = train_opt["pixel_criterion"]
             if loss_type == "l1":
-                self.cri_pix = nn.L1Loss(reduction="sum").to(self.device)
+                self.cri_pix = L1SumLoss().to(self.device)        # nn.L1Loss(reduction='sum') in the reference
             elif loss_type == "l2":
-                self.cri_pix = nn.MSELoss(reduction="sum").to(self.device)
+                self.cri_pix = L2SumLoss().to(self.device)        # nn.MSELoss(reduction='sum')
             elif loss_type == "cb":
                 self.cri_pix = CharbonnierLoss().to(self.device)
             else:

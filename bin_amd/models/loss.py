@@ -1,23 +1,26 @@
-"""CharbonnierLoss (reference models/loss.py:130-141) on the HIP reduction kernels, with backward."""
+"""Pixel criteria of bin_model (reference models/bin_model.py:52-60) on the HIP reduction kernels, with backward:
+CharbonnierLoss (reference models/loss.py:130-141), and the sum-reduced L1 / L2 losses the option 'pixel_criterion'
+can select instead (`nn.L1Loss(reduction='sum')`, `nn.MSELoss(reduction='sum')` in the reference)."""
 import torch
 import torch.nn as nn
 
 from .. import ops
+from .. import _lib as L
 
 
-class _CharbonnierFn(torch.autograd.Function):
+class _PixelLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, y, eps):
+    def forward(ctx, x, y, kind, eps):
         ctx.save_for_backward(x, y)
-        ctx.eps = eps
-        return ops.charbonnier(x, y, eps)
+        ctx.kind, ctx.eps = kind, eps
+        return ops.pixel_loss(kind, x, y, eps)
 
     @staticmethod
     def backward(ctx, g):
         x, y = ctx.saved_tensors
-        gx = ops.charbonnier_grad(x, y, g, ctx.eps)
+        gx = ops.pixel_loss_grad(ctx.kind, x, y, g, ctx.eps)
         return (gx if ctx.needs_input_grad[0] else None,
-                -gx if ctx.needs_input_grad[1] else None, None)
+                -gx if ctx.needs_input_grad[1] else None, None, None)
 
 
 class CharbonnierLoss(nn.Module):
@@ -28,4 +31,18 @@ class CharbonnierLoss(nn.Module):
         self.eps = eps
 
     def forward(self, x, y):
-        return _CharbonnierFn.apply(x, y, self.eps)
+        return _PixelLossFn.apply(x, y, L.LOSS_CHARBONNIER, self.eps)
+
+
+class L1SumLoss(nn.Module):
+    """sum |x - y|  (= nn.L1Loss(reduction='sum'), bin_model.py:55)."""
+
+    def forward(self, x, y):
+        return _PixelLossFn.apply(x, y, L.LOSS_L1_SUM, 0.0)
+
+
+class L2SumLoss(nn.Module):
+    """sum (x - y)^2  (= nn.MSELoss(reduction='sum'), bin_model.py:57)."""
+
+    def forward(self, x, y):
+        return _PixelLossFn.apply(x, y, L.LOSS_L2_SUM, 0.0)

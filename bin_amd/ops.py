@@ -4,6 +4,7 @@ PyTorch is plumbing here (device memory, streams); every computation is a hand-w
 Activations between layers are "chunk planes" (CP): fp16 [C/16][N][H][W][16], optionally hi+lo.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -136,10 +137,39 @@ def pack_inputs(images, nterms=1):
     return y
 
 
-class ConvWeights:
-    """Kernel-layout weights of one convolution (see binhip_weights_relayout)."""
+def relayout_item(kind, srcs, bias, w_hi, w_lo, bias_out, cout, cin, ks, rows_pad, cin_chunks, cout_block, shuffle_or_group):
+    """One BinRelayoutItem (include/binhip.h).  `srcs`: the fp32 OIHW source tensor(s); the caller keeps them alive until
+    relayout_batch() has enqueued the launch."""
+    it = L.BinRelayoutItem()
+    for i, t in enumerate(srcs):
+        it.w[i] = t.data_ptr() if t is not None else None
+    it.bias = bias.data_ptr() if bias is not None else None
+    it.w_hi, it.w_lo = w_hi.data_ptr(), (w_lo.data_ptr() if w_lo is not None else None)
+    it.bias_out = bias_out.data_ptr()
+    it.kind, it.cout, it.cin, it.ksize, it.rows_pad = kind, cout, cin, ks, rows_pad
+    it.cin_chunks, it.cout_block, it.shuffle_or_group = cin_chunks, cout_block, shuffle_or_group
+    return it
 
-    def __init__(self, weight, bias, nterms=1, shuffle=False, cout_pad=None, cin_chunks=None):
+
+def relayout_batch(items):
+    """Enqueue the relayouts of `items` (list of BinRelayoutItem) in as few launches as the library needs.
+    BIN_AMD_RELAYOUT_BATCH=0 (A/B switch of tools/): one launch per item, as before round 3."""
+    if not items:
+        return
+    lib = L.lib()
+    if os.environ.get("BIN_AMD_RELAYOUT_BATCH", "1") == "0":
+        for it in items:
+            L.check(lib.binhip_weights_relayout_batch(C.byref(it), 1, _stream()), "weights_relayout_batch")
+        return
+    arr = (L.BinRelayoutItem * len(items))(*items)
+    L.check(lib.binhip_weights_relayout_batch(arr, len(items), _stream()), "weights_relayout_batch")
+
+
+class ConvWeights:
+    """Kernel-layout weights of one convolution (see binhip_weights_relayout).  `defer`: a list that receives this
+    layer's relayout item instead of launching it (RdnWeights batches the 66 layers of a weight set)."""
+
+    def __init__(self, weight, bias, nterms=1, shuffle=False, cout_pad=None, cin_chunks=None, defer=None):
         _need_cuda(weight)
         cout, cin, ks, _ = weight.shape
         self.cout, self.cin, self.ks, self.nterms, self.shuffle = cout, cin, ks, nterms, shuffle
@@ -154,6 +184,11 @@ class ConvWeights:
         self.bias = torch.empty(self.cout_pad, dtype=torch.float32, device=dev)
         w = weight.detach().contiguous().float()
         b = bias.detach().contiguous().float() if bias is not None else None
+        if defer is not None:
+            self._src = (w, b)
+            defer.append(relayout_item(L.RELAYOUT_FWD, [w], b, self.w_hi, self.w_lo, self.bias, cout, cin, ks, self.cout_pad,
+                                       self.cin_chunks, self.cout_block, 1 if shuffle else 0))
+            return
         L.check(lib.binhip_weights_relayout(_ptr(w), _ptr(b), cout, cin, ks, self.cout_pad, self.cin_chunks,
                                             self.cout_block, 1 if shuffle else 0, _ptr(self.w_hi), _ptr(self.w_lo),
                                             _ptr(self.bias), _stream()), "weights_relayout")
@@ -211,27 +246,38 @@ def convlstm_cell(x, state, weight, bias, forget_bias=1.0):
     return hn, [cn, hn]
 
 
-def charbonnier(x, y, eps=1e-6):
-    """mean(sqrt((x-y)^2 + eps)) (reference loss.py:137-141), forward only."""
+def pixel_loss(kind, x, y, eps=1e-6):
+    """One of bin_model's pixel criteria (L.LOSS_*), forward only: Charbonnier mean, L1 sum, L2 sum."""
     _need_cuda(x, y)
     x = x.contiguous().float()
     y = y.contiguous().float()
     lib = L.lib()
     part = torch.empty(lib.binhip_charbonnier_partials(x.numel()), dtype=torch.float32, device=x.device)
     loss = torch.empty((), dtype=torch.float32, device=x.device)
-    L.check(lib.binhip_charbonnier_fwd(_ptr(x), _ptr(y), x.numel(), float(eps), _ptr(part), _ptr(loss), _stream()),
-            "charbonnier_fwd")
+    with on_device(x):
+        L.check(lib.binhip_pixel_loss_fwd(kind, _ptr(x), _ptr(y), x.numel(), float(eps), _ptr(part), _ptr(loss), _stream()),
+                "pixel_loss_fwd")
     return loss
 
 
-def charbonnier_grad(x, y, gloss, eps=1e-6):
+def pixel_loss_grad(kind, x, y, gloss, eps=1e-6):
     x = x.contiguous().float()
     y = y.contiguous().float()
     gx = torch.empty_like(x)
     g = gloss.reshape(1).contiguous().float()
-    L.check(L.lib().binhip_charbonnier_bwd(_ptr(x), _ptr(y), x.numel(), float(eps), _ptr(g), _ptr(gx),
-                                           C.c_void_p(0), _stream()), "charbonnier_bwd")
+    with on_device(x):
+        L.check(L.lib().binhip_pixel_loss_bwd(kind, _ptr(x), _ptr(y), x.numel(), float(eps), _ptr(g), _ptr(gx),
+                                              C.c_void_p(0), _stream()), "pixel_loss_bwd")
     return gx
+
+
+def charbonnier(x, y, eps=1e-6):
+    """mean(sqrt((x-y)^2 + eps)) (reference loss.py:137-141), forward only."""
+    return pixel_loss(L.LOSS_CHARBONNIER, x, y, eps)
+
+
+def charbonnier_grad(x, y, gloss, eps=1e-6):
+    return pixel_loss_grad(L.LOSS_CHARBONNIER, x, y, gloss, eps)
 
 
 # --------------------------------------------------------------------------------------------- backward ops

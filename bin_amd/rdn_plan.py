@@ -5,7 +5,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
-from .ops import ConvWeights, _ptr, _stream, _need_cuda, on_device, status_word
+from .ops import ConvWeights, _ptr, _stream, _need_cuda, on_device, relayout_batch, relayout_item, status_word
 
 D_BLOCKS, C_CONVS = 12, 4
 
@@ -26,14 +26,16 @@ class RdnWeights:
     def __init__(self, params, n_inputs, nterms, prefix=""):
         self.n_inputs, self.nterms = n_inputs, nterms
         self.layers = []
+        items = []                         # the 66 relayouts of the set go out as a few batched launches
         for i, nm in enumerate(layer_names()):
             w, b = params[f"{prefix}{nm}.weight"], params[f"{prefix}{nm}.bias"]
             shuffle = nm == "UPNet.0"
             cin_chunks = None
             if nm == "SFENet1":
                 cin_chunks = (12 * n_inputs + 15) // 16
-            self.layers.append(ConvWeights(w, b, nterms=nterms, shuffle=shuffle, cin_chunks=cin_chunks))
+            self.layers.append(ConvWeights(w, b, nterms=nterms, shuffle=shuffle, cin_chunks=cin_chunks, defer=items))
         assert len(self.layers) == L.RDN_LAYERS
+        relayout_batch(items)
 
         self._dgrad = None
 
@@ -76,6 +78,8 @@ class RdnDgradWeights:
             lo = torch.empty(nbytes // 2, dtype=torch.float16, device=dev) if nterms == 3 else None
             return hi, lo, torch.empty(rows, dtype=torch.float32, device=dev)
 
+        items, scratch = [], []              # scratch: per-layer zero-bias outputs, only needed until the launch is queued
+        self._src = fp32
         for nm in names:
             w = fp32[nm]
             dev = w.device
@@ -84,20 +88,21 @@ class RdnDgradWeights:
                 d, g = int(nm.split(".")[1]), int(nm.split(".")[3])
                 rows, chunks = (96, 8) if g == 0 else (32, 2 * (4 - g))
                 hi, lo, zb = alloc(rows, chunks, 3)
-                src = (C.c_void_p * 4)(*[fp32[f"RDBs.{d}.convs.{c}.conv.0"].data_ptr() for c in range(4)])
+                srcs = [fp32[f"RDBs.{d}.convs.{c}.conv.0"] for c in range(4)]
                 cb = lib.binhip_conv_cout_block(3, rows, nterms)
-                L.check(lib.binhip_weights_relayout_rdb_gather(src, g, cb, _ptr(hi), _ptr(lo), _ptr(zb), _stream()),
-                        "weights_relayout_rdb_gather")
+                items.append(relayout_item(L.RELAYOUT_RDB_GATHER, srcs, None, hi, lo, zb, 32, 96 + 32 * g, 3, rows, chunks, cb, g))
             else:
                 rows_pad = lib.binhip_dgrad_rows_pad(ks, cin)
                 cin_chunks = (cout + 15) // 16
                 cb = lib.binhip_conv_cout_block(ks, rows_pad, nterms)
                 hi, lo, zb = alloc(rows_pad, cin_chunks, ks)
-                L.check(lib.binhip_weights_relayout_dgrad(_ptr(w), cout, cin, ks, rows_pad, cin_chunks, cb,
-                                                          1 if nm == "UPNet.0" else 0, _ptr(hi), _ptr(lo), _ptr(zb),
-                                                          _stream()), "weights_relayout_dgrad")
+                items.append(relayout_item(L.RELAYOUT_DGRAD, [w], None, hi, lo, zb, cout, cin, ks, rows_pad, cin_chunks, cb,
+                                           1 if nm == "UPNet.0" else 0))
             self.w_hi.append(hi)
             self.w_lo.append(lo)
+            scratch.append(zb)
+        relayout_batch(items)
+        del scratch
         self.zero_bias = torch.zeros(1152, dtype=torch.float32, device=dev)
 
     def fill_plan(self, plan):

@@ -95,6 +95,24 @@ BINHIP_API int binhip_weights_relayout(const float* w_oihw, const float* bias, i
                             int cout_pad, int cin_chunks, int cout_block, int shuffle_perm,
                             void* w_hi, void* w_lo, float* bias_out, void* stream);
 BINHIP_API size_t binhip_weights_bytes(int cout_pad, int cin_chunks, int ksize);   /* per plane (hi or lo) */
+/* Several relayouts per launch (a training step re-lays-out all 66 layers of a weight set twice, forward and backward
+ * layouts, after every optimizer update).  One item = the arguments of binhip_weights_relayout (kind FWD: rows_pad =
+ * cout_pad, shuffle_or_group = shuffle_perm), of binhip_weights_relayout_dgrad (kind DGRAD) or of
+ * binhip_weights_relayout_rdb_gather (kind RDB_GATHER: w[0..3] = the block's four conv weights, shuffle_or_group = group,
+ * rows_pad = 96 / 32, cin_chunks = 2 (4 - group), ksize = 3; bias is ignored, bias_out zeroed) — same results bit for bit.
+ * `items` is a HOST array; nothing of it is referenced after the call returns.                                        */
+#define BINHIP_RELAYOUT_FWD        0
+#define BINHIP_RELAYOUT_DGRAD      1
+#define BINHIP_RELAYOUT_RDB_GATHER 2
+typedef struct BinRelayoutItem {
+    const float* w[4];        /* OIHW fp32 sources (w[0] only, except RDB_GATHER)                     */
+    const float* bias;        /* FWD: bias or NULL                                                   */
+    void* w_hi;
+    void* w_lo;               /* NULL when nterms == 1                                               */
+    float* bias_out;          /* rows_pad floats                                                     */
+    int32_t kind, cout, cin, ksize, rows_pad, cin_chunks, cout_block, shuffle_or_group;
+} BinRelayoutItem;
+BINHIP_API int binhip_weights_relayout_batch(const BinRelayoutItem* items, int n, void* stream);
 
 BINHIP_API int binhip_conv2d_fwd(const BinConvDesc* d,
                       const void* x_hi, const void* x_lo,
@@ -173,6 +191,16 @@ BINHIP_API int binhip_charbonnier_fwd(const float* x, const float* y, int64_t nu
 /* gx = gloss * (x-y)/sqrt((x-y)^2+eps)/numel ; gy = -gx (either may be NULL).                    */
 BINHIP_API int binhip_charbonnier_bwd(const float* x, const float* y, int64_t numel, float eps,
                            const float* gloss, float* gx, float* gy, void* stream);
+/* The three pixel criteria bin_model.py:52-60 can select ('cb' | 'l1' | 'l2'), same reduction and workspace:
+ * CHARBONNIER = mean(sqrt((x-y)^2 + eps)) (the two entry points above), L1_SUM = nn.L1Loss(reduction='sum') =
+ * sum|x-y| (gradient sign(x-y), 0 at 0), L2_SUM = nn.MSELoss(reduction='sum') = sum (x-y)^2.                     */
+#define BINHIP_LOSS_CHARBONNIER 0
+#define BINHIP_LOSS_L1_SUM      1
+#define BINHIP_LOSS_L2_SUM      2
+BINHIP_API int binhip_pixel_loss_fwd(int kind, const float* x, const float* y, int64_t numel, float eps,
+                          float* partials, float* loss, void* stream);
+BINHIP_API int binhip_pixel_loss_bwd(int kind, const float* x, const float* y, int64_t numel, float eps,
+                          const float* gloss, float* gx, float* gy, void* stream);
 
 /* ---- fused tail of a residual dense block: o3 = relu(conv3x3(blk[0:192])), y = LFF(cat(blk[0:192], o3)) + blk[0:96]
  * (RDN.py:141-147 for conv #3, :162-165 for LFF + residual) in one kernel; blk = 14-chunk dense-block buffer,

@@ -314,3 +314,69 @@ def test_workspace_cache_is_bounded_and_skips_graph_capture():
     assert dict(rdn_plan._workspaces) == before                                            # nothing cached during capture
     rdn_plan.release_workspaces()
     assert not rdn_plan._workspaces
+
+
+# ------------------------------------------------------------------------------------------------ l1 / l2 criteria
+@pytest.mark.parametrize("kind", ["l1", "l2"])
+def test_l1_l2_sum_criteria_on_the_hip_kernels(kind, tmp_path):
+    """`pixel_criterion: l1 | l2` (reference bin_model.py:52-57: nn.L1Loss / nn.MSELoss with reduction='sum') run on the same
+    HIP reduction kernels as Charbonnier: value and gradient against torch's own fp32 ops, and a whole training step with
+    that criterion through the wrapper."""
+    from bin_amd.models import create_model
+    from bin_amd.models.loss import L1SumLoss, L2SumLoss
+    from bin_amd.weights import reference_state_dict
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(2, 3, 37, 53, generator=g).cuda().requires_grad_(True)
+    y = torch.rand(2, 3, 37, 53, generator=g).cuda()
+    with torch.no_grad():
+        y[0, 0, :5] = x[0, 0, :5]                                  # exact ties: sign(0) = 0 in the L1 gradient
+    mine = (L1SumLoss() if kind == "l1" else L2SumLoss())(x, y)
+    (mine * 0.37).backward()
+    gx = x.grad.clone()
+    x.grad = None
+    ref_mod = torch.nn.L1Loss(reduction="sum") if kind == "l1" else torch.nn.MSELoss(reduction="sum")
+    ref = ref_mod(x, y)
+    (ref * 0.37).backward()
+    assert abs(float(mine) - float(ref)) <= 2e-6 * abs(float(ref))
+    assert float((gx - x.grad).abs().max()) <= 1e-6
+    opt = _train_opt(tmp_path)
+    opt["train"]["pixel_criterion"] = kind
+    m = create_model(opt)
+    assert type(m.cri_pix).__name__ == ("L1SumLoss" if kind == "l1" else "L2SumLoss")
+    m.netG.module.load_state_dict(reference_state_dict(0), strict=True)
+    m.feed_data(_batch(1, 64, 3))
+    before = torch.cat([p.detach().reshape(-1) for p in m.netG.module.parameters()]).clone()
+    m.optimize_parameters(1)
+    after = torch.cat([p.detach().reshape(-1) for p in m.netG.module.parameters()])
+    assert torch.isfinite(m.loss) and float(m.loss) > 0 and torch.isfinite(after).all()
+    assert float((after - before).abs().max()) > 0
+
+
+# ------------------------------------------------------------------------------------------------ batched relayout
+def test_batched_relayout_equals_per_layer_relayout(canon_gpu):
+    """binhip_weights_relayout_batch (66 forward + 66 backward layouts of a weight set in a few launches) writes the same
+    bytes as the per-layer entry points."""
+    import ctypes as C
+    from bin_amd import ops, _lib as L
+    from bin_amd.rdn_plan import RdnWeights, RdnDgradWeights, layer_names
+    params = {k[len("model1."):]: v for k, v in canon_gpu.items() if k.startswith("model1.")}
+    for nt in (3, 1):
+        fw = RdnWeights(params, 2, nt)                                  # batched
+        bw = RdnDgradWeights(params, 2, nt)
+        lib = L.lib()
+        for i, nm in enumerate(layer_names()):
+            w, b = params[nm + ".weight"], params[nm + ".bias"]
+            one = ops.ConvWeights(w, b, nterms=nt, shuffle=nm == "UPNet.0", cin_chunks=2 if nm == "SFENet1" else None)
+            assert torch.equal(one.w_hi, fw.layers[i].w_hi) and torch.equal(one.bias, fw.layers[i].bias), nm
+            assert nt == 1 or torch.equal(one.w_lo, fw.layers[i].w_lo), nm
+            if ".convs." in nm:
+                d, g = int(nm.split(".")[1]), int(nm.split(".")[3])
+                ref = ops.RdbGatherWeights([params[f"RDBs.{d}.convs.{c}.conv.0.weight"] for c in range(4)], g, nt)
+            else:
+                ref = ops.DgradWeights(w, nterms=nt, shuffle=nm == "UPNet.0")
+            assert torch.equal(ref.w_hi, bw.w_hi[i]), nm
+            assert nt == 1 or torch.equal(ref.w_lo, bw.w_lo[i]), nm
+    null = C.c_void_p(0)
+    assert lib.binhip_weights_relayout_batch(None, 1, null) == -1
+    bad = L.BinRelayoutItem()
+    assert lib.binhip_weights_relayout_batch(C.byref(bad), 1, null) == -1
