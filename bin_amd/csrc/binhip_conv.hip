@@ -584,7 +584,8 @@ __global__ void relayout_dgrad_kernel(const float* __restrict__ w, int cout, int
 // (cmin = g for g >= 1, 0 for g = 0).  Stacking those convs' masked output gradients G_c (32 channels each, contiguous
 // in the gradient buffer) along K turns the sum into ONE forward-shaped conv per group:
 //   Wg[r][32 (c - cmin) + co][dy][dx] = W_c[co][base_g + r][2-dy][2-dx],   base_0 = 0, base_g = 96 + 32 (g - 1).
-struct GatherSrc { const float* w[4]; };
+//   General block (G0, C, G): rows = G0 (group 0) or G, K = (C - group) G stacked output gradients, base_g = G0 + G (g - 1).
+struct GatherSrc { const float* w[BINHIP_RDN_MAX_CONVS + 1]; int G0, G; };
 __device__ __forceinline__ void relayout_rdb_gather_body(long long t, const GatherSrc& src, int group, int rows, int nchunks,
                                                          int cb, _Float16* __restrict__ w_hi, _Float16* __restrict__ w_lo,
                                                          float* __restrict__ bias_out) {
@@ -599,16 +600,17 @@ __device__ __forceinline__ void relayout_rdb_gather_body(long long t, const Gath
     const int r = (int)u * cb + row;
     const int cg = s ^ ((row >> 3) & 1);
     const int dy = 2 - tap / 3, dx = 2 - tap % 3;
+    const int G0 = src.G0, G = src.G;
     const int cmin = group;                            // group 0 and group 1.. both start at conv index == group
-    const int ci = (group == 0) ? r : 96 + 32 * (group - 1) + r;
-    const int j0 = c * 16 + cg * 8;                    // 8 consecutive K entries never straddle a conv (32 each)
-    const int conv = cmin + j0 / 32;
-    const int cin_c = 96 + 32 * conv;
+    const int ci = (group == 0) ? r : G0 + G * (group - 1) + r;
+    const int j0 = c * 16 + cg * 8;                    // 8 consecutive K entries never straddle a conv (G is a multiple of 32)
+    const int conv = cmin + j0 / G;
+    const int cin_c = G0 + G * conv;
     const float* w = src.w[conv];
     half8 hv, lv;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const int co = (j0 & 31) + e;
+        const int co = (j0 % G) + e;
         const float v = w[(((long long)co * cin_c + ci) * 3 + dy) * 3 + dx];
         hv[e] = (_Float16)v;
         lv[e] = (_Float16)(v - (float)hv[e]);
@@ -625,7 +627,7 @@ __global__ void relayout_rdb_gather_kernel(GatherSrc src, int group, int rows, i
 // ---- batched relayout: a training step re-lays-out every weight of a set after each optimizer update (66 forward + 66
 // backward layouts per set); one launch per <= RELAYOUT_BATCH layers instead of one per layer (round 3: 528 -> 24 launches
 // per step of ~4.5 us each).  Block b of the grid belongs to the item whose block range contains it.
-#define RELAYOUT_BATCH 24
+#define RELAYOUT_BATCH 22
 struct RelayoutBatch {
     BinRelayoutItem it[RELAYOUT_BATCH];
     unsigned start[RELAYOUT_BATCH + 1];
@@ -649,7 +651,9 @@ relayout_batch_kernel(const RelayoutBatch rb) {
     } else {
         GatherSrc src;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) src.w[i] = L.w[i];
+        for (int i = 0; i <= BINHIP_RDN_MAX_CONVS; ++i) src.w[i] = L.w[i];
+        src.G0 = L.shape.G0 > 0 ? L.shape.G0 : 96;
+        src.G = L.shape.G > 0 ? L.shape.G : 32;
         relayout_rdb_gather_body(t, src, L.shuffle_or_group, L.rows_pad, L.cin_chunks, L.cout_block, (_Float16*)L.w_hi,
                                  (_Float16*)L.w_lo, L.bias_out);
     }
@@ -672,10 +676,12 @@ int binhip_weights_relayout_batch(const BinRelayoutItem* items, int n, void* str
             if (L.shuffle_or_group && L.cout % 4) return BINHIP_E_SHAPE;
         } else if (L.kind == BINHIP_RELAYOUT_RDB_GATHER) {
             const int g = L.shuffle_or_group;
-            if (g < 0 || g > 3) return BINHIP_E_ARG;
-            if (L.rows_pad != (g == 0 ? 96 : 32) || L.cin_chunks != 2 * (4 - g) || L.ksize != 3) return BINHIP_E_SHAPE;
+            const int G0 = L.shape.G0 > 0 ? L.shape.G0 : 96, G = L.shape.G > 0 ? L.shape.G : 32, C = L.shape.C > 0 ? L.shape.C : 4;
+            if (C > BINHIP_RDN_MAX_CONVS || G0 % 32 || G % 32) return BINHIP_E_SHAPE;
+            if (g < 0 || g >= C) return BINHIP_E_ARG;
+            if (L.rows_pad != (g == 0 ? G0 : G) || L.cin_chunks != (C - g) * G / 16 || L.ksize != 3) return BINHIP_E_SHAPE;
             if (L.cout_block <= 0 || L.rows_pad % L.cout_block || L.cout_block % 32) return BINHIP_E_SHAPE;
-            for (int k = g; k < 4; ++k) if (!L.w[k]) return BINHIP_E_ARG;
+            for (int k = g; k < C; ++k) if (!L.w[k]) return BINHIP_E_ARG;
         } else {
             return BINHIP_E_ARG;
         }
@@ -728,6 +734,8 @@ int binhip_weights_relayout_rdb_gather(const float* const* w_oihw4, int group, i
     const int nchunks = 2 * (4 - group);
     if (cout_block <= 0 || rows % cout_block || cout_block % 32) return BINHIP_E_SHAPE;
     GatherSrc src;
+    for (int i = 0; i <= BINHIP_RDN_MAX_CONVS; ++i) src.w[i] = nullptr;
+    src.G0 = 96; src.G = 32;
     for (int i = 0; i < 4; ++i) {
         src.w[i] = w_oihw4[i];
         if (i >= group && !src.w[i]) return BINHIP_E_ARG;

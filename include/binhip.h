@@ -58,7 +58,14 @@ extern "C" {
 #define BINHIP_EPI_SHUFFLE 1     /* conv + b -> PixelShuffle(2) -> chunk planes at 2H x 2W       */
 #define BINHIP_EPI_FINAL   2     /* conv + b + mean(images) -> fp32 NCHW [N,cout,H,W]            */
 
-#define BINHIP_RDN_LAYERS 66     /* SFE1, SFE2, 12 x (4 conv + LFF), GFF.0, GFF.1, UP.0, UP.2    */
+#define BINHIP_RDN_LAYERS 66     /* bin_stage4: SFE1, SFE2, 12 x (4 conv + LFF), GFF.0, GFF.1, UP.0, UP.2 */
+/* Shape of an RDN sub-network (constructor arguments of RDN.py:168-186): G0 feature channels, D residual dense blocks of
+ * C 3x3 convs growing by G channels each.  All zero = bin_stage4's (96, 12, 4, 32).  Supported: G0 and G multiples of 32,
+ * 32 <= G0 <= 256, G <= 128, 1 <= C <= 7, 1 <= D <= 20.  Layer order / index: SFENet1 = 0, SFENet2 = 1, conv c of block d =
+ * 2 + d (C + 1) + c, LFF of block d = 2 + d (C + 1) + C, then GFF.0, GFF.1, UPNet.0, UPNet.2; 2 + D (C + 1) + 4 layers.    */
+typedef struct BinRdnShape { int32_t G0, D, C, G; } BinRdnShape;
+#define BINHIP_RDN_MAX_LAYERS 192
+#define BINHIP_RDN_MAX_CONVS 7
 
 BINHIP_API int binhip_version(void);
 
@@ -98,19 +105,21 @@ BINHIP_API size_t binhip_weights_bytes(int cout_pad, int cin_chunks, int ksize);
 /* Several relayouts per launch (a training step re-lays-out all 66 layers of a weight set twice, forward and backward
  * layouts, after every optimizer update).  One item = the arguments of binhip_weights_relayout (kind FWD: rows_pad =
  * cout_pad, shuffle_or_group = shuffle_perm), of binhip_weights_relayout_dgrad (kind DGRAD) or of
- * binhip_weights_relayout_rdb_gather (kind RDB_GATHER: w[0..3] = the block's four conv weights, shuffle_or_group = group,
- * rows_pad = 96 / 32, cin_chunks = 2 (4 - group), ksize = 3; bias is ignored, bias_out zeroed) — same results bit for bit.
+ * binhip_weights_relayout_rdb_gather (kind RDB_GATHER: w[0..C-1] = the block's conv weights, shuffle_or_group = group,
+ * rows_pad = G0 (group 0) / G, cin_chunks = (C - group) G / 16, ksize = 3; bias is ignored, bias_out zeroed; `shape` gives
+ * G0, C, G for blocks other than bin_stage4's) — same results bit for bit.
  * `items` is a HOST array; nothing of it is referenced after the call returns.                                        */
 #define BINHIP_RELAYOUT_FWD        0
 #define BINHIP_RELAYOUT_DGRAD      1
 #define BINHIP_RELAYOUT_RDB_GATHER 2
 typedef struct BinRelayoutItem {
-    const float* w[4];        /* OIHW fp32 sources (w[0] only, except RDB_GATHER)                     */
+    const float* w[BINHIP_RDN_MAX_CONVS + 1]; /* OIHW fp32 sources (w[0] only, except RDB_GATHER: the block's C convs) */
     const float* bias;        /* FWD: bias or NULL                                                   */
     void* w_hi;
     void* w_lo;               /* NULL when nterms == 1                                               */
     float* bias_out;          /* rows_pad floats                                                     */
     int32_t kind, cout, cin, ksize, rows_pad, cin_chunks, cout_block, shuffle_or_group;
+    BinRdnShape shape;        /* RDB_GATHER only: the dense block's (G0, -, C, G); all zero = (96, -, 4, 32)        */
 } BinRelayoutItem;
 BINHIP_API int binhip_weights_relayout_batch(const BinRelayoutItem* items, int n, void* stream);
 
@@ -222,23 +231,28 @@ typedef struct BinRdnPlan {
     int32_t n_inputs;         /* 2, 3 or 5 input frames                                          */
     int32_t nterms;           /* 1 or 3                                                          */
     int32_t reserved;         /* BINHIP_PLAN_* flags                                             */
-    const void* w_hi[BINHIP_RDN_LAYERS];   /* relayouted weights per layer                       */
-    const void* w_lo[BINHIP_RDN_LAYERS];   /* NULL when nterms == 1                              */
-    const float* bias[BINHIP_RDN_LAYERS];
+    BinRdnShape shape;        /* all zero = bin_stage4 (96, 12, 4, 32)                            */
+    const void* w_hi[BINHIP_RDN_MAX_LAYERS];   /* relayouted weights per layer (first 2 + D (C + 1) + 4 used) */
+    const void* w_lo[BINHIP_RDN_MAX_LAYERS];   /* NULL when nterms == 1                          */
+    const float* bias[BINHIP_RDN_MAX_LAYERS];
     void* status;                          /* device uint32 status word (BINHIP_STATUS_*) or NULL */
     struct BinhipProfiler* profiler;       /* optional live kernel timing (below) or NULL         */
 } BinRdnPlan;
+/* The fused dense-block tail and the three-phase launch exist for the bin_stage4 shape only; other shapes run conv C-1 and
+ * the LFF as two launches (what BINHIP_PLAN_NO_FUSE does for bin_stage4) — same values.                                 */
 
-BINHIP_API size_t binhip_rdn_workspace_bytes(int N, int H, int W, int n_inputs, int nterms);
+BINHIP_API size_t binhip_rdn_workspace_bytes(int N, int H, int W, int n_inputs, int nterms, const BinRdnShape* shape /* NULL = bin_stage4 */);
 /* Where the activations of a call live inside its workspace (the caller owns it, and with BINHIP_PLAN_KEEP_ACTS it is
  * the saved state of the call): fp16-ELEMENT offsets from the workspace pointer rounded up to 256 B.  A tensor's hi
  * planes start at its offset, its lo planes (nterms == 3) at offset + size.  out[0..15] =
  *   P (elements of one half-resolution plane: N*H/2*W/2*16), PF (full resolution), kc0 (chunks of the packed input),
- *   x0, size | f1, size | blk, size (13 blocks x 14 planes: block d input = planes [14d, 14d+6), conv c output =
- *   planes 14d + 6 + 2c, + 7 + 2c) | g0, size | g1, size | u, size (4 full-resolution planes) | has_lo.
+ *   x0, size | f1, size | blk, size (D + 1 blocks x B planes, B = (G0 + C G) / 16: block d input = planes [B d, B d + G0/16),
+ *   conv c output = the G/16 planes from B d + (G0 + c G) / 16; bin_stage4: 13 x 14, conv c at 14d + 6 + 2c) | g0, size |
+ *   g1, size | u, size (4 full-resolution planes) | has_lo.
  * Used by tools/fp16_headroom.py and the GPU tests to measure the stored dynamic range; no device work.            */
 #define BINHIP_RDN_LAYOUT_WORDS 16
-BINHIP_API int binhip_rdn_workspace_layout(int N, int H, int W, int n_inputs, int nterms, int64_t* out, int n_out);
+BINHIP_API int binhip_rdn_workspace_layout(int N, int H, int W, int n_inputs, int nterms, const BinRdnShape* shape,
+                                int64_t* out, int n_out);
 BINHIP_API int binhip_rdn_forward(const BinRdnPlan* plan, const float* const* inputs /* host array of
                        n_inputs device ptrs, fp32 [N,3,H,W] */, float* out /* fp32 [N,3,H,W] */,
                        void* workspace, size_t workspace_bytes, void* stream);
@@ -291,12 +305,13 @@ BINHIP_API int binhip_convlstm_bwd(const float* x, const float* c_prev, const fl
                                    * gradient error); wt_* are then the nterms = 1 backward-data weights              */
 typedef struct BinRdnBwdPlan {
     int32_t N, H, W, n_inputs, nterms, reserved;   /* reserved = flags (BINHIP_BWD_*)                     */
-    const void* wt_hi[BINHIP_RDN_LAYERS];   /* binhip_weights_relayout_dgrad outputs; for the slots   */
-                                            /* RDBs.d.convs.g: binhip_weights_relayout_rdb_gather(g)   */
-    const void* wt_lo[BINHIP_RDN_LAYERS];
-    const float* zero_bias;                 /* >= 1152 zero floats                                    */
-    float* dw[BINHIP_RDN_LAYERS];
-    float* db[BINHIP_RDN_LAYERS];
+    BinRdnShape shape;                      /* all zero = bin_stage4                                  */
+    const void* wt_hi[BINHIP_RDN_MAX_LAYERS];   /* binhip_weights_relayout_dgrad outputs; for the slots */
+                                            /* RDBs.d.convs.g: the gather-form weights of group g      */
+    const void* wt_lo[BINHIP_RDN_MAX_LAYERS];
+    const float* zero_bias;                 /* >= max(D G0, G0 + C G, 256) zero floats (bin_stage4: 1152) */
+    float* dw[BINHIP_RDN_MAX_LAYERS];
+    float* db[BINHIP_RDN_MAX_LAYERS];
     float* gin[5];
     void* status;                           /* device uint32 status word (BINHIP_STATUS_*) or NULL     */
     void* aux_stream;                       /* optional second hipStream_t: the weight-gradient kernels run on it,  */
@@ -305,15 +320,17 @@ typedef struct BinRdnBwdPlan {
     struct BinhipProfiler* profiler;        /* optional live timing of the weight-gradient launches (epilogue class  */
                                             /* BINHIP_PROF_WGRAD) or NULL                                            */
 } BinRdnBwdPlan;
-BINHIP_API size_t binhip_rdn_backward_workspace_bytes(int N, int H, int W, int n_inputs, int nterms);
+BINHIP_API size_t binhip_rdn_backward_workspace_bytes(int N, int H, int W, int n_inputs, int nterms, const BinRdnShape* shape);
 /* Gradient planes inside the backward workspace after a call (same conventions as binhip_rdn_workspace_layout; all
  * stored multiplied by the call's power-of-two scale).  out[0..23] = P, PF, gx0_chunks,
  *   gout, size (1 full-res plane) | gu, size (4 full-res) | guu, size (16) | gg1, size | gg0, size | gf1, size (6 each) |
- *   gy, size (13 x 6: gradient of SFENet2's output and of every dense block's output) | gcat, size | gcat2, size (14 each:
- *   gradient-concat buffers of the last even / odd dense block processed) | gx0, size | byte offset of the float pair
+ *   gy, size ((D + 1) x G0/16: gradient of SFENet2's output and of every dense block's output) | gcat, size | gcat2, size
+ *   ((G0 + C G)/16 planes each: gradient-concat buffers of the last even / odd dense block processed; gg1, gg0, gf1 have
+ *   G0/16 planes) | gx0, size | byte offset of the float pair
  *   {scale, 1/scale}.                                                                                                */
 #define BINHIP_RDN_BWD_LAYOUT_WORDS 24
-BINHIP_API int binhip_rdn_backward_workspace_layout(int N, int H, int W, int n_inputs, int nterms, int64_t* out, int n_out);
+BINHIP_API int binhip_rdn_backward_workspace_layout(int N, int H, int W, int n_inputs, int nterms, const BinRdnShape* shape,
+                                         int64_t* out, int n_out);
 BINHIP_API int binhip_rdn_backward(const BinRdnBwdPlan* plan, const void* saved, size_t saved_bytes,
                         const float* gout, void* workspace, size_t workspace_bytes, void* stream);
 
