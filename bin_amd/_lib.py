@@ -5,7 +5,8 @@ import os
 
 from .build import LIB_PATH
 
-RDN_LAYERS = 66
+RDN_LAYERS = 66              # bin_stage4's layer count; BinRdnPlan arrays hold RDN_MAX_LAYERS
+RDN_MAX_LAYERS, RDN_MAX_CONVS = 192, 7
 PLAN_KEEP_ACTS, PLAN_NO_FUSE, PLAN_RDB3 = 1, 2, 4
 BWD_ACCUMULATE = 1          # BinRdnBwdPlan.reserved flag (BINHIP_BWD_ACCUMULATE)
 BWD_SAVED_X3 = 2            # BINHIP_BWD_SAVED_X3
@@ -23,27 +24,32 @@ class BinConvDesc(C.Structure):
                 ("reserved", C.c_int32), ("status", C.c_void_p)]
 
 
+class BinRdnShape(C.Structure):
+    """(G0, D, C, G) of an RDN sub-network (include/binhip.h); all zero = bin_stage4's (96, 12, 4, 32)."""
+    _fields_ = [("G0", C.c_int32), ("D", C.c_int32), ("C", C.c_int32), ("G", C.c_int32)]
+
+
 class BinRdnPlan(C.Structure):
     _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("n_inputs", C.c_int32),
-                ("nterms", C.c_int32), ("reserved", C.c_int32),
-                ("w_hi", C.c_void_p * RDN_LAYERS), ("w_lo", C.c_void_p * RDN_LAYERS),
-                ("bias", C.c_void_p * RDN_LAYERS), ("status", C.c_void_p), ("profiler", C.c_void_p)]
+                ("nterms", C.c_int32), ("reserved", C.c_int32), ("shape", BinRdnShape),
+                ("w_hi", C.c_void_p * RDN_MAX_LAYERS), ("w_lo", C.c_void_p * RDN_MAX_LAYERS),
+                ("bias", C.c_void_p * RDN_MAX_LAYERS), ("status", C.c_void_p), ("profiler", C.c_void_p)]
 
 
 class BinRdnBwdPlan(C.Structure):
     _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("n_inputs", C.c_int32),
-                ("nterms", C.c_int32), ("reserved", C.c_int32),
-                ("wt_hi", C.c_void_p * RDN_LAYERS), ("wt_lo", C.c_void_p * RDN_LAYERS),
+                ("nterms", C.c_int32), ("reserved", C.c_int32), ("shape", BinRdnShape),
+                ("wt_hi", C.c_void_p * RDN_MAX_LAYERS), ("wt_lo", C.c_void_p * RDN_MAX_LAYERS),
                 ("zero_bias", C.c_void_p),
-                ("dw", C.c_void_p * RDN_LAYERS), ("db", C.c_void_p * RDN_LAYERS), ("gin", C.c_void_p * 5),
+                ("dw", C.c_void_p * RDN_MAX_LAYERS), ("db", C.c_void_p * RDN_MAX_LAYERS), ("gin", C.c_void_p * 5),
                 ("status", C.c_void_p), ("aux_stream", C.c_void_p), ("profiler", C.c_void_p)]
 
 
 class BinRelayoutItem(C.Structure):
-    _fields_ = [("w", C.c_void_p * 4), ("bias", C.c_void_p), ("w_hi", C.c_void_p), ("w_lo", C.c_void_p),
+    _fields_ = [("w", C.c_void_p * (RDN_MAX_CONVS + 1)), ("bias", C.c_void_p), ("w_hi", C.c_void_p), ("w_lo", C.c_void_p),
                 ("bias_out", C.c_void_p), ("kind", C.c_int32), ("cout", C.c_int32), ("cin", C.c_int32),
                 ("ksize", C.c_int32), ("rows_pad", C.c_int32), ("cin_chunks", C.c_int32), ("cout_block", C.c_int32),
-                ("shuffle_or_group", C.c_int32)]
+                ("shuffle_or_group", C.c_int32), ("shape", BinRdnShape)]
 
 
 RELAYOUT_FWD, RELAYOUT_DGRAD, RELAYOUT_RDB_GATHER = 0, 1, 2
@@ -102,7 +108,7 @@ _SIGNATURES = {
     "binhip_convlstm_bwd_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "binhip_convlstm_bwd": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_size_t] + [C.c_void_p] * 6),
-    "binhip_rdn_backward_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
+    "binhip_rdn_backward_workspace_bytes": (C.c_size_t, [C.c_int] * 5 + [C.POINTER(BinRdnShape)]),
     "binhip_rdn_backward": (C.c_int, [C.POINTER(BinRdnBwdPlan), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                       C.c_size_t, C.c_void_p]),
     "binhip_profiler_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
@@ -110,9 +116,9 @@ _SIGNATURES = {
     "binhip_profiler_destroy": (None, [C.c_void_p]),
     "binhip_rdb_tail_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 10 +
                             [C.c_int, C.c_void_p, C.c_void_p]),
-    "binhip_rdn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
-    "binhip_rdn_workspace_layout": (C.c_int, [C.c_int] * 5 + [C.POINTER(C.c_int64), C.c_int]),
-    "binhip_rdn_backward_workspace_layout": (C.c_int, [C.c_int] * 5 + [C.POINTER(C.c_int64), C.c_int]),
+    "binhip_rdn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(BinRdnShape)]),
+    "binhip_rdn_workspace_layout": (C.c_int, [C.c_int] * 5 + [C.POINTER(BinRdnShape), C.POINTER(C.c_int64), C.c_int]),
+    "binhip_rdn_backward_workspace_layout": (C.c_int, [C.c_int] * 5 + [C.POINTER(BinRdnShape), C.POINTER(C.c_int64), C.c_int]),
     "binhip_rdn_forward": (C.c_int, [C.POINTER(BinRdnPlan), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p,
                                      C.c_size_t, C.c_void_p]),
 }

@@ -20,7 +20,7 @@ import torch
 
 from . import _lib as L
 from .ops import _ptr, _stream, on_device, status_word
-from .rdn_plan import layer_names, rdn_forward, workspace
+from .rdn_plan import c_shape, layer_names, rdn_forward, workspace
 
 
 # Per-module switches (attributes of the RDN sub-network objects, models/archs/RDN.py::_RDNBase — nothing here is a mutable
@@ -70,13 +70,13 @@ class _RdnFn(torch.autograd.Function):
         weights = module.kernel_weights(nterms)
         n, _, h, w = frames[0].shape
         lib = L.lib()
-        nbytes = lib.binhip_rdn_workspace_bytes(n, h, w, n_frames, nterms)
+        nbytes = lib.binhip_rdn_workspace_bytes(n, h, w, n_frames, nterms, C.byref(c_shape(weights.shape)))
         if nbytes == 0:
             raise RuntimeError(f"bin_amd: unsupported RDN shape N={n} H={h} W={w}")
         saved = torch.empty(nbytes, dtype=torch.uint8, device=frames[0].device)
         out = rdn_forward(weights, frames, ws=saved, flags=module.plan_flags | L.PLAN_KEEP_ACTS, profiler=module.profiler)
         if module.debug_hook is not None:
-            module.debug_hook("forward", module, (n, h, w, n_frames, nterms), saved, {})
+            module.debug_hook("forward", module, (n, h, w, n_frames, nterms), saved, {"shape": module.shape})
         ctx.module, ctx.nterms, ctx.n_frames = module, nterms, n_frames
         ctx.saved_ws = saved
         ctx.dims = (n, h, w)
@@ -129,7 +129,7 @@ class _RdnFn(torch.autograd.Function):
             plan.reserved |= L.BWD_ACCUMULATE
         else:
             grads = [torch.empty(shape, dtype=torch.float32, device=dev) for shape, _ in ctx.param_meta]
-        for i in range(L.RDN_LAYERS):
+        for i in range(len(grads) // 2):
             plan.dw[i] = grads[2 * i].data_ptr()
             plan.db[i] = grads[2 * i + 1].data_ptr()
         gins = []
@@ -141,13 +141,14 @@ class _RdnFn(torch.autograd.Function):
             else:
                 plan.gin[i] = None
                 gins.append(None)
-        nbytes = lib.binhip_rdn_backward_workspace_bytes(n, h, w, k, nt_bwd)
+        nbytes = lib.binhip_rdn_backward_workspace_bytes(n, h, w, k, nt_bwd, C.byref(plan.shape))
         ws = workspace(nbytes, dev, key="bwd")
         with on_device(gout):
             L.check(lib.binhip_rdn_backward(C.byref(plan), _ptr(ctx.saved_ws), ctx.saved_ws.numel(), _ptr(gout),
                                             _ptr(ws), ws.numel(), _stream()), "rdn_backward")
         if module.debug_hook is not None:          # tools/fp16_headroom.py, tests: inspect the planes of this call
-            module.debug_hook("backward", module, (n, h, w, k, nt_bwd), ws, {"input_grads": any(g is not None for g in gins)})
+            module.debug_hook("backward", module, (n, h, w, k, nt_bwd), ws, {"input_grads": any(g is not None for g in gins),
+                                                                              "shape": module.shape})
         ctx.saved_ws = None
         module._bwd_pending = getattr(module, "_bwd_pending", 1) - 1
         if module._bwd_pending == 0 and direct:
@@ -168,7 +169,7 @@ def rdn_apply(module, frames):
     nterms = train_precision(module)
     params = dict(module.named_parameters())
     flat = []
-    for nm in layer_names():
+    for nm in layer_names(module.shape):
         flat += [params[nm + ".weight"], params[nm + ".bias"]]
     return _RdnFn.apply(module, nterms, len(frames), *frames, *flat)
 

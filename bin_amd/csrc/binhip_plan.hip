@@ -9,21 +9,45 @@
 //                   BLK[d][6+2c : 8+2c] = output of conv c of RDB d  -> "cat" is free
 //   G0,G1 [6]       GFF.0 / GFF.1(+f__1)
 //   U    [4]        UPNet.0 output after PixelShuffle, full resolution
+// (numbers for bin_stage4's shape G0 = 96, D = 12, C = 4, G = 32; in general c0 = G0/16 planes per feature map, cg = G/16
+//  per conv output, BLK [D + 1][c0 + C cg], layer index 2 + d (C + 1) + c — include/binhip.h, BinRdnShape)
 #include "binhip_conv_common.h"
 
 namespace {
+
+// resolved network shape (BinRdnShape with the defaults filled in)
+struct Shp {
+    int G0, D, C, G;
+    int c0, cg, cb;       // planes per feature map / per conv output / per dense-block buffer
+    int L;                // layers
+    bool stage4;          // bin_stage4's shape: the fused tail / three-phase kernels exist for it
+};
+bool resolve_shape(const BinRdnShape* s, Shp* o) {
+    Shp h;
+    const bool dflt = !s || (s->G0 == 0 && s->D == 0 && s->C == 0 && s->G == 0);
+    h.G0 = dflt ? 96 : s->G0; h.D = dflt ? 12 : s->D; h.C = dflt ? 4 : s->C; h.G = dflt ? 32 : s->G;
+    if (h.G0 < 32 || h.G0 > 256 || h.G0 % 32 || h.G < 32 || h.G > 128 || h.G % 32) return false;
+    if (h.C < 1 || h.C > BINHIP_RDN_MAX_CONVS || h.D < 1 || h.D > 20) return false;
+    h.c0 = h.G0 / 16; h.cg = h.G / 16; h.cb = h.c0 + h.C * h.cg;
+    h.L = 2 + h.D * (h.C + 1) + 4;
+    if (h.L > BINHIP_RDN_MAX_LAYERS) return false;
+    h.stage4 = (h.G0 == 96 && h.C == 4 && h.G == 32);
+    *o = h;
+    return true;
+}
+inline int layer_conv(const Shp& sh, int d, int c) { return 2 + d * (sh.C + 1) + c; }      // c == C: the block's LFF
 
 struct Ws {
     int64_t P, PF;        // plane elems at half / full res
     int kc0;
     int64_t x0, f1, blk, g0, g1, u, total;   // element offsets of the hi part
-    int64_t sync;                            // element offset of the dense-block sync words (12 counters + 2 T flags, uint32)
+    int64_t sync;                            // element offset of the dense-block sync words (32 counters + 2 T flags, uint32)
     int tiles;                               // 16x32 tiles of one dense-block conv launch
     int64_t s_x0, s_f1, s_blk, s_g, s_u;     // sizes (elements) of each tensor's hi part
     int nt;
 };
 
-Ws make_ws(int N, int H, int W, int nin, int nt) {
+Ws make_ws(int N, int H, int W, int nin, int nt, const Shp& sh) {
     Ws w;
     const int h = H / 2, ww = W / 2;
     w.P = (int64_t)N * h * ww * 16;
@@ -31,7 +55,8 @@ Ws make_ws(int N, int H, int W, int nin, int nt) {
     w.kc0 = (12 * nin + 15) / 16;
     w.nt = nt;
     const int mul = (nt == 3) ? 2 : 1;
-    w.s_x0 = w.kc0 * w.P; w.s_f1 = 6 * w.P; w.s_blk = (int64_t)13 * 14 * w.P; w.s_g = 6 * w.P; w.s_u = 4 * w.PF;
+    w.s_x0 = w.kc0 * w.P; w.s_f1 = sh.c0 * w.P; w.s_blk = (int64_t)(sh.D + 1) * sh.cb * w.P; w.s_g = sh.c0 * w.P;
+    w.s_u = 4 * w.PF;
     int64_t o = 0;
     w.x0 = o; o += mul * w.s_x0;
     w.f1 = o; o += mul * w.s_f1;
@@ -39,11 +64,11 @@ Ws make_ws(int N, int H, int W, int nin, int nt) {
     w.g0 = o; o += mul * w.s_g;
     w.g1 = o; o += mul * w.s_g;
     w.u = o; o += mul * w.s_u;
-    // sync words of the three-phase dense-block launches (binhip_conv_x3.hip): 16 counters (12 used, one per block) + two
+    // sync words of the three-phase dense-block launches (binhip_conv_x3.hip): 32 counters (one per block) + two
     // flag words per tile; 4-byte words kept in the fp16-element address space (2 elements each), 256-B aligned
     w.tiles = N * ((h + 15) / 16) * ((ww + 31) / 32);
     o = (o + 127) & ~(int64_t)127;
-    w.sync = o; o += 2 * (16 + 2 * (int64_t)w.tiles);
+    w.sync = o; o += 2 * (32 + 2 * (int64_t)w.tiles);
     w.total = o;
     return w;
 }
@@ -52,16 +77,20 @@ Ws make_ws(int N, int H, int W, int nin, int nt) {
 
 extern "C" {
 
-size_t binhip_rdn_workspace_bytes(int N, int H, int W, int n_inputs, int nterms) {
+size_t binhip_rdn_workspace_bytes(int N, int H, int W, int n_inputs, int nterms, const BinRdnShape* shape) {
     if (N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return 0;
     if (n_inputs != 2 && n_inputs != 3 && n_inputs != 5) return 0;
-    return (size_t)make_ws(N, H, W, n_inputs, nterms).total * 2 + 256;
+    Shp sh;
+    if (!resolve_shape(shape, &sh)) return 0;
+    return (size_t)make_ws(N, H, W, n_inputs, nterms, sh).total * 2 + 256;
 }
 
-int binhip_rdn_workspace_layout(int N, int H, int W, int n_inputs, int nterms, int64_t* out, int n_out) {
+int binhip_rdn_workspace_layout(int N, int H, int W, int n_inputs, int nterms, const BinRdnShape* shape, int64_t* out,
+                                int n_out) {
     if (!out || n_out < BINHIP_RDN_LAYOUT_WORDS) return BINHIP_E_ARG;
-    if (binhip_rdn_workspace_bytes(N, H, W, n_inputs, nterms) == 0) return BINHIP_E_SHAPE;
-    const Ws w = make_ws(N, H, W, n_inputs, nterms);
+    Shp sh;
+    if (!resolve_shape(shape, &sh) || binhip_rdn_workspace_bytes(N, H, W, n_inputs, nterms, shape) == 0) return BINHIP_E_SHAPE;
+    const Ws w = make_ws(N, H, W, n_inputs, nterms, sh);
     const int64_t v[BINHIP_RDN_LAYOUT_WORDS] = {w.P, w.PF, w.kc0, w.x0, w.s_x0, w.f1, w.s_f1, w.blk, w.s_blk,
                                                  w.g0, w.s_g, w.g1, w.s_g, w.u, w.s_u, nterms == 3 ? 1 : 0};
     for (int i = 0; i < BINHIP_RDN_LAYOUT_WORDS; ++i) out[i] = v[i];
@@ -75,14 +104,16 @@ int binhip_rdn_forward(const BinRdnPlan* p, const float* const* inputs, float* o
     if (N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return BINHIP_E_SHAPE;
     if (nin != 2 && nin != 3 && nin != 5) return BINHIP_E_SHAPE;
     if (nt != 1 && nt != 3) return BINHIP_E_ARG;
-    const size_t need = binhip_rdn_workspace_bytes(N, H, W, nin, nt);
+    Shp sh;
+    if (!resolve_shape(&p->shape, &sh)) return BINHIP_E_SHAPE;
+    const size_t need = binhip_rdn_workspace_bytes(N, H, W, nin, nt, &p->shape);
     if (workspace_bytes < need) return BINHIP_E_WORKSPACE;
     for (int i = 0; i < nin; ++i) if (!inputs[i]) return BINHIP_E_ARG;
-    for (int i = 0; i < BINHIP_RDN_LAYERS; ++i)
+    for (int i = 0; i < sh.L; ++i)
         if (!p->w_hi[i] || !p->bias[i] || (nt == 3 && !p->w_lo[i])) return BINHIP_E_ARG;
 
     hipStream_t s = (hipStream_t)stream;
-    const Ws w = make_ws(N, H, W, nin, nt);
+    const Ws w = make_ws(N, H, W, nin, nt, sh);
     const int h = H / 2, ww = W / 2;
     // align the workspace base to 256 B
     _Float16* base = (_Float16*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
@@ -125,60 +156,62 @@ int binhip_rdn_forward(const BinRdnPlan* p, const float* const* inputs, float* o
     // three-phase dense-block launches (BINHIP_PLAN_RDB3, opt-in, fp32-class path): one memset per call zeroes the 12
     // work-queue heads and the per-tile flags (block d publishes the value d + 1, so the blocks of one call never confuse
     // each other's flags; the memset only removes what an earlier call or uninitialised memory left behind)
-    const bool rdb3 = (p->reserved & BINHIP_PLAN_RDB3) && nt == 3;
+    const bool rdb3 = (p->reserved & BINHIP_PLAN_RDB3) && nt == 3 && sh.stage4;
     unsigned* sync_words = (unsigned*)(base + w.sync);
     const int cus = binhip_device_cus();
     if (rdb3) {
-        hipError_t me = hipMemsetAsync(sync_words, 0, (size_t)(16 + 2 * (size_t)w.tiles) * 4, s);
+        hipError_t me = hipMemsetAsync(sync_words, 0, (size_t)(32 + 2 * (size_t)w.tiles) * 4, s);
         if (me != hipSuccess) return (int)me;
     }
     const int P_ = BINHIP_EPI_PLANES;
     const int64_t P = w.P;
+    const int G0 = sh.G0, G = sh.G, C = sh.C, D = sh.D, c0 = sh.c0, cg = sh.cg, cb = sh.cb;
     // SFENet1 5x5 (RDN.py:187/245/299) and SFENet2 3x3 (:188)
-    if ((rc = conv(0, 5, w.kc0, 96, 96, P_, 0, h, ww, w.x0, w.s_x0, 0, 0, w.f1, w.s_f1, -1, 0))) return rc;
-    if ((rc = conv(1, 3, 6, 96, 96, P_, 0, h, ww, w.f1, w.s_f1, 0, 0, w.blk, w.s_blk, -1, 0))) return rc;
-    // 12 residual dense blocks (RDN.py:149-165)
-    for (int d = 0; d < 12; ++d) {
-        const int64_t b = w.blk + (int64_t)d * 14 * P;
-        const bool fuse = !(p->reserved & BINHIP_PLAN_NO_FUSE);
+    if ((rc = conv(0, 5, w.kc0, G0, G0, P_, 0, h, ww, w.x0, w.s_x0, 0, 0, w.f1, w.s_f1, -1, 0))) return rc;
+    if ((rc = conv(1, 3, c0, G0, G0, P_, 0, h, ww, w.f1, w.s_f1, 0, 0, w.blk, w.s_blk, -1, 0))) return rc;
+    // D residual dense blocks (RDN.py:149-165)
+    for (int d = 0; d < D; ++d) {
+        const int64_t b = w.blk + (int64_t)d * cb * P;
+        const bool fuse = sh.stage4 && !(p->reserved & BINHIP_PLAN_NO_FUSE);
         bool done3 = false;
         if (rdb3 && fuse) {
             // convs 0-2 as three phases of one launch (work queue + neighbour flags instead of two kernel boundaries)
             ConvKArgs ka[3];
             bool ok3 = true;
             for (int c = 0; c < 3 && ok3; ++c) {
-                BhConvCall cc = mk(2 + 5 * d + c, 3, 6 + 2 * c, 32, 32, P_, 1, h, ww, b, w.s_blk, 0, 0,
-                                   b + (int64_t)(6 + 2 * c) * P, w.s_blk, -1, 0);
+                BhConvCall cc = mk(layer_conv(sh, d, c), 3, c0 + cg * c, G, G, P_, 1, h, ww, b, w.s_blk, 0, 0,
+                                   b + (int64_t)(c0 + cg * c) * P, w.s_blk, -1, 0);
                 if ((rc = bh_prepare_conv(cc, &ka[c]))) return rc;
                 ok3 = ok3 && ka[c].wt;
             }
             if (ok3) {
-                if ((rc = bh_launch_rdb3_x3(ka, sync_words + d, sync_words + 16, (unsigned)(d + 1), cus, s))) return rc;
+                if ((rc = bh_launch_rdb3_x3(ka, sync_words + d, sync_words + 32, (unsigned)(d + 1), cus, s))) return rc;
                 done3 = true;
             }
         }
-        for (int c = 0; c < (fuse ? 3 : 4) && !done3; ++c) {
-            if ((rc = conv(2 + 5 * d + c, 3, 6 + 2 * c, 32, 32, P_, 1, h, ww, b, w.s_blk, 0, 0,
-                           b + (int64_t)(6 + 2 * c) * P, w.s_blk, -1, 0))) return rc;
+        for (int c = 0; c < (fuse ? C - 1 : C) && !done3; ++c) {
+            if ((rc = conv(layer_conv(sh, d, c), 3, c0 + cg * c, G, G, P_, 1, h, ww, b, w.s_blk, 0, 0,
+                           b + (int64_t)(c0 + cg * c) * P, w.s_blk, -1, 0))) return rc;
         }
         if (fuse) {
             // conv #3 + LFF + residual in one kernel (binhip_fused.hip); o3 is only written out for training
-            const int L = 2 + 5 * d;
-            if ((rc = binhip_rdb_tail_fwd(N, h, ww, nt, HI(b), LO(b, w.s_blk), p->w_hi[L + 3], p->w_lo[L + 3], p->bias[L + 3],
-                                          p->w_hi[L + 4], p->w_lo[L + 4], p->bias[L + 4], HI(b + 14 * P),
-                                          LO(b + 14 * P, w.s_blk), (p->reserved & BINHIP_PLAN_KEEP_ACTS) ? 1 : 0, p->status, stream)))
+            const int L3 = layer_conv(sh, d, 3), LF = layer_conv(sh, d, 4);
+            if ((rc = binhip_rdb_tail_fwd(N, h, ww, nt, HI(b), LO(b, w.s_blk), p->w_hi[L3], p->w_lo[L3], p->bias[L3],
+                                          p->w_hi[LF], p->w_lo[LF], p->bias[LF], HI(b + (int64_t)cb * P),
+                                          LO(b + (int64_t)cb * P, w.s_blk), (p->reserved & BINHIP_PLAN_KEEP_ACTS) ? 1 : 0, p->status, stream)))
                 return rc;
-        } else if ((rc = conv(2 + 5 * d + 4, 1, 14, 96, 96, P_, 0, h, ww, b, w.s_blk, 0, 0, b + 14 * P, w.s_blk, b, w.s_blk)))
+        } else if ((rc = conv(layer_conv(sh, d, C), 1, cb, G0, G0, P_, 0, h, ww, b, w.s_blk, 0, 0, b + (int64_t)cb * P, w.s_blk, b, w.s_blk)))
             return rc;
     }
-    // GFF.0 1x1 over cat(RDBs_out) (RDN.py:199, 218): 12 groups of 6 chunks, one per dense block
-    if ((rc = conv(62, 1, 72, 96, 96, P_, 0, h, ww, w.blk + 14 * P, w.s_blk, 6, 14 * P, w.g0, w.s_g, -1, 0))) return rc;
+    const int LG = sh.L - 4;
+    // GFF.0 1x1 over cat(RDBs_out) (RDN.py:199, 218): D groups of c0 chunks, one per dense block
+    if ((rc = conv(LG, 1, D * c0, G0, G0, P_, 0, h, ww, w.blk + (int64_t)cb * P, w.s_blk, c0, (int64_t)cb * P, w.g0, w.s_g, -1, 0))) return rc;
     // GFF.1 3x3, x += f__1 (RDN.py:200, 219)
-    if ((rc = conv(63, 3, 6, 96, 96, P_, 0, h, ww, w.g0, w.s_g, 0, 0, w.g1, w.s_g, w.f1, w.s_f1))) return rc;
-    // UPNet.0 3x3 96->256 + PixelShuffle(2) (RDN.py:205-206)
-    if ((rc = conv(64, 3, 6, 256, 256, BINHIP_EPI_SHUFFLE, 0, h, ww, w.g1, w.s_g, 0, 0, w.u, w.s_u, -1, 0))) return rc;
+    if ((rc = conv(LG + 1, 3, c0, G0, G0, P_, 0, h, ww, w.g0, w.s_g, 0, 0, w.g1, w.s_g, w.f1, w.s_f1))) return rc;
+    // UPNet.0 3x3 G0->256 + PixelShuffle(2) (RDN.py:205-206)
+    if ((rc = conv(LG + 2, 3, c0, 256, 256, BINHIP_EPI_SHUFFLE, 0, h, ww, w.g1, w.s_g, 0, 0, w.u, w.s_u, -1, 0))) return rc;
     // UPNet.2 3x3 64->3 + mean(inputs) (RDN.py:207, 221/279/333)
-    if ((rc = conv(65, 3, 4, 3, 32, BINHIP_EPI_FINAL, 0, H, W, w.u, w.s_u, 0, 0, -1, 0, -1, 0))) return rc;
+    if ((rc = conv(LG + 3, 3, 4, 3, 32, BINHIP_EPI_FINAL, 0, H, W, w.u, w.s_u, 0, 0, -1, 0, -1, 0))) return rc;
     return 0;
 }
 
@@ -201,7 +234,7 @@ struct Bws {
     size_t wg_bytes, sc_off_bytes, wg_off_bytes, total_bytes;
 };
 
-Bws make_bws(int N, int H, int W, int nin, int nt) {
+Bws make_bws(int N, int H, int W, int nin, int nt, const Shp& sh) {
     Bws b;
     const int h = H / 2, w = W / 2;
     b.P = (int64_t)N * h * w * 16;
@@ -209,8 +242,8 @@ Bws make_bws(int N, int H, int W, int nin, int nt) {
     b.kc0 = (12 * nin + 15) / 16;
     b.gx0_chunks = ((12 * nin + 31) / 32) * 2;
     const int mul = (nt == 3) ? 2 : 1;
-    b.s_gout = b.PF; b.s_gu = 4 * b.PF; b.s_guu = 16 * b.P; b.s_g = 6 * b.P; b.s_gy = (int64_t)13 * 6 * b.P;
-    b.s_gcat = 14 * b.P; b.s_gx0 = (int64_t)b.gx0_chunks * b.P;
+    b.s_gout = b.PF; b.s_gu = 4 * b.PF; b.s_guu = 16 * b.P; b.s_g = sh.c0 * b.P; b.s_gy = (int64_t)(sh.D + 1) * sh.c0 * b.P;
+    b.s_gcat = (int64_t)sh.cb * b.P; b.s_gx0 = (int64_t)b.gx0_chunks * b.P;
     int64_t o = 0;
     b.gout = o; o += mul * b.s_gout;
     b.gu = o; o += mul * b.s_gu;
@@ -227,17 +260,17 @@ Bws make_bws(int N, int H, int W, int nin, int nt) {
     // weight-gradient partial workspace: max over the layer shapes
     size_t wg = 0;
     auto mx = [&](size_t v) { if (v > wg) wg = v; };
-    mx(binhip_wgrad_workspace_bytes(3, N, H, W, 4, 3));          // UPNet.2
-    mx(binhip_wgrad_workspace_bytes(3, N, h, w, 6, 256));        // UPNet.0
-    mx(binhip_wgrad_workspace_bytes(3, N, h, w, 6, 96));         // GFF.1 / SFENet2
-    mx(binhip_wgrad_workspace_bytes(1, N, h, w, 72, 96));        // GFF.0
-    mx(binhip_wgrad_workspace_bytes(1, N, h, w, 14, 96));        // LFF
-    for (int c = 0; c < 4; ++c) mx(binhip_wgrad_workspace_bytes(3, N, h, w, 6 + 2 * c, 32));
-    mx(binhip_wgrad_workspace_bytes(5, N, h, w, b.kc0, 96));     // SFENet1
+    mx(binhip_wgrad_workspace_bytes(3, N, H, W, 4, 3));                       // UPNet.2
+    mx(binhip_wgrad_workspace_bytes(3, N, h, w, sh.c0, 256));                 // UPNet.0
+    mx(binhip_wgrad_workspace_bytes(3, N, h, w, sh.c0, sh.G0));               // GFF.1 / SFENet2
+    mx(binhip_wgrad_workspace_bytes(1, N, h, w, sh.D * sh.c0, sh.G0));        // GFF.0
+    mx(binhip_wgrad_workspace_bytes(1, N, h, w, sh.cb, sh.G0));               // LFF
+    for (int c = 0; c < sh.C; ++c) mx(binhip_wgrad_workspace_bytes(3, N, h, w, sh.c0 + sh.cg * c, sh.G));
+    mx(binhip_wgrad_workspace_bytes(5, N, h, w, b.kc0, sh.G0));               // SFENet1
     b.wg_bytes = wg;
     size_t bytes = ((size_t)b.total_halfs * 2 + 255) & ~(size_t)255;
     b.sc_off_bytes = bytes; bytes += 8192;                       // scale[2] + 1024 amax partials (+pad)
-    b.wg_off_bytes = bytes; bytes += 5 * wg;                     // one partial region per layer of a dense block (batched reduce)
+    b.wg_off_bytes = bytes; bytes += (size_t)(sh.C + 1) * wg;    // one partial region per layer of a dense block (batched reduce)
     b.total_bytes = bytes + 256;
     return b;
 }
@@ -246,16 +279,21 @@ Bws make_bws(int N, int H, int W, int nin, int nt) {
 
 extern "C" {
 
-size_t binhip_rdn_backward_workspace_bytes(int N, int H, int W, int n_inputs, int nterms) {
+size_t binhip_rdn_backward_workspace_bytes(int N, int H, int W, int n_inputs, int nterms, const BinRdnShape* shape) {
     if (N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return 0;
     if (n_inputs != 2 && n_inputs != 3 && n_inputs != 5) return 0;
-    return make_bws(N, H, W, n_inputs, nterms).total_bytes;
+    Shp sh;
+    if (!resolve_shape(shape, &sh)) return 0;
+    return make_bws(N, H, W, n_inputs, nterms, sh).total_bytes;
 }
 
-int binhip_rdn_backward_workspace_layout(int N, int H, int W, int n_inputs, int nterms, int64_t* out, int n_out) {
+int binhip_rdn_backward_workspace_layout(int N, int H, int W, int n_inputs, int nterms, const BinRdnShape* shape, int64_t* out,
+                                         int n_out) {
     if (!out || n_out < BINHIP_RDN_BWD_LAYOUT_WORDS) return BINHIP_E_ARG;
-    if (binhip_rdn_backward_workspace_bytes(N, H, W, n_inputs, nterms) == 0) return BINHIP_E_SHAPE;
-    const Bws b = make_bws(N, H, W, n_inputs, nterms);
+    Shp sh;
+    if (!resolve_shape(shape, &sh) || binhip_rdn_backward_workspace_bytes(N, H, W, n_inputs, nterms, shape) == 0)
+        return BINHIP_E_SHAPE;
+    const Bws b = make_bws(N, H, W, n_inputs, nterms, sh);
     const int64_t v[BINHIP_RDN_BWD_LAYOUT_WORDS] = {b.P, b.PF, b.gx0_chunks, b.gout, b.s_gout, b.gu, b.s_gu, b.guu, b.s_guu,
                                                      b.gg1, b.s_g, b.gg0, b.s_g, b.gf1, b.s_g, b.gy, b.s_gy, b.gcat, b.s_gcat,
                                                      b.gcat2, b.s_gcat, b.gx0, b.s_gx0, (int64_t)b.sc_off_bytes};
@@ -275,11 +313,14 @@ int binhip_rdn_backward(const BinRdnBwdPlan* p, const void* saved, size_t saved_
     // sign of hi, which is the sign of hi + lo) at the offsets of the 3-term layout
     const int nt_saved = (p->reserved & BINHIP_BWD_SAVED_X3) ? 3 : nt;
     if (nt_saved == 3 && nt == 3 && (p->reserved & BINHIP_BWD_SAVED_X3)) return BINHIP_E_ARG;
-    if (saved_bytes < binhip_rdn_workspace_bytes(N, H, W, nin, nt_saved)) return BINHIP_E_WORKSPACE;
-    const Bws b = make_bws(N, H, W, nin, nt);
+    Shp sh;
+    if (!resolve_shape(&p->shape, &sh)) return BINHIP_E_SHAPE;
+    if (saved_bytes < binhip_rdn_workspace_bytes(N, H, W, nin, nt_saved, &p->shape)) return BINHIP_E_WORKSPACE;
+    const Bws b = make_bws(N, H, W, nin, nt, sh);
     if (workspace_bytes < b.total_bytes) return BINHIP_E_WORKSPACE;
-    for (int i = 0; i < BINHIP_RDN_LAYERS; ++i)
+    for (int i = 0; i < sh.L; ++i)
         if (!p->wt_hi[i] || (nt == 3 && !p->wt_lo[i]) || !p->dw[i] || !p->db[i]) return BINHIP_E_ARG;
+    const int G0 = sh.G0, G = sh.G, C = sh.C, D = sh.D, c0 = sh.c0, cg = sh.cg, cb = sh.cb, LG = sh.L - 4;
 
     hipStream_t s = (hipStream_t)stream;
     // Optional second stream (plan->aux_stream): the weight-gradient kernels of a layer depend only on that layer's
@@ -301,7 +342,7 @@ int binhip_rdn_backward(const BinRdnBwdPlan* p, const void* saved, size_t saved_
         (void)hipEventDestroy(e);                                    // released once the recorded work completes
         return r == hipSuccess ? 0 : (int)r;
     };
-    const Ws w = make_ws(N, H, W, nin, nt_saved);
+    const Ws w = make_ws(N, H, W, nin, nt_saved, sh);
     const int h = H / 2, ww = W / 2;
     const int64_t P = w.P;
     _Float16* sbase = (_Float16*)(((uintptr_t)saved + 255) & ~(uintptr_t)255);
@@ -374,57 +415,57 @@ int binhip_rdn_backward(const BinRdnBwdPlan* p, const void* saved, size_t saved_
     // Everything below may have work in flight on the side stream: every exit — error or not — goes through ONE epilogue
     // that destroys the pending per-block events and joins the side stream into the main stream (the caller reuses
     // `workspace` / frees `saved` in main-stream order, also after a failed call).
-    hipEvent_t b_done[12] = {};
+    hipEvent_t b_done[20] = {};
     auto chain = [&]() -> int {
         // ---- UPNet.2 (64 -> 3 at full res): X = U
-        if ((rc = wgrad(65, 3, H, W, 4, 64, 3, w.u, w.s_u, 0, 0, b.gout, b.s_gout, 0))) return rc;
-        if ((rc = dgrad(65, 3, H, W, 1, 64, b.gout, b.s_gout, b.gu, b.s_gu, -1, 0, 0, false, -1, 0, 0, 0))) return rc;
-        // ---- PixelShuffle backward, then UPNet.0 (96 -> 256): X = G1
+        if ((rc = wgrad(LG + 3, 3, H, W, 4, 64, 3, w.u, w.s_u, 0, 0, b.gout, b.s_gout, 0))) return rc;
+        if ((rc = dgrad(LG + 3, 3, H, W, 1, 64, b.gout, b.s_gout, b.gu, b.s_gu, -1, 0, 0, false, -1, 0, 0, 0))) return rc;
+        // ---- PixelShuffle backward, then UPNet.0 (G0 -> 256): X = G1
         if ((rc = binhip_unshuffle_planes(GH(b.gu), GL(b.gu, b.s_gu), N, h, ww, 4, GH(b.guu), GL(b.guu, b.s_guu), stream))) return rc;
-        if ((rc = wgrad(64, 3, h, ww, 6, 96, 256, w.g1, w.s_g, 0, 0, b.guu, b.s_guu, 1))) return rc;
-        if ((rc = dgrad(64, 3, h, ww, 16, 96, b.guu, b.s_guu, b.gg1, b.s_g, -1, 0, 0, false, -1, 0, 0, 0))) return rc;
+        if ((rc = wgrad(LG + 2, 3, h, ww, c0, G0, 256, w.g1, w.s_g, 0, 0, b.guu, b.s_guu, 1))) return rc;
+        if ((rc = dgrad(LG + 2, 3, h, ww, 16, G0, b.guu, b.s_guu, b.gg1, b.s_g, -1, 0, 0, false, -1, 0, 0, 0))) return rc;
         // ---- GFF.1 (+ f__1 skip): X = G0
-        if ((rc = wgrad(63, 3, h, ww, 6, 96, 96, w.g0, w.s_g, 0, 0, b.gg1, b.s_g, 0))) return rc;
-        if ((rc = dgrad(63, 3, h, ww, 6, 96, b.gg1, b.s_g, b.gg0, b.s_g, -1, 0, 0, false, -1, 0, 0, 0))) return rc;
-        // ---- GFF.0 over cat(RDB outputs): X = BLK[1..12][0:6]; gradient scattered to GY[1..12]
-        if ((rc = wgrad(62, 1, h, ww, 72, 1152, 96, w.blk + 14 * P, w.s_blk, 6, 14 * P, b.gg0, b.s_g, 0))) return rc;
-        if ((rc = dgrad(62, 1, h, ww, 6, 1152, b.gg0, b.s_g, b.gy + 6 * P, b.s_gy, -1, 0, 0, false, -1, 0, 6, 6 * P))) return rc;
-        // ---- the 12 residual dense blocks, last to first
-        for (int d = 11; d >= 0; --d) {
-            const int64_t blk = w.blk + (int64_t)d * 14 * P;      // saved forward buffer of RDB d
-            const int64_t gy = b.gy + (int64_t)(d + 1) * 6 * P;   // grad of RDB d's output
-            const int64_t gcat = (d & 1) ? b.gcat2 : b.gcat;      // this block's gradient-concat buffer
-            const int L = 2 + 5 * d;
-            // LFF 1x1 224 -> 96 (+x): gcat = W'^T gy (+ gy on the first 6 chunks); ReLU mask of conv 3's output
-            if ((rc = wgrad(L + 4, 1, h, ww, 14, 224, 96, blk, w.s_blk, 0, 0, gy, b.s_gy, 0, 4))) return rc;
+        if ((rc = wgrad(LG + 1, 3, h, ww, c0, G0, G0, w.g0, w.s_g, 0, 0, b.gg1, b.s_g, 0))) return rc;
+        if ((rc = dgrad(LG + 1, 3, h, ww, c0, G0, b.gg1, b.s_g, b.gg0, b.s_g, -1, 0, 0, false, -1, 0, 0, 0))) return rc;
+        // ---- GFF.0 over cat(RDB outputs): X = BLK[1..D][0:c0]; gradient scattered to GY[1..D]
+        if ((rc = wgrad(LG, 1, h, ww, D * c0, D * G0, G0, w.blk + (int64_t)cb * P, w.s_blk, c0, (int64_t)cb * P, b.gg0, b.s_g, 0))) return rc;
+        if ((rc = dgrad(LG, 1, h, ww, c0, D * G0, b.gg0, b.s_g, b.gy + (int64_t)c0 * P, b.s_gy, -1, 0, 0, false, -1, 0, c0, (int64_t)c0 * P))) return rc;
+        // ---- the D residual dense blocks, last to first
+        for (int d = D - 1; d >= 0; --d) {
+            const int64_t blk = w.blk + (int64_t)d * cb * P;          // saved forward buffer of RDB d
+            const int64_t gy = b.gy + (int64_t)(d + 1) * c0 * P;      // grad of RDB d's output
+            const int64_t gcat = (d & 1) ? b.gcat2 : b.gcat;          // this block's gradient-concat buffer
+            const int L = layer_conv(sh, d, 0);
+            // LFF 1x1 (G0 + C G) -> G0 (+x): gcat = W'^T gy (+ gy on the first c0 chunks); ReLU mask of the last conv's output
+            if ((rc = wgrad(L + C, 1, h, ww, cb, G0 + C * G, G0, blk, w.s_blk, 0, 0, gy, b.s_gy, 0, C))) return rc;
             // block d+2 used this gcat buffer: its weight gradients (side stream) must have read it before it is refilled.
             // Everything queued on the side stream up to here is older than block d+1's wgrads, so a plain join suffices
             // only every other block would over-serialise; the side stream is in order, so "block d+2 done" = an event
             // recorded there right after block d+2's last wgrad.
-            if (two && d + 2 <= 11 && b_done[d + 2]) {
+            if (two && d + 2 <= D - 1 && b_done[d + 2]) {
                 hipError_t r = hipStreamWaitEvent(s, b_done[d + 2], 0);
                 (void)hipEventDestroy(b_done[d + 2]);
                 b_done[d + 2] = nullptr;
                 if (r != hipSuccess) return (int)r;
             }
-            if ((rc = dgrad(L + 4, 1, h, ww, 6, 224, gy, b.s_gy, gcat, b.s_gcat, gy, b.s_gy, 6, false, blk, 12, 0, 0))) return rc;
-            // The four 3x3 convs in gather form (binhip_weights_relayout_rdb_gather): every group of gcat is produced
+            if ((rc = dgrad(L + C, 1, h, ww, c0, G0 + C * G, gy, b.s_gy, gcat, b.s_gcat, gy, b.s_gy, c0, false, blk, c0 + cg * (C - 1), 0, 0))) return rc;
+            // The C 3x3 convs in gather form (binhip_weights_relayout_rdb_gather): every group of gcat is produced
             // ONCE as L_g + conv(stacked G_c of the later convs) instead of being read-modified-written by each of them.
-            for (int c = 3; c >= 0; --c) {
-                const int64_t gyc = gcat + (int64_t)(6 + 2 * c) * P;       // G_c .. G_3, contiguous chunks
-                if ((rc = wgrad(L + c, 3, h, ww, 6 + 2 * c, 96 + 32 * c, 32, blk, w.s_blk, 0, 0, gyc, b.s_gcat, 0, c))) return rc;
+            for (int c = C - 1; c >= 0; --c) {
+                const int64_t gyc = gcat + (int64_t)(c0 + cg * c) * P;     // G_c .. G_{C-1}, contiguous chunks
+                if ((rc = wgrad(L + c, 3, h, ww, c0 + cg * c, G0 + G * c, G, blk, w.s_blk, 0, 0, gyc, b.s_gcat, 0, c))) return rc;
                 if (c > 0) {
-                    // group c = conv c-1's output slot (chunks 4+2c, 5+2c): G_{c-1} = relu'( L_c + sum_{c' >= c} dgrad_c' )
-                    const int64_t slot = gcat + (int64_t)(4 + 2 * c) * P;
-                    if ((rc = dgrad(L + c, 3, h, ww, 2 * (4 - c), 32, gyc, b.s_gcat, slot, b.s_gcat, slot, b.s_gcat, 0, false,
-                                    blk + (int64_t)(4 + 2 * c) * P, 0, 0, 0))) return rc;
+                    // group c = conv c-1's output slot: G_{c-1} = relu'( L_c + sum_{c' >= c} dgrad_c' )
+                    const int64_t slot = gcat + (int64_t)(c0 + cg * (c - 1)) * P;
+                    if ((rc = dgrad(L + c, 3, h, ww, cg * (C - c), G, gyc, b.s_gcat, slot, b.s_gcat, slot, b.s_gcat, 0, false,
+                                    blk + (int64_t)(c0 + cg * (c - 1)) * P, 0, 0, 0))) return rc;
                 } else {
-                    // group 0: L_0 + all four convs -> grad of the block input = GY[d] (already holds GFF.0's share when d >= 1)
-                    if ((rc = dgrad(L, 3, h, ww, 8, 96, gyc, b.s_gcat, b.gy + (int64_t)d * 6 * P, b.s_gy, gcat, b.s_gcat, 0,
+                    // group 0: L_0 + all C convs -> grad of the block input = GY[d] (already holds GFF.0's share when d >= 1)
+                    if ((rc = dgrad(L, 3, h, ww, cg * C, G0, gyc, b.s_gcat, b.gy + (int64_t)d * c0 * P, b.s_gy, gcat, b.s_gcat, 0,
                                     d >= 1, -1, 0, 0, 0))) return rc;
                 }
             }
-            if ((rc = flush_reduces())) return rc;                       // the block's five layers in one reduce launch
+            if ((rc = flush_reduces())) return rc;                       // the block's C + 1 layers in one reduce launch
             if (two) {
                 hipError_t r = hipEventCreateWithFlags(&b_done[d], hipEventDisableTiming);
                 if (r == hipSuccess) r = hipEventRecord(b_done[d], sb);
@@ -432,20 +473,20 @@ int binhip_rdn_backward(const BinRdnBwdPlan* p, const void* saved, size_t saved_
             }
         }
         // ---- SFENet2: X = F1; gF1 = dgrad + gG1 (the `x += f__1` skip)
-        if ((rc = wgrad(1, 3, h, ww, 6, 96, 96, w.f1, w.s_f1, 0, 0, b.gy, b.s_gy, 0))) return rc;
-        if ((rc = dgrad(1, 3, h, ww, 6, 96, b.gy, b.s_gy, b.gf1, b.s_g, b.gg1, b.s_g, 0, false, -1, 0, 0, 0))) return rc;
+        if ((rc = wgrad(1, 3, h, ww, c0, G0, G0, w.f1, w.s_f1, 0, 0, b.gy, b.s_gy, 0))) return rc;
+        if ((rc = dgrad(1, 3, h, ww, c0, G0, b.gy, b.s_gy, b.gf1, b.s_g, b.gg1, b.s_g, 0, false, -1, 0, 0, 0))) return rc;
         // ---- SFENet1 5x5: X = X0
-        if ((rc = wgrad(0, 5, h, ww, w.kc0, 12 * nin, 96, w.x0, w.s_x0, 0, 0, b.gf1, b.s_g, 0))) return rc;
+        if ((rc = wgrad(0, 5, h, ww, w.kc0, 12 * nin, G0, w.x0, w.s_x0, 0, 0, b.gf1, b.s_g, 0))) return rc;
         bool need_in = false;
         for (int i = 0; i < nin; ++i) need_in = need_in || (p->gin[i] != nullptr);
         if (need_in) {
-            if ((rc = dgrad(0, 5, h, ww, 6, 12 * nin, b.gf1, b.s_g, b.gx0, b.s_gx0, -1, 0, 0, false, -1, 0, 0, 0))) return rc;
+            if ((rc = dgrad(0, 5, h, ww, c0, 12 * nin, b.gf1, b.s_g, b.gx0, b.s_gx0, -1, 0, 0, false, -1, 0, 0, 0))) return rc;
             if ((rc = binhip_unpack_input_grads(GH(b.gx0), GL(b.gx0, b.s_gx0), gout, sc, nin, N, H, W, p->gin, stream))) return rc;
         }
         return 0;
     };
     rc = chain();
-    for (int d = 0; d < 12; ++d)
+    for (int d = 0; d < 20; ++d)
         if (b_done[d]) { (void)hipEventDestroy(b_done[d]); b_done[d] = nullptr; }
     const int rj = order(sb, s);
     return rc ? rc : rj;

@@ -13,6 +13,7 @@ Precision (`precision` attribute of the top module, or env BIN_AMD_PRECISION):
   "f16x3" (default) fp16 hi/lo split, 3 MFMA products, fp32-class results (~1e-6 vs reference)
   "f16"             fp16-input MFMA, fp32 accumulate; whole-net max-abs error ~3e-4 (bar: 1e-3)
 """
+import ctypes as C
 import os
 
 import torch
@@ -113,8 +114,8 @@ class _RDNBase(nn.Module):
 
     def __init__(self, G0=64, D=6, C=4, G=32):
         super().__init__()
-        if (G0, D, C, G) != (96, 12, 4, 32):
-            raise NotImplementedError("bin_amd RDN: only the bin_stage4 configuration G0=96, D=12, C=4, G=32 is built")
+        from ...rdn_plan import check_shape
+        self.shape = check_shape((G0, D, C, G))     # raises NotImplementedError outside what the HIP plan runs
         self.G0, self.D, self.C, self.G = G0, D, C, G
         kSize = 3
         self.SFENet1 = nn.Conv2d(12 * self.N_INPUTS, G0, 5, padding=2, stride=1)
@@ -154,7 +155,7 @@ class _RDNBase(nn.Module):
         key = self._weights_key(nterms)
         if self._wcache is None or self._wcache[0] != key:
             with torch.no_grad():
-                self._wcache = (key, RdnWeights(dict(self.named_parameters()), self.N_INPUTS, nterms))
+                self._wcache = (key, RdnWeights(dict(self.named_parameters()), self.N_INPUTS, nterms, shape=self.shape))
         return self._wcache[1]
 
     def _run(self, *frames):
@@ -452,7 +453,8 @@ def _forward_streams(self, B, stage1_cache=None, input_events=None):
         return out
 
     def rdn(si, k, *ins):
-        nb = lib.binhip_rdn_workspace_bytes(n, h, w, len(ins), nterms[k])
+        from ...rdn_plan import c_shape
+        nb = lib.binhip_rdn_workspace_bytes(n, h, w, len(ins), nterms[k], C.byref(c_shape(mods[k].shape)))
 
         def fn():
             # layout / dtype conversions (no-ops for the usual contiguous fp32 frames) run on the call's own stream,

@@ -137,7 +137,8 @@ def pack_inputs(images, nterms=1):
     return y
 
 
-def relayout_item(kind, srcs, bias, w_hi, w_lo, bias_out, cout, cin, ks, rows_pad, cin_chunks, cout_block, shuffle_or_group):
+def relayout_item(kind, srcs, bias, w_hi, w_lo, bias_out, cout, cin, ks, rows_pad, cin_chunks, cout_block, shuffle_or_group,
+                  shape=None):
     """One BinRelayoutItem (include/binhip.h).  `srcs`: the fp32 OIHW source tensor(s); the caller keeps them alive until
     relayout_batch() has enqueued the launch."""
     it = L.BinRelayoutItem()
@@ -148,6 +149,8 @@ def relayout_item(kind, srcs, bias, w_hi, w_lo, bias_out, cout, cin, ks, rows_pa
     it.bias_out = bias_out.data_ptr()
     it.kind, it.cout, it.cin, it.ksize, it.rows_pad = kind, cout, cin, ks, rows_pad
     it.cin_chunks, it.cout_block, it.shuffle_or_group = cin_chunks, cout_block, shuffle_or_group
+    if shape is not None:                  # RDB_GATHER of a block other than bin_stage4's
+        it.shape.G0, it.shape.D, it.shape.C, it.shape.G = shape
     return it
 
 

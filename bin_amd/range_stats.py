@@ -21,10 +21,13 @@ F16_MIN_NORMAL = 6.103515625e-05
 F16_MIN_SUBNORMAL = 5.960464477539063e-08
 
 
-def _layout(fn, dims, words):
+def _layout(fn, dims, words, shape=None):
     n, h, w, k, nt = dims
     out = (C.c_int64 * words)()
-    L.check(fn(n, h, w, k, nt, out, words), "workspace_layout")
+    sh = L.BinRdnShape()
+    if shape is not None:
+        sh.G0, sh.D, sh.C, sh.G = shape
+    L.check(fn(n, h, w, k, nt, C.byref(sh), out, words), "workspace_layout")
     return list(out)
 
 
@@ -50,10 +53,12 @@ def _stats(name, hi, lo=None, scale=1.0, cls=None, kind="activation"):
     return row
 
 
-def forward_stats(ws, dims, tag=""):
+def forward_stats(ws, dims, tag="", shape=(96, 12, 4, 32)):
     """Rows for X0, F1, every dense block's input and its four conv outputs, G0, G1, U of ONE forward call whose
     workspace `ws` was filled with BINHIP_PLAN_KEEP_ACTS (the training forward).  dims = (N, H, W, n_inputs, nterms)."""
-    v = _layout(L.lib().binhip_rdn_workspace_layout, dims, L.RDN_LAYOUT_WORDS)
+    v = _layout(L.lib().binhip_rdn_workspace_layout, dims, L.RDN_LAYOUT_WORDS, shape)
+    G0, D, Cc, G = shape
+    c0, cg, cb = G0 // 16, G // 16, (G0 + Cc * G) // 16
     P, PF, kc0 = v[0], v[1], v[2]
     has_lo = bool(v[15])
     rows = []
@@ -66,24 +71,26 @@ def forward_stats(ws, dims, tag=""):
     add("X0 (packed frames)", v[3], v[4], v[4])
     add("F1 = SFENet1", v[5], v[6], v[6])
     blk, s_blk = v[7], v[8]
-    for d in range(13):
-        b = blk + d * 14 * P
-        add("SFENet2 out" if d == 0 else f"RDB{d - 1} out", b, 6 * P, s_blk, "SFENet2 / dense-block outputs")
-        if d < 12:
-            for c in range(4):
-                o = b + (6 + 2 * c) * P
-                add(f"RDB{d}.conv{c} out", o, 2 * P, s_blk, "dense-block conv outputs (post-ReLU)")
+    for d in range(D + 1):
+        b = blk + d * cb * P
+        add("SFENet2 out" if d == 0 else f"RDB{d - 1} out", b, c0 * P, s_blk, "SFENet2 / dense-block outputs")
+        if d < D:
+            for c in range(Cc):
+                o = b + (c0 + cg * c) * P
+                add(f"RDB{d}.conv{c} out", o, cg * P, s_blk, "dense-block conv outputs (post-ReLU)")
     add("G0 = GFF.0", v[9], v[10], v[10])
     add("G1 = GFF.1 + F1", v[11], v[12], v[12])
     add("U = UPNet.0 shuffled", v[13], v[14], v[14])
     return rows
 
 
-def backward_stats(ws, dims, tag="", input_grads=True):
+def backward_stats(ws, dims, tag="", input_grads=True, shape=(96, 12, 4, 32)):
     """Rows for the gradient planes left in the backward workspace of ONE call (stored x its power-of-two scale).
     `input_grads=False`: the call produced no input-frame gradients (stage 1 of the pyramid reads the raw frames), so its
     gX0 planes were never written and are reported as empty."""
-    v = _layout(L.lib().binhip_rdn_backward_workspace_layout, dims, L.RDN_BWD_LAYOUT_WORDS)
+    v = _layout(L.lib().binhip_rdn_backward_workspace_layout, dims, L.RDN_BWD_LAYOUT_WORDS, shape)
+    G0, D = shape[0], shape[1]
+    c0 = G0 // 16
     P = v[0]
     nt = dims[4]
     base = (-ws.data_ptr()) % 256
@@ -100,8 +107,8 @@ def backward_stats(ws, dims, tag="", input_grads=True):
     for i, nm in enumerate(names):
         add(nm, v[3 + 2 * i], v[4 + 2 * i], v[4 + 2 * i])
     gy, s_gy = v[15], v[16]
-    for d in range(13):
-        add("g SFENet2 out" if d == 0 else f"g RDB{d - 1} out", gy + d * 6 * P, 6 * P, s_gy, "g SFENet2 / dense-block outputs")
+    for d in range(D + 1):
+        add("g SFENet2 out" if d == 0 else f"g RDB{d - 1} out", gy + d * c0 * P, c0 * P, s_gy, "g SFENet2 / dense-block outputs")
     add("g concat (last even block)", v[17], v[18], v[18], "g dense-block concat (blocks 0, 1)")
     add("g concat (last odd block)", v[19], v[20], v[20], "g dense-block concat (blocks 0, 1)")
     if input_grads:
@@ -145,5 +152,6 @@ class Recorder:
             return
         torch.cuda.synchronize()
         tag = f"{self.tag}{type(module).__name__[len('RDN_residual_interp_'):]} N={dims[0]} "
-        self.rows += (forward_stats(ws, dims, tag) if kind == "forward"
-                      else backward_stats(ws, dims, tag, info.get("input_grads", True)))
+        shape = info.get("shape", (96, 12, 4, 32))
+        self.rows += (forward_stats(ws, dims, tag, shape) if kind == "forward"
+                      else backward_stats(ws, dims, tag, info.get("input_grads", True), shape))

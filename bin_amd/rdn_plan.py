@@ -7,14 +7,32 @@ import torch
 from . import _lib as L
 from .ops import ConvWeights, _ptr, _stream, _need_cuda, on_device, relayout_batch, relayout_item, status_word
 
-D_BLOCKS, C_CONVS = 12, 4
+STAGE4_SHAPE = (96, 12, 4, 32)          # (G0, D, C, G) of bin_stage4's sub-networks (reference RDN.py:418, :171-172)
 
 
-def layer_names():
-    """Local parameter prefixes of the 66 layers in launch order (matches binhip_plan.hip)."""
+def check_shape(shape):
+    """The (G0, D, C, G) configurations the HIP plan runs (include/binhip.h, BinRdnShape); anything else raises."""
+    G0, D, C, G = (int(v) for v in shape)
+    if G0 % 32 or not 32 <= G0 <= 256 or G % 32 or not 32 <= G <= 128 or not 1 <= C <= L.RDN_MAX_CONVS or not 1 <= D <= 20 \
+            or 2 + D * (C + 1) + 4 > L.RDN_MAX_LAYERS:
+        raise NotImplementedError(
+            f"bin_amd RDN: unsupported configuration G0={G0}, D={D}, C={C}, G={G} (built: G0 and G multiples of 32 with "
+            f"32 <= G0 <= 256, G <= 128; 1 <= C <= {L.RDN_MAX_CONVS}; 1 <= D <= 20)")
+    return G0, D, C, G
+
+
+def c_shape(shape):
+    s = L.BinRdnShape()
+    s.G0, s.D, s.C, s.G = shape
+    return s
+
+
+def layer_names(shape=STAGE4_SHAPE):
+    """Local parameter prefixes of the 2 + D (C + 1) + 4 layers in launch order (matches binhip_plan.hip; 66 for bin_stage4)."""
+    _, D, C, _ = shape
     names = ["SFENet1", "SFENet2"]
-    for d in range(D_BLOCKS):
-        names += [f"RDBs.{d}.convs.{c}.conv.0" for c in range(C_CONVS)]
+    for d in range(D):
+        names += [f"RDBs.{d}.convs.{c}.conv.0" for c in range(C)]
         names.append(f"RDBs.{d}.LFF")
     names += ["GFF.0", "GFF.1", "UPNet.0", "UPNet.2"]
     return names
@@ -23,23 +41,24 @@ def layer_names():
 class RdnWeights:
     """Kernel-layout weights of one RDN weight set + the BinRdnPlan pointer table."""
 
-    def __init__(self, params, n_inputs, nterms, prefix=""):
-        self.n_inputs, self.nterms = n_inputs, nterms
+    def __init__(self, params, n_inputs, nterms, prefix="", shape=STAGE4_SHAPE):
+        self.n_inputs, self.nterms, self.shape = n_inputs, nterms, check_shape(shape)
         self.layers = []
-        items = []                         # the 66 relayouts of the set go out as a few batched launches
-        for i, nm in enumerate(layer_names()):
+        items = []                         # the relayouts of the set (66 for bin_stage4) go out as a few batched launches
+        for i, nm in enumerate(layer_names(self.shape)):
             w, b = params[f"{prefix}{nm}.weight"], params[f"{prefix}{nm}.bias"]
             shuffle = nm == "UPNet.0"
             cin_chunks = None
             if nm == "SFENet1":
                 cin_chunks = (12 * n_inputs + 15) // 16
             self.layers.append(ConvWeights(w, b, nterms=nterms, shuffle=shuffle, cin_chunks=cin_chunks, defer=items))
-        assert len(self.layers) == L.RDN_LAYERS
+        assert len(self.layers) == 2 + self.shape[1] * (self.shape[2] + 1) + 4
         relayout_batch(items)
 
         self._dgrad = None
 
     def fill_plan(self, plan):
+        plan.shape = c_shape(self.shape)
         for i, cw in enumerate(self.layers):
             plan.w_hi[i] = cw.w_hi.data_ptr()
             plan.w_lo[i] = cw.w_lo.data_ptr() if cw.w_lo is not None else None
@@ -53,7 +72,8 @@ class RdnWeights:
             self._dgrad = {}
         if nterms not in self._dgrad:
             with torch.no_grad():
-                self._dgrad[nterms] = RdnDgradWeights(dict(module.named_parameters()), self.n_inputs, nterms)
+                self._dgrad[nterms] = RdnDgradWeights(dict(module.named_parameters()), self.n_inputs, nterms,
+                                                      shape=self.shape)
         return self._dgrad[nterms]
 
 
@@ -65,11 +85,12 @@ class RdnDgradWeights:
     slot `RDBs.d.convs.g` holds the weights that produce concat-group g of the block from the stacked output
     gradients of convs g..3 - what binhip_rdn_backward expects (include/binhip.h, BinRdnBwdPlan)."""
 
-    def __init__(self, params, n_inputs, nterms, prefix=""):
+    def __init__(self, params, n_inputs, nterms, prefix="", shape=STAGE4_SHAPE):
         lib = L.lib()
+        self.shape = G0, D, C, G = check_shape(shape)
         self.w_hi, self.w_lo = [], []
         dev = None
-        names = layer_names()
+        names = layer_names(self.shape)
         fp32 = {nm: params[f"{prefix}{nm}.weight"].detach().contiguous().float() for nm in names}
 
         def alloc(rows, chunks, ks):
@@ -86,11 +107,12 @@ class RdnDgradWeights:
             cout, cin, ks, _ = w.shape
             if ".convs." in nm:
                 d, g = int(nm.split(".")[1]), int(nm.split(".")[3])
-                rows, chunks = (96, 8) if g == 0 else (32, 2 * (4 - g))
+                rows, chunks = (G0 if g == 0 else G), (C - g) * G // 16
                 hi, lo, zb = alloc(rows, chunks, 3)
-                srcs = [fp32[f"RDBs.{d}.convs.{c}.conv.0"] for c in range(4)]
+                srcs = [fp32[f"RDBs.{d}.convs.{c}.conv.0"] for c in range(C)]
                 cb = lib.binhip_conv_cout_block(3, rows, nterms)
-                items.append(relayout_item(L.RELAYOUT_RDB_GATHER, srcs, None, hi, lo, zb, 32, 96 + 32 * g, 3, rows, chunks, cb, g))
+                items.append(relayout_item(L.RELAYOUT_RDB_GATHER, srcs, None, hi, lo, zb, G, G0 + G * g, 3, rows, chunks, cb, g,
+                                           shape=self.shape))
             else:
                 rows_pad = lib.binhip_dgrad_rows_pad(ks, cin)
                 cin_chunks = (cout + 15) // 16
@@ -103,10 +125,11 @@ class RdnDgradWeights:
             scratch.append(zb)
         relayout_batch(items)
         del scratch
-        self.zero_bias = torch.zeros(1152, dtype=torch.float32, device=dev)
+        self.zero_bias = torch.zeros(max(D * G0, G0 + C * G, 256, 1152), dtype=torch.float32, device=dev)
 
     def fill_plan(self, plan):
-        for i in range(L.RDN_LAYERS):
+        plan.shape = c_shape(self.shape)
+        for i in range(len(self.w_hi)):
             plan.wt_hi[i] = self.w_hi[i].data_ptr()
             plan.wt_lo[i] = self.w_lo[i].data_ptr() if self.w_lo[i] is not None else None
         plan.zero_bias = self.zero_bias.data_ptr()
@@ -179,7 +202,7 @@ def _rdn_forward(weights, inputs, out, ws, flags, profiler):
     plan.status = status_word(inputs[0].device).data_ptr()
     plan.profiler = profiler if profiler else None
     weights.fill_plan(plan)
-    nbytes = lib.binhip_rdn_workspace_bytes(n, h, w, weights.n_inputs, weights.nterms)
+    nbytes = lib.binhip_rdn_workspace_bytes(n, h, w, weights.n_inputs, weights.nterms, C.byref(plan.shape))
     if nbytes == 0:
         raise RuntimeError(f"bin_amd: unsupported RDN shape N={n} H={h} W={w} (H, W must be even)")
     if ws is None:

@@ -32,8 +32,10 @@ CLSTM_NAMES = ("clstm_4_prime", "clstm_6_prime", "clstm_8_prime",
 G0, D, C, G = 96, 12, 4, 32   # RDN.py:418 (GO=96, D=12), RDN.py:171-172 (C=4, G=32)
 
 
-def rdn_param_shapes(n_in):
-    """Ordered {local name: shape} of one RDN sub-net with `n_in` input frames (RDN.py:167-334)."""
+def rdn_param_shapes(n_in, shape=None):
+    """Ordered {local name: shape} of one RDN sub-net with `n_in` input frames (RDN.py:167-334); `shape` = (G0, D, C, G)
+    constructor arguments, default bin_stage4's."""
+    G0, D, C, G = shape if shape is not None else (96, 12, 4, 32)
     s = OrderedDict()
     s["SFENet1.weight"] = (G0, 12 * n_in, 5, 5)
     s["SFENet1.bias"] = (G0,)
@@ -82,6 +84,20 @@ def canonical_weights(seed=0):
             fan_in = wshape[1] * wshape[2] * wshape[3]
             out[f"{set_name}.{local}"] = _uniform(seed, f"{set_name}.{local}", shape,
                                                   1.0 / math.sqrt(fan_in))
+    return out
+
+
+def general_rdn_weights(seed, n_in, shape):
+    """{local name: float32 ndarray} for ONE RDN sub-network of an arbitrary (G0, D, C, G) — the parity tests of the general
+    constructor arguments (reference RDN.py:168-186).  Same initialiser magnitudes as canonical_weights; the values depend on
+    (seed, n_in, shape, local name)."""
+    shapes = rdn_param_shapes(n_in, shape)
+    tag = "rdn%d@%d.%d.%d.%d." % ((n_in,) + tuple(shape))
+    out = OrderedDict()
+    for local, shp in shapes.items():
+        wshape = shp if len(shp) == 4 else shapes[local.replace(".bias", ".weight")]
+        fan_in = wshape[1] * wshape[2] * wshape[3]
+        out[local] = _uniform(seed, tag + local, shp, 1.0 / math.sqrt(fan_in))
     return out
 
 

@@ -66,9 +66,12 @@ def rdb_conv(x, w, b):
 
 
 def rdb(x, W, prefix):
-    """RDB: 4 x rdb_conv -> LFF 1x1 -> + x  (RDN.py:156-165)."""
+    """RDB: C x rdb_conv -> LFF 1x1 -> + x  (RDN.py:156-165); C = the number of convs the weight dict holds for the block."""
     y = x
-    for c in range(C_CONVS):
+    n_convs = 0
+    while f"{prefix}.convs.{n_convs}.conv.0.weight" in W:
+        n_convs += 1
+    for c in range(n_convs):
         y = rdb_conv(y, W[f"{prefix}.convs.{c}.conv.0.weight"], W[f"{prefix}.convs.{c}.conv.0.bias"])
     return F.conv2d(y, W[f"{prefix}.LFF.weight"], W[f"{prefix}.LFF.bias"]) + x
 
@@ -82,7 +85,10 @@ def rdn(inputs, W, set_name):
     f1 = F.conv2d(shuffled, W[f"{p}.SFENet1.weight"], W[f"{p}.SFENet1.bias"], padding=2)
     x = F.conv2d(f1, W[f"{p}.SFENet2.weight"], W[f"{p}.SFENet2.bias"], padding=1)
     outs = []
-    for d in range(D_BLOCKS):
+    n_blocks = 0
+    while f"{p}.RDBs.{n_blocks}.LFF.weight" in W:       # D = the number of dense blocks the weight dict holds (RDN.py:195-198)
+        n_blocks += 1
+    for d in range(n_blocks):
         x = rdb(x, W, f"{p}.RDBs.{d}")
         outs.append(x)
     x = F.conv2d(torch.cat(outs, 1), W[f"{p}.GFF.0.weight"], W[f"{p}.GFF.0.bias"])

@@ -51,10 +51,26 @@ def test_library_host_queries():
     assert lib.binhip_conv_cout_block(3, 256, 1) == 128 and lib.binhip_conv_cout_block(3, 256, 3) == 32
     assert lib.binhip_conv_cout_block(3, 96, 3) == 32 and lib.binhip_conv_cout_block(3, 96, 1) == 96
     assert lib.binhip_weights_bytes(32, 6, 3) == 32 * 6 * 9 * 32
-    assert lib.binhip_rdn_workspace_bytes(1, 33, 32, 2, 1) == 0          # odd height rejected
-    assert lib.binhip_rdn_workspace_bytes(1, 64, 64, 4, 1) == 0          # 4 inputs do not exist
-    b1, b3 = lib.binhip_rdn_workspace_bytes(1, 768, 1344, 2, 1), lib.binhip_rdn_workspace_bytes(1, 768, 1344, 2, 3)
+    assert lib.binhip_rdn_workspace_bytes(1, 33, 32, 2, 1, None) == 0          # odd height rejected
+    assert lib.binhip_rdn_workspace_bytes(1, 64, 64, 4, 1, None) == 0          # 4 inputs do not exist
+    b1, b3 = lib.binhip_rdn_workspace_bytes(1, 768, 1344, 2, 1, None), lib.binhip_rdn_workspace_bytes(1, 768, 1344, 2, 3, None)
     assert 0 < b1 < b3 < (8 << 30)
+    # network shapes (BinRdnShape): NULL and all-zero mean bin_stage4's (96, 12, 4, 32); others are sized accordingly
+    def shp(*v):
+        s_ = _lib.BinRdnShape()
+        s_.G0, s_.D, s_.C, s_.G = v
+        return ctypes.byref(s_)
+    assert lib.binhip_rdn_workspace_bytes(1, 768, 1344, 2, 1, shp(0, 0, 0, 0)) == b1
+    assert lib.binhip_rdn_workspace_bytes(1, 768, 1344, 2, 1, shp(96, 12, 4, 32)) == b1
+    small = lib.binhip_rdn_workspace_bytes(1, 768, 1344, 2, 1, shp(64, 6, 4, 32))
+    assert 0 < small < b1
+    for bad in ((48, 6, 4, 32), (64, 6, 4, 16), (64, 6, 8, 32), (64, 21, 4, 32), (64, 0, 4, 32)):
+        assert lib.binhip_rdn_workspace_bytes(1, 64, 64, 2, 1, shp(*bad)) == 0, bad
+        assert lib.binhip_rdn_backward_workspace_bytes(1, 64, 64, 2, 1, shp(*bad)) == 0, bad
+    from bin_amd.rdn_plan import check_shape, layer_names
+    assert len(layer_names()) == 66 and len(layer_names((64, 6, 4, 32))) == 36 and len(layer_names((32, 2, 3, 64))) == 14
+    with pytest.raises(NotImplementedError):
+        check_shape((48, 6, 4, 32))
 
 
 def test_abi_error_codes_without_a_gpu():
@@ -84,7 +100,7 @@ def test_abi_error_codes_without_a_gpu():
     plan.N, plan.H, plan.W, plan.n_inputs, plan.nterms = 1, 33, 32, 2, 1
     arr = (ctypes.c_void_p * 2)(16, 16)
     assert lib.binhip_rdn_forward(ctypes.byref(plan), arr, one, one, 1 << 20, null) in (E_SHAPE, E_ARG)      # odd height
-    assert lib.binhip_rdn_backward_workspace_bytes(1, 64, 64, 4, 1) == 0
+    assert lib.binhip_rdn_backward_workspace_bytes(1, 64, 64, 4, 1, None) == 0
     assert lib.binhip_wgrad_workspace_bytes(3, 0, 8, 8, 2, 32) == 0
     h = ctypes.c_void_p(0)
     assert lib.binhip_profiler_create(3, 32, 0, 0, ctypes.byref(h)) == E_ARG and not h.value     # max_launches <= 0

@@ -380,3 +380,65 @@ def test_batched_relayout_equals_per_layer_relayout(canon_gpu):
     assert lib.binhip_weights_relayout_batch(None, 1, null) == -1
     bad = L.BinRelayoutItem()
     assert lib.binhip_weights_relayout_batch(C.byref(bad), 1, null) == -1
+
+
+# ------------------------------------------------------------------------------------------------ constructor generality
+@pytest.mark.parametrize("tag", ["rdn2_default_args", "rdn3_wide_growth", "rdn5_one_block"])
+def test_rdn_constructor_arguments_other_than_bin_stage4(tag):
+    """The reference's RDN classes take any G0 / D / C / G (RDN.py:168-186; bin_stage4 uses 96 / 12 / 4 / 32).  Fixture
+    g10_rdn_shapes holds the REFERENCE modules' outputs and autograd gradients for three other configurations (tests/golden/
+    make_golden_shapes.py); the HIP plan must reproduce them — forward in both precision modes, backward (fp32-class) for
+    every input and every parameter (all gradient norms, the stored full gradients, and all of them against torch autograd
+    of the oracle, which the generator pins to the reference)."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from conftest import load_golden
+    from shape_cases import CASES
+    from bin_amd.models.archs import RDN as A
+    from bin_amd.weights import general_rdn_weights
+    from oracle import rdn_oracle as O
+    k, shape, n, h, w = CASES[tag]
+    G0, D, C, G = shape
+    g = load_golden("g10_rdn_shapes")
+    cls = {2: A.RDN_residual_interp_2_input, 3: A.RDN_residual_interp_2_1_input, 5: A.RDN_residual_interp_4_1_input}[k]
+    Wnp = general_rdn_weights(0, k, shape)
+    mod = cls(G0=G0, D=D, C=C, G=G)
+    mod.load_state_dict({nm: torch.from_numpy(v) for nm, v in Wnp.items()}, strict=True)
+    mod = mod.cuda()
+    ins = [torch.from_numpy(g[f"{tag}.in{i}"]) for i in range(k)]
+    want = torch.from_numpy(g[f"{tag}.y"])
+    with torch.no_grad():
+        for prec, tol in (("f16x3", 2e-5), ("f16", 1e-3)):
+            mod.precision = prec
+            y = mod(*[t.cuda() for t in ins]).cpu()
+            err = float((y - want).abs().max())
+            print(f"{tag} {shape} forward {prec}: max|hip - reference| = {err:.2e}")
+            assert err <= tol, (prec, err)
+    # ---- backward, fp32-class
+    mod.precision = "f16x3"
+    gout = torch.from_numpy(g[f"{tag}.gout"])
+    ins_gpu = [t.cuda().requires_grad_(True) for t in ins]
+    mod(*ins_gpu).backward(gout.cuda())
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+    for i in range(k):
+        assert rel(ins_gpu[i].grad.cpu(), torch.from_numpy(g[f"{tag}.gin{i}"])) <= 3e-5, i
+    named = dict(mod.named_parameters())
+    norms = np.array([float(p.grad.double().norm()) for p in named.values()])
+    assert np.allclose(norms, g[f"{tag}.grad_norms"], rtol=2e-4, atol=1e-9)
+    stored = [key for key in g.files if key.startswith(f"{tag}.grad.")]
+    assert len(stored) >= 8
+    for key in stored:
+        nm = key[len(tag) + 6:]
+        assert rel(named[nm].grad.cpu(), torch.from_numpy(g[key])) <= 3e-5, nm
+    Wo = {f"m.{nm}": torch.from_numpy(v).clone().requires_grad_(True) for nm, v in Wnp.items()}
+    ins_o = [t.clone().requires_grad_(True) for t in ins]
+    O.rdn(ins_o, Wo, "m").backward(gout)
+    worst = max(rel(named[nm].grad.cpu(), Wo[f"m.{nm}"].grad) for nm in named)
+    print(f"{tag}: worst relative parameter-gradient error vs oracle autograd {worst:.2e} over {len(named)} tensors")
+    assert worst <= 3e-5
+
+
+def test_unsupported_rdn_configurations_raise():
+    from bin_amd.models.archs import RDN as A
+    for bad in (dict(G0=48), dict(G=16), dict(C=8), dict(D=21)):
+        with pytest.raises(NotImplementedError):
+            A.RDN_residual_interp_2_input(**bad)

@@ -31,7 +31,7 @@ elif case in ("A", "B", "C", "D"):
     fr = [f.cuda() for f in synthetic_frames(1, 1, 64, 64, 6)]
     m1 = net.model.model1_1
     kw = m1.kernel_weights(1)
-    nb = L.lib().binhip_rdn_workspace_bytes(1, 64, 64, 2, 1)
+    nb = L.lib().binhip_rdn_workspace_bytes(1, 64, 64, 2, 1, None)
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     ws1, ws2 = workspace(nb, dev, key="p1"), workspace(nb, dev, key="p2")
     cellm = net.clstm_4_prime
