@@ -49,7 +49,9 @@ def main():
             doc = json.load(open(out_json))
         except Exception:
             doc = {}
-        dom = [k for k in rows if ("conv_x3_kernel<3, 2, 8, 0, 0>" in k if key == "f16x3" else "conv_mfma_kernel<3, 1, 1, 2, 8, 1, 1, 2, 0>" in k)]
+        want = {"f16x3": "conv_x3_kernel<3, 2, 8, 0, 0>", "f16": "conv_mfma_kernel<3, 1, 1, 2, 8, 1, 1, 2, 0>",
+                "wgrad3x3": "wgrad3x3_db_kernel<3>"}[key]          # the dominant kernel of the profiled run
+        dom = [k for k in rows if want in k]
         doc[key] = {"kernel": dom[0] if dom else None,
                     "traffic_bytes_per_launch": int(rows[dom[0]]["traffic_MB"] * 1e6) if dom else None,
                     "calibration_KiB": {"copy_bytes_KiB": 262144, "FETCH_SIZE": BIG.get("FETCH_SIZE"), "WRITE_SIZE": BIG.get("WRITE_SIZE")},
