@@ -343,6 +343,7 @@ int bh_conv_cout_block(int ksize, int cout_pad, int nterms) {
 
 static int bh_dispatch_conv(const ConvKArgs& a, int k, int cp, int nt, int e, hipStream_t s);
 int bh_launch_conv_x3(const ConvKArgs& a, int cout_pad, int epilogue, hipStream_t s);   // binhip_conv_x3.hip
+int bh_launch_final_dot2(const ConvKArgs& a, int nterms, hipStream_t s);                 // binhip_conv_x3.hip
 
 // validate a call and fill the kernel argument block (everything but the tile counts, which the launcher of the chosen
 // tile shape sets)
@@ -448,6 +449,10 @@ static int bh_dispatch_conv(const ConvKArgs& a0, int k, int cp, int nt, int e, h
     a.xcd_remap = g_xcd_remap;
     a.dbg = g_dbg;
     if (!g_wt) a.wt = 0;
+#endif
+    // UPNet.2 (64 -> 3 + mean of the frames): three output channels are a VALU dot-product job, not a 32-row MFMA tile
+#ifndef BINHIP_NO_DOT2        // (side builds: the round-2 MFMA path, for the A/B)
+    if (e == F && k == 3 && cp == 32 && a.cout <= 3 && BH_VARIANT(CLS_FINAL) < 0) return bh_launch_final_dot2(a, nt, s);
 #endif
     //                                   KS MT WM R WN KC NT NBUF EPI
     if (nt == 1) {

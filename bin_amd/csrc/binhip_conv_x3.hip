@@ -350,6 +350,139 @@ int bh_launch_rdb3_x3(const ConvKArgs* convs, unsigned* counter, unsigned* flags
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// UPNet.2 (reference RDN.py:207: conv3x3 64 -> 3 at FULL resolution, + mean of the input frames :221/279/333) without the
+// matrix cores.  With three output channels a 32-row MFMA tile is 91 % padding (round 2: 110 us per launch at 720p, 2.6 % of
+// the window, 0.04 of the MFMA peak); here every lane owns ONE output pixel and accumulates its three channels with
+// v_dot2_f32_f16 (two fp16 products + fp32 add per lane and instruction): operands stay fp16 — the patch planes as they sit in
+// LDS, the weights as wave-uniform scalar loads straight from the relayouted rows 0..2 (no swizzle below row 8) — and the
+// hi / lo split keeps its three products (x_hi w_hi + x_hi w_lo + x_lo w_hi), each exact in fp32.
+//   * tile 8 x 32 pixels, 4 waves (lane = pixel column, wave / lane half = row), patch planes DMA'd per 16-channel chunk and
+//     per precision plane into a two-slot ring exactly like x3_tile (20 KB of LDS: many workgroups per CU);
+//   * per chunk and lane: 72 ds_read_b128 (9 taps x 2 channel halves x 2 planes x ... ) and 648 dot2 (f16x3) / 216 (f16).
+template <int NT>
+__global__ void __launch_bounds__(256)
+final_dot2_kernel(const ConvKArgs a, const unsigned* __restrict__ w_hi32, const unsigned* __restrict__ w_lo32) {
+    // (the weight planes come as separate `const __restrict__` kernel parameters: only then does the compiler know that the
+    //  kernel's own stores cannot clobber them and turns the wave-uniform loads into s_load_dwordx8)
+    using C = X3Cfg<3, 2, 4>;                     // TH = 8, patch 10 x 34, 11 DMA pieces per plane, 4 waves
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = blockIdx.x;
+    if (a.xcd_remap) bid = xcd_band(bid, gridDim.x);
+    const int tx = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y;
+    const int img = bid / a.tiles_y;
+    const int tx0 = tx * 32, ty0 = ty * C::TH;
+    const int H = a.H, W = a.W;
+    const long long plane_elems = (long long)a.N * H * W * 16;
+    const unsigned plane_bytes = (unsigned)(plane_elems * 2);
+
+    unsigned voff[C::NPJ];
+#pragma unroll
+    for (int j = 0; j < C::NPJ; ++j) {
+        const int i = wave + C::NW * j;
+        const int q = i * 64 + lane;
+        const int cg = q >= C::PH * C::PW ? 1 : 0;
+        const int p = q - cg * (C::PH * C::PW);
+        const int py = p / C::PW;
+        const int px = p - py * C::PW;
+        const int gy = ty0 + py - 1;
+        const int gx = tx0 + px - 1;
+        const bool ok = (p < C::PH * C::PW) && (gy >= 0) && (gy < H) && (gx >= 0) && (gx < W);
+        voff[j] = ok ? (unsigned)((((long long)img * H + gy) * W + gx) * 32 + cg * 16) : 0x80000000u;
+    }
+    const int px = lane & 31, py = 2 * wave + (lane >> 5);          // this lane's pixel inside the tile
+    const int base_off = (py * C::PW + px) * 16;                      // patch pixel (py, px) = tap (0, 0) of the output pixel
+    float acc[3] = {0.f, 0.f, 0.f};
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    union X8 { half8 h; half2v p[4]; };
+    union W2 { unsigned u; half2v p; };
+
+    const int nchunks = a.nchunks;
+    auto compute = [&](const char* pb, int c, bool hi_plane) {
+        // weights of chunk c: rows 0..2 of every tap are 3 x 32 B contiguous (row stride 32 B, no slot swizzle below row 8)
+        const unsigned* wh = w_hi32 + (long long)c * (9 * 32 * 8);
+        const unsigned* wl = w_lo32 + (long long)c * (9 * 32 * 8);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dy = t / 3, dx = t % 3;
+#pragma unroll
+            for (int cg = 0; cg < 2; ++cg) {
+                X8 x;
+                x.h = *reinterpret_cast<const half8*>(pb + cg * (C::PH * C::PW * 16) + base_off + (dy * C::PW + dx) * 16);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        W2 w;
+                        w.u = wh[(t * 32 + r) * 8 + cg * 4 + k];
+                        acc[r] = __builtin_amdgcn_fdot2(x.p[k], w.p, acc[r], false);
+                        if (NT == 3 && hi_plane) {
+                            W2 v;
+                            v.u = wl[(t * 32 + r) * 8 + cg * 4 + k];
+                            acc[r] = __builtin_amdgcn_fdot2(x.p[k], v.p, acc[r], false);
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    x3_issue_patch<C>(a, smem, 0, 0, 0, wave, voff, plane_elems, plane_bytes);
+    for (int c = 0; c < nchunks; ++c) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NT == 3) {
+            x3_issue_patch<C>(a, smem, c, 1, 1, wave, voff, plane_elems, plane_bytes);
+            compute(smem, c, true);
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 < nchunks) x3_issue_patch<C>(a, smem, c + 1, 0, 0, wave, voff, plane_elems, plane_bytes);
+            compute(smem + C::PATCH_BYTES, c, false);
+        } else {
+            if (c + 1 < nchunks) x3_issue_patch<C>(a, smem, c + 1, 0, (c + 1) & 1, wave, voff, plane_elems, plane_bytes);
+            compute(smem + (c & 1) * C::PATCH_BYTES, c, true);
+        }
+    }
+    const int gy = ty0 + py, gx = tx0 + px;
+    if (gy < H && gx < W) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (j >= a.cout) break;
+            const long long idx = (((long long)img * a.cout + j) * H + gy) * W + gx;
+            float s = 0.f;
+            if (a.nimg > 0) {
+                s = a.img[0][idx];
+                for (int t = 1; t < a.nimg; ++t) s += a.img[t][idx];
+                s = s / (float)a.nimg;
+            }
+            a.out_f32[idx] = (acc[j] + a.bias[j]) + s;
+        }
+    }
+}
+
+// FINAL epilogue with <= 3 output channels (UPNet.2), both precisions
+int bh_launch_final_dot2(const ConvKArgs& ka, int nterms, hipStream_t s) {
+    using C = X3Cfg<3, 2, 4>;
+    ConvKArgs a = ka;
+    a.tiles_x = (a.W + 31) / 32;
+    a.tiles_y = (a.H + C::TH - 1) / C::TH;
+    a.ncol = 1;
+    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N));
+    const unsigned* wh = reinterpret_cast<const unsigned*>(a.w_hi);
+    const unsigned* wl = reinterpret_cast<const unsigned*>(nterms == 3 ? a.w_lo : a.w_hi);
+    if (nterms == 3) final_dot2_kernel<3><<<grid, dim3(256), 2 * C::PATCH_BYTES, s>>>(a, wh, wl);
+    else final_dot2_kernel<1><<<grid, dim3(256), 2 * C::PATCH_BYTES, s>>>(a, wh, wl);
+    BH_CHECK_LAUNCH();
+    return 0;
+}
+
 // entry for the dispatcher in binhip_conv.hip: every 3x3 convolution of the nterms = 3 path, in 32-row output blocks
 // (wider layers — 96 -> 96, UPNet.0's 96 -> 256, the 96-row backward-data convs — run as cout_pad / 32 workgroup
 // columns over the same tiles: the input patch is re-read per column, from L2)
