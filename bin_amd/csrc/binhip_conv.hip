@@ -450,9 +450,16 @@ static int bh_dispatch_conv(const ConvKArgs& a0, int k, int cp, int nt, int e, h
     a.dbg = g_dbg;
     if (!g_wt) a.wt = 0;
 #endif
-    // UPNet.2 (64 -> 3 + mean of the frames): three output channels are a VALU dot-product job, not a 32-row MFMA tile
+    // UPNet.2 (64 -> 3 + mean of the frames) in the single-product mode: three output channels as VALU dot products instead of
+    // a 32-row MFMA tile (f16 720p window 33.02 -> 32.71 ms).  In the fp32-class mode the same kernel needs 648 dot2 per lane
+    // and chunk behind 112 scalar weight loads and measured 224 us against the MFMA kernel's 110 (profiles/r03_experiments.md):
+    // -DBINHIP_DOT2_X3=1 side builds only.
 #ifndef BINHIP_NO_DOT2        // (side builds: the round-2 MFMA path, for the A/B)
-    if (e == F && k == 3 && cp == 32 && a.cout <= 3 && BH_VARIANT(CLS_FINAL) < 0) return bh_launch_final_dot2(a, nt, s);
+#ifndef BINHIP_DOT2_X3
+#define BINHIP_DOT2_X3 0
+#endif
+    if (e == F && k == 3 && cp == 32 && a.cout <= 3 && (nt == 1 || BINHIP_DOT2_X3) && BH_VARIANT(CLS_FINAL) < 0)
+        return bh_launch_final_dot2(a, nt, s);
 #endif
     //                                   KS MT WM R WN KC NT NBUF EPI
     if (nt == 1) {
