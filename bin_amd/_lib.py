@@ -78,6 +78,10 @@ _SIGNATURES = {
                                      C.c_void_p]),
     "binhip_convlstm_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                                           C.c_void_p, C.c_void_p]),
+    "binhip_lstm_gates_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]),
+    "binhip_lstm_gates_bwd": (C.c_int, [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
     "binhip_charbonnier_partials": (C.c_int, [C.c_int64]),
     "binhip_charbonnier_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p,
                                          C.c_void_p]),

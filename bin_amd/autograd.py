@@ -208,6 +208,69 @@ class _ConvLstmFn(torch.autograd.Function):
         return gx, gcp, ghp, dw, db, None
 
 
+# ---- ConvLSTM cells of any size (reference RDN.py:14-24): gates conv on the general kernels + the elementwise gate kernels
+GENERAL_NTERMS = 3          # the general cell always computes fp32-class (it is not on bin_stage4's path; its cost is irrelevant)
+
+
+class _ConvFn(torch.autograd.Function):
+    """One stride-1 'same' convolution (k = 1, 3, 5) as a differentiable op on the per-op C ABI: forward binhip_conv2d_fwd,
+    backward binhip_conv2d_bwd_weight / _bwd_data on gradient planes carrying a power-of-two scale."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from . import ops
+        nt = GENERAL_NTERMS
+        cw = ops.ConvWeights(weight, bias, nterms=nt)
+        xp = ops.nchw_to_planes(x, nt)
+        y = ops.planes_to_nchw(ops.conv2d(xp, cw), weight.shape[0])
+        ctx.xp, ctx.weight, ctx.has_bias = xp, weight, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import ops
+        nt = GENERAL_NTERMS
+        cout, cin, ks, _ = ctx.weight.shape
+        gp, sc = ops.grad_planes(gy, nt)
+        dw = db = gx = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dw, db = ops.conv2d_bwd_weight(ctx.xp, gp, cout, cin, ks, nt, inv_scale=sc[1:2])
+        if ctx.needs_input_grad[0]:
+            gxs = ops.planes_to_nchw(ops.conv2d_bwd_data(gp, ops.DgradWeights(ctx.weight, nterms=nt)), cin)
+            gx = gxs * sc[1]                              # un-scale (the dgrad is linear in the stored gradient)
+        return gx, dw, (db if ctx.has_bias else None)
+
+
+class _LstmGatesFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gates, c_prev, forget_bias, hidden):
+        from . import ops
+        c1, h1 = ops.lstm_gates(gates, c_prev, forget_bias, hidden)
+        ctx.save_for_backward(gates, c_prev)
+        ctx.fb, ctx.hidden = float(forget_bias), hidden
+        return h1, c1
+
+    @staticmethod
+    def backward(ctx, gh, gc):
+        from . import ops
+        gates, cp = ctx.saved_tensors
+        if gh is None and gc is None:
+            return None, None, None, None
+        dg, gcp = ops.lstm_gates_grad(gates, cp, gh, gc, ctx.fb, ctx.hidden, cp is not None and ctx.needs_input_grad[1])
+        return dg, gcp, None, None
+
+
+def convlstm_general(x, state, weight, bias, forget_bias, hidden):
+    """ConvLSTMCell.forward for any (input_size, hidden_size, kernel_size in 1/3/5) — differentiable when grad is enabled."""
+    c_prev, h_prev = (None, None) if state is None else state
+    if h_prev is None:
+        h_prev = torch.zeros((x.shape[0], hidden, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device)
+    stacked = torch.cat((x.float(), h_prev.float()), 1)
+    gates = _ConvFn.apply(stacked, weight, bias)
+    h1, c1 = _LstmGatesFn.apply(gates, c_prev, forget_bias, hidden)
+    return h1, [c1, h1]
+
+
 def convlstm_apply(x, state, weight, bias, forget_bias):
     c_prev, h_prev = (None, None) if state is None else state
     h, c = _ConvLstmFn.apply(x, c_prev, h_prev, weight, bias, forget_bias)

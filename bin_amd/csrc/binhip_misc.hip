@@ -179,6 +179,45 @@ convlstm_kernel(const float* __restrict__ x, const float* __restrict__ cp, const
     }
 }
 
+// ---- ConvLSTM gate arithmetic for cells OTHER than the (3, 3) cell of the live path (reference RDN.py:74-82, any
+// input_size / hidden_size: RDN.py:14-24).  The gates conv of such a cell runs on the general convolution kernels; these two
+// elementwise kernels are the rest: gates [N, 4h, H, W] (i, j, f, o) -> c', h' and its backward.
+__global__ void __launch_bounds__(256)
+lstm_gates_fwd_kernel(const float* __restrict__ gates, const float* __restrict__ cp, float fb, int hid, long long HW,
+                      long long total, float* __restrict__ cn, float* __restrict__ hn) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;          // over [N, hid, H, W]
+    if (t >= total) return;
+    const long long chw = (long long)hid * HW;
+    const long long n = t / chw, r = t - n * chw;
+    const float* g = gates + n * 4 * chw + r;
+    const float cprev = cp ? cp[t] : 0.f;
+    const float c1 = cprev * sigmoidf_(g[2 * chw] + fb) + sigmoidf_(g[0]) * tanhf(g[chw]);
+    cn[t] = c1;
+    hn[t] = tanhf(c1) * sigmoidf_(g[3 * chw]);
+}
+__global__ void __launch_bounds__(256)
+lstm_gates_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ cp, const float* __restrict__ gh,
+                      const float* __restrict__ gc, float fb, int hid, long long HW, long long total,
+                      float* __restrict__ dg, float* __restrict__ gcp) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const long long chw = (long long)hid * HW;
+    const long long n = t / chw, r = t - n * chw;
+    const float* g = gates + n * 4 * chw + r;
+    float* d = dg + n * 4 * chw + r;
+    const float cprev = cp ? cp[t] : 0.f;
+    const float si = sigmoidf_(g[0]), tj = tanhf(g[chw]), sf = sigmoidf_(g[2 * chw] + fb), so = sigmoidf_(g[3 * chw]);
+    const float c1 = cprev * sf + si * tj;
+    const float tc = tanhf(c1);
+    const float ghv = gh ? gh[t] : 0.f;
+    const float dc = (gc ? gc[t] : 0.f) + ghv * so * (1.f - tc * tc);
+    d[0] = dc * tj * si * (1.f - si);
+    d[chw] = dc * si * (1.f - tj * tj);
+    d[2 * chw] = dc * cprev * sf * (1.f - sf);
+    d[3 * chw] = ghv * tc * so * (1.f - so);
+    if (gcp) gcp[t] = dc * sf;
+}
+
 // ---- pixel criteria (bin_model.py:52-60): Charbonnier mean (loss.py:137-141), L1 sum, L2 sum --------------------
 #define CHARB_BLOCKS 1024
 template <int KIND>
@@ -550,6 +589,28 @@ int binhip_convlstm_fwd(const float* x, const float* c_prev, const float* h_prev
     const long long total = (long long)N * H * W;
     hipLaunchKernelGGL(convlstm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        x, c_prev, h_prev, w, b, forget_bias, N, H, W, c_new, h_new);
+    BH_CHECK_LAUNCH();
+    return 0;
+}
+
+int binhip_lstm_gates_fwd(const float* gates, const float* c_prev, float forget_bias, int N, int hidden, int H, int W,
+                          float* c_new, float* h_new, void* stream) {
+    if (!gates || !c_new || !h_new) return BINHIP_E_ARG;
+    if (N <= 0 || hidden <= 0 || H <= 0 || W <= 0) return BINHIP_E_SHAPE;
+    const long long HW = (long long)H * W, total = (long long)N * hidden * HW;
+    hipLaunchKernelGGL(lstm_gates_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gates,
+                       c_prev, forget_bias, hidden, HW, total, c_new, h_new);
+    BH_CHECK_LAUNCH();
+    return 0;
+}
+
+int binhip_lstm_gates_bwd(const float* gates, const float* c_prev, const float* g_h, const float* g_c, float forget_bias, int N,
+                          int hidden, int H, int W, float* g_gates, float* g_cprev, void* stream) {
+    if (!gates || !g_gates || (!g_h && !g_c)) return BINHIP_E_ARG;
+    if (N <= 0 || hidden <= 0 || H <= 0 || W <= 0) return BINHIP_E_SHAPE;
+    const long long HW = (long long)H * W, total = (long long)N * hidden * HW;
+    hipLaunchKernelGGL(lstm_gates_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gates,
+                       c_prev, g_h, g_c, forget_bias, hidden, HW, total, g_gates, g_cprev);
     BH_CHECK_LAUNCH();
     return 0;
 }

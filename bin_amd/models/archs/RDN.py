@@ -64,8 +64,11 @@ class ConvLSTMCell(nn.Module):
 
     def __init__(self, input_size, hidden_size, forget_bias=1.0, kernel_size=3, padding=3 // 2):
         super().__init__()
-        if (input_size, hidden_size, kernel_size, padding) != (3, 3, 3, 1):
-            raise NotImplementedError("bin_amd ConvLSTMCell: only the (3,3) 3x3 cell of bin_stage4 is built")
+        if kernel_size not in (1, 3, 5) or padding != kernel_size // 2:
+            raise NotImplementedError("bin_amd ConvLSTMCell: kernel_size 1 / 3 / 5 with 'same' padding (the reference's cells are 3x3, pad 1)")
+        # (3, 3, 3x3) = the cell of bin_stage4's live path: ONE fused kernel; every other size: gates conv on the general
+        # convolution kernels + elementwise gate kernels (bin_amd/autograd.py::convlstm_general)
+        self._fused = (input_size, hidden_size, kernel_size) == (3, 3, 3)
         self.input_size, self.hidden_size = input_size, hidden_size
         self.Gates = nn.Conv2d(input_size + hidden_size, 4 * hidden_size, kernel_size, padding=padding, bias=True)
         self._forget_bias = forget_bias
@@ -77,6 +80,14 @@ class ConvLSTMCell(nn.Module):
             return self._forward(input_, prev_state)
 
     def _forward(self, input_, prev_state):
+        if not self._fused:
+            if not input_.is_cuda:
+                raise RuntimeError("bin_amd: ConvLSTMCell runs on a HIP device only (no CPU fallback; see oracle/)")
+            from ...autograd import convlstm_general
+            if torch.is_grad_enabled():
+                return convlstm_general(input_, prev_state, self.Gates.weight, self.Gates.bias, self._forget_bias, self.hidden_size)
+            with torch.no_grad():
+                return convlstm_general(input_, prev_state, self.Gates.weight, self.Gates.bias, self._forget_bias, self.hidden_size)
         if torch.is_grad_enabled() and (input_.requires_grad or self.Gates.weight.requires_grad):
             from ...autograd import convlstm_apply
             return convlstm_apply(input_, prev_state, self.Gates.weight, self.Gates.bias, self._forget_bias)

@@ -384,6 +384,51 @@ def conv2d_bwd_weight(x, gy, cout, cin, ks, nterms, inv_scale=None, shuffle=Fals
     return dw, db
 
 
+def grad_planes(g, nterms):
+    """fp32 NCHW gradient -> chunk planes stored times a power-of-two scale that maps max|g| into (8, 16] (fp16 range), plus
+    the device pair [scale, 1 / scale] (binhip_grad_scale + binhip_nchw_to_planes_scaled)."""
+    _need_cuda(g)
+    g = g.contiguous().float()
+    n, c, h, w = g.shape
+    lib = L.lib()
+    part = torch.empty(lib.binhip_charbonnier_partials(g.numel()), dtype=torch.float32, device=g.device)
+    sc = torch.empty(2, dtype=torch.float32, device=g.device)
+    y = CP.empty(chunks(c), n, h, w, nterms, g.device, c)
+    with on_device(g):
+        L.check(lib.binhip_grad_scale(_ptr(g), g.numel(), 16.0, _ptr(part), _ptr(sc), _stream()), "grad_scale")
+        L.check(lib.binhip_nchw_to_planes_scaled(_ptr(g), n, c, h, w, _ptr(sc), _ptr(y.hi), _ptr(y.lo),
+                                                 _ptr(status_word(g.device)), _stream()), "nchw_to_planes_scaled")
+    return y, sc
+
+
+def lstm_gates(gates, c_prev, forget_bias, hidden):
+    """(c', h') from the gates conv output [N, 4*hidden, H, W] of a ConvLSTM cell of any size (reference RDN.py:74-82)."""
+    _need_cuda(gates)
+    gates = gates.contiguous().float()
+    n, c4, h, w = gates.shape
+    assert c4 == 4 * hidden
+    cn = torch.empty((n, hidden, h, w), dtype=torch.float32, device=gates.device)
+    hn = torch.empty_like(cn)
+    cp = c_prev.contiguous().float() if c_prev is not None else None
+    with on_device(gates):
+        L.check(L.lib().binhip_lstm_gates_fwd(_ptr(gates), _ptr(cp), float(forget_bias), n, hidden, h, w, _ptr(cn), _ptr(hn),
+                                              _stream()), "lstm_gates_fwd")
+    return cn, hn
+
+
+def lstm_gates_grad(gates, c_prev, g_h, g_c, forget_bias, hidden, need_cprev):
+    n, _, h, w = gates.shape
+    dg = torch.empty_like(gates)
+    gcp = torch.empty((n, hidden, h, w), dtype=torch.float32, device=gates.device) if need_cprev else None
+    cp = c_prev.contiguous().float() if c_prev is not None else None
+    gh = g_h.contiguous().float() if g_h is not None else None
+    gc = g_c.contiguous().float() if g_c is not None else None
+    with on_device(gates):
+        L.check(L.lib().binhip_lstm_gates_bwd(_ptr(gates), _ptr(cp), _ptr(gh), _ptr(gc), float(forget_bias), n, hidden, h, w,
+                                              _ptr(dg), _ptr(gcp), _stream()), "lstm_gates_bwd")
+    return dg, gcp
+
+
 # --------------------------------------------------------------------------------------------- harness glue (N1)
 def u8_to_frame(img_u8, pads):
     """HWC BGR uint8 device tensor -> padded fp32 [1,3,Hp,Wp] RGB frame (read_image + ReplicationPad2d)."""

@@ -101,6 +101,15 @@ def general_rdn_weights(seed, n_in, shape):
     return out
 
 
+def general_lstm_weights(seed, input_size, hidden_size, ksize):
+    """(Gates.weight, Gates.bias) of a ConvLSTMCell of any size: xavier-uniform weight, zero bias (reference RDN.py:26-38)."""
+    shape = (4 * hidden_size, input_size + hidden_size, ksize, ksize)
+    fan_in, fan_out = shape[1] * ksize * ksize, shape[0] * ksize * ksize
+    tag = "clstm@%d.%d.%d." % (input_size, hidden_size, ksize)
+    return (_uniform(seed, tag + "Gates.weight", shape, math.sqrt(6.0 / (fan_in + fan_out))),
+            _uniform(seed, tag + "Gates.bias", (shape[0],), 0.05))      # non-zero bias: the fixture should see it
+
+
 def reference_state_dict(seed=0):
     """The 1332-key aliased state_dict of RDN_residual_interp_5_input_ConvLSTM_L
     (reference RDN.py:408-465; key naming per SURVEY.md §8b) as torch tensors."""

@@ -192,6 +192,15 @@ BINHIP_API int binhip_convlstm_fwd(const float* x, const float* c_prev, const fl
                         const float* w /*[12,6,3,3]*/, const float* b /*[12]*/, float forget_bias,
                         int N, int H, int W, float* c_new, float* h_new, void* stream);
 
+/* Gate arithmetic of a ConvLSTM cell of ANY size (RDN.py:14-24 takes input_size / hidden_size; RDN.py:74-82): the gates
+ * convolution of such a cell runs on binhip_conv2d_fwd / _bwd_data / _bwd_weight, these are the elementwise rest.
+ * gates: fp32 [N, 4*hidden, H, W] in (i, j, f, o) order; c_prev may be NULL (zero state); backward: g_h / g_c = gradients of
+ * h' / c' (either may be NULL), g_gates [N, 4*hidden, H, W], g_cprev may be NULL.                                      */
+BINHIP_API int binhip_lstm_gates_fwd(const float* gates, const float* c_prev, float forget_bias, int N, int hidden, int H, int W,
+                          float* c_new, float* h_new, void* stream);
+BINHIP_API int binhip_lstm_gates_bwd(const float* gates, const float* c_prev, const float* g_h, const float* g_c,
+                          float forget_bias, int N, int hidden, int H, int W, float* g_gates, float* g_cprev, void* stream);
+
 /* ---- Charbonnier loss (loss.py:137-141): mean(sqrt((x-y)^2 + eps)).  Deterministic two-pass
  * reduction; `partials` is a caller workspace of binhip_charbonnier_partials() floats.           */
 BINHIP_API int binhip_charbonnier_partials(int64_t numel);

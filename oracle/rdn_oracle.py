@@ -107,10 +107,11 @@ def rdn(inputs, W, set_name):
 def convlstm_cell(x, state, w, b, forget_bias=1.0):
     """ConvLSTMCell.forward (RDN.py:50-95).  state = [c, h] or None (zeros).  Returns (h', [c', h'])."""
     if state is None:
-        z = torch.zeros_like(x)
+        hidden = w.shape[0] // 4                          # zero state of the cell's hidden size (RDN.py:57-68)
+        z = torch.zeros((x.shape[0], hidden) + tuple(x.shape[2:]), dtype=x.dtype)
         state = [z, z]
     c, h = state
-    gates = F.conv2d(torch.cat((x, h), 1), w, b, padding=1)
+    gates = F.conv2d(torch.cat((x, h), 1), w, b, padding=w.shape[-1] // 2)
     i, j, f, o = gates.chunk(4, 1)
     new_c = c * torch.sigmoid(f + forget_bias) + torch.sigmoid(i) * torch.tanh(j)
     new_h = torch.tanh(new_c) * torch.sigmoid(o)

@@ -20,8 +20,8 @@ sys.path.insert(0, "/root/reference")
 
 import models.archs.RDN as REF                  # noqa: E402  (the reference)
 
-from shape_cases import CASES                   # noqa: E402
-from bin_amd.weights import general_rdn_weights  # noqa: E402
+from shape_cases import CASES, LSTM_CASES       # noqa: E402
+from bin_amd.weights import general_rdn_weights, general_lstm_weights  # noqa: E402
 from oracle import rdn_oracle as O              # noqa: E402
 
 torch.set_num_threads(8)
@@ -61,6 +61,34 @@ if __name__ == "__main__":
             if dict(mod.named_parameters())[nm].numel() <= 20000:
                 out[f"{tag}.grad.{nm}"] = dict(mod.named_parameters())[nm].grad.numpy()
         print(tag, "params", sum(p.numel() for p in mod.parameters()), "y", tuple(y.shape), "oracle == reference")
+    # ---- ConvLSTM cells of other sizes (RDN.py:14-24): the reference module's outputs and autograd gradients
+    for tag, (a, b, ks, n, h, w, with_state) in LSTM_CASES.items():
+        Wg, Bg = (torch.from_numpy(v) for v in general_lstm_weights(0, a, b, ks))
+        cell = REF.ConvLSTMCell(a, b, kernel_size=ks, padding=ks // 2)
+        cell.load_state_dict({"Gates.weight": Wg, "Gates.bias": Bg}, strict=True)
+        g = torch.Generator().manual_seed(200 + a + b)
+        x = (torch.rand(n, a, h, w, generator=g) - 0.3).requires_grad_(True)
+        state = [(torch.randn(n, b, h, w, generator=g) * 0.5).requires_grad_(True) for _ in range(2)] if with_state else None
+        gh = torch.randn(n, b, h, w, generator=g) * 1e-2
+        gc = torch.randn(n, b, h, w, generator=g) * 1e-2
+        h1, (c1, h1b) = cell(x, state)
+        assert h1b is h1
+        ((h1 * gh).sum() + (c1 * gc).sum()).backward()
+        xo = x.detach().clone().requires_grad_(True)
+        so = [t.detach().clone().requires_grad_(True) for t in state] if with_state else None
+        wo, bo = Wg.clone().requires_grad_(True), Bg.clone().requires_grad_(True)
+        ho, (co, _) = O.convlstm_cell(xo, so, wo, bo)
+        ((ho * gh).sum() + (co * gc).sum()).backward()
+        assert float((ho - h1).abs().max()) == 0.0 and float((co - c1).abs().max()) == 0.0, tag
+        assert float((wo.grad - cell.Gates.weight.grad).abs().max()) <= 1e-7, tag
+        out[f"{tag}.x"], out[f"{tag}.gh"], out[f"{tag}.gc"] = x.detach().numpy(), gh.numpy(), gc.numpy()
+        out[f"{tag}.h"], out[f"{tag}.c"] = h1.detach().numpy(), c1.detach().numpy()
+        out[f"{tag}.gx"] = x.grad.numpy()
+        out[f"{tag}.dw"], out[f"{tag}.db"] = cell.Gates.weight.grad.numpy(), cell.Gates.bias.grad.numpy()
+        if with_state:
+            out[f"{tag}.c0"], out[f"{tag}.h0"] = state[0].detach().numpy(), state[1].detach().numpy()
+            out[f"{tag}.gc0"], out[f"{tag}.gh0"] = state[0].grad.numpy(), state[1].grad.numpy()
+        print(tag, "oracle == reference")
     path = os.path.join(HERE, "g10_rdn_shapes.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")

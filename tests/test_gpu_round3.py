@@ -442,3 +442,40 @@ def test_unsupported_rdn_configurations_raise():
     for bad in (dict(G0=48), dict(G=16), dict(C=8), dict(D=21)):
         with pytest.raises(NotImplementedError):
             A.RDN_residual_interp_2_input(**bad)
+
+
+@pytest.mark.parametrize("tag", ["lstm_5_7_k3_state", "lstm_3_16_k5_nostate", "lstm_20_4_k1_state"])
+def test_convlstm_cells_of_other_sizes(tag):
+    """ConvLSTMCell(input_size, hidden_size, kernel_size) other than bin_stage4's (3, 3, 3x3) (reference RDN.py:14-24): the
+    gates convolution on the general conv / weight-gradient / backward-data kernels + the elementwise gate kernels, against
+    the REFERENCE cell's outputs and autograd gradients (fixture g10_rdn_shapes)."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from conftest import load_golden
+    from shape_cases import LSTM_CASES
+    from bin_amd.models.archs import RDN as A
+    from bin_amd.weights import general_lstm_weights
+    a, b, ks, n, h, w, with_state = LSTM_CASES[tag]
+    g = load_golden("g10_rdn_shapes")
+    T = lambda k: torch.from_numpy(g[f"{tag}.{k}"])
+    Wg, Bg = (torch.from_numpy(v) for v in general_lstm_weights(0, a, b, ks))
+    cell = A.ConvLSTMCell(a, b, kernel_size=ks, padding=ks // 2)
+    cell.load_state_dict({"Gates.weight": Wg, "Gates.bias": Bg}, strict=True)
+    cell = cell.cuda()
+    x = T("x").cuda().requires_grad_(True)
+    state = [T("c0").cuda().requires_grad_(True), T("h0").cuda().requires_grad_(True)] if with_state else None
+    with torch.no_grad():                                   # inference path
+        h_inf, (c_inf, _) = cell(x.detach(), [t.detach() for t in state] if state else None)
+    h1, (c1, h1b) = cell(x, state)
+    assert h1b is h1
+    for got in ((h1, c1), (h_inf, c_inf)):
+        assert float((got[0].detach().cpu() - T("h")).abs().max()) <= 2e-6
+        assert float((got[1].detach().cpu() - T("c")).abs().max()) <= 2e-6
+    ((h1 * T("gh").cuda()).sum() + (c1 * T("gc").cuda()).sum()).backward()
+    rel = lambda u, v: float((u - v).abs().max() / v.abs().max().clamp_min(1e-12))
+    assert rel(x.grad.cpu(), T("gx")) <= 3e-5
+    assert rel(cell.Gates.weight.grad.cpu(), T("dw")) <= 3e-5
+    assert rel(cell.Gates.bias.grad.cpu(), T("db")) <= 3e-5
+    if with_state:
+        assert rel(state[0].grad.cpu(), T("gc0")) <= 3e-5 and rel(state[1].grad.cpu(), T("gh0")) <= 3e-5
+    with pytest.raises(NotImplementedError):
+        A.ConvLSTMCell(3, 3, kernel_size=7, padding=3)
