@@ -191,9 +191,13 @@ __device__ __forceinline__ void compute_stage(const char* smem, int st, int buf,
     }
 }
 
-template <int KS, int MT, int WM, int R, int WN, int KC, int NT, int NBUF, int EPI>
-__global__ void __launch_bounds__(64 * WM * WN)
-conv_mfma_kernel(const ConvKArgs a) {
+// XTRA: the epilogue also reads residual / accumulator / ReLU-mask planes (backward-data layers, layers with a skip
+// connection); `bias`: the layer's bias again as the kernel's own restrict parameter (scalar loads, binhip_conv_common.h)
+// (at least two waves per SIMD = at most 256 registers: with no waits left between the epilogue's stores the scheduler would
+//  otherwise overlap more of its iterations and take the 4-wave 3-tile kernels from 240 to 272 registers — one workgroup per CU)
+template <int KS, int MT, int WM, int R, int WN, int KC, int NT, int NBUF, int EPI, bool XTRA>
+__global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)))
+conv_mfma_kernel(const ConvKArgs a, const float* __restrict__ bias) {
     using C = ConvCfg<KS, MT, WM, R, WN, KC, NT, NBUF, EPI>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -292,24 +296,32 @@ conv_mfma_kernel(const ConvKArgs a) {
 
     // ---- epilogue (binhip_conv_common.h) ----------------------------------------------------------
     if (BH_DBG(a, 8)) { if (acc[0][0][0] == 12345.f) a.y_hi[0] = (_Float16)1.f; return; }   // timing: no epilogue
-    conv_epilogue<MT, R, NT, EPI>(a, acc, img, ty0 + wn * R, tx0, z * C::COUTB + wm * MT * 32, z == 0 && wm == 0, n, kg,
+    conv_epilogue<MT, R, NT, EPI, XTRA>(a, bias, acc, img, ty0 + wn * R, tx0, z * C::COUTB + wm * MT * 32, z == 0 && wm == 0, n, kg,
                                   plane_elems);
 }
 
 // ---------------------------------------------------------------------------------------------------
-template <int KS, int MT, int WM, int R, int WN, int KC, int NT, int NBUF, int EPI>
-static int launch_cfg(const ConvKArgs& ka, int cout_pad, hipStream_t s) {
+template <int KS, int MT, int WM, int R, int WN, int KC, int NT, int NBUF, int EPI, bool XTRA>
+static int launch_cfg_x(const ConvKArgs& ka, int cout_pad, hipStream_t s) {
     using C = ConvCfg<KS, MT, WM, R, WN, KC, NT, NBUF, EPI>;
     static std::atomic<unsigned long long> lds_set{0};
-    if (int rc = bh_set_max_lds(&conv_mfma_kernel<KS, MT, WM, R, WN, KC, NT, NBUF, EPI>, C::LDS_BYTES, lds_set)) return rc;
+    if (int rc = bh_set_max_lds(&conv_mfma_kernel<KS, MT, WM, R, WN, KC, NT, NBUF, EPI, XTRA>, C::LDS_BYTES, lds_set)) return rc;
     ConvKArgs a = ka;
     a.tiles_x = (a.W + 31) / 32;
     a.tiles_y = (a.H + C::TH - 1) / C::TH;
     a.ncol = cout_pad / C::COUTB;
     dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N * a.ncol));
-    conv_mfma_kernel<KS, MT, WM, R, WN, KC, NT, NBUF, EPI><<<grid, dim3(64 * C::NW), C::LDS_BYTES, s>>>(a);
+    conv_mfma_kernel<KS, MT, WM, R, WN, KC, NT, NBUF, EPI, XTRA><<<grid, dim3(64 * C::NW), C::LDS_BYTES, s>>>(a, a.bias);
     BH_CHECK_LAUNCH();
     return 0;
+}
+// the epilogue with residual / accumulator / mask reads only where a call has them (plane epilogue)
+template <int KS, int MT, int WM, int R, int WN, int KC, int NT, int NBUF, int EPI>
+static int launch_cfg(const ConvKArgs& ka, int cout_pad, hipStream_t s) {
+    if constexpr (EPI == BINHIP_EPI_PLANES) {
+        if (ka.has_res || ka.r2_hi || ka.m_hi) return launch_cfg_x<KS, MT, WM, R, WN, KC, NT, NBUF, EPI, true>(ka, cout_pad, s);
+    }
+    return launch_cfg_x<KS, MT, WM, R, WN, KC, NT, NBUF, EPI, false>(ka, cout_pad, s);
 }
 
 // ---- optional live timing of ONE kernel class with HIP events on the launch stream ---------------------

@@ -73,19 +73,38 @@ __device__ __forceinline__ int xcd_band(int bid, int nwg) {
 // channels of one pixel per g, and lanes n / n+32 hold the two halves of each 8-channel slot.  One
 // v_permlane32_swap per dword turns a (g even, g odd) pair into full 16-byte slots — lanes 0-31 get slot 0, lanes
 // 32-63 slot 1 of the same pixel — so every store instruction writes 32 pixels x 32 B = 1 KiB contiguous.
-// row0 = first image row of this wave's R rows, co0 = first output channel of this wave's MT x 32 rows.
-template <int MT, int R, int NT, int EPI>
-__device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, floatx16 (&acc)[MT][R], int img, int row0, int tx0,
-                                              int co0, bool first_col, int n, int kg, long long plane_elems) {
+// row0 = first image row of this wave's R rows, co0 = first output channel of this wave's MT x 32 rows (wave-uniform).
+//
+// Loads and stores share ONE counter on gfx9 (vmcnt) and retire out of order with each other, so the compiler has to
+// drain every earlier store (s_waitcnt vmcnt(0): a full trip to L2) before it may use a later load.  Round 2's epilogue
+// loaded the bias — and, in the backward-data kernels, residual / accumulator / ReLU-mask values — per 8-channel slot
+// between the plane stores: up to 28 such drains per pixel row of the 224-row LFF backward-data tile.  Now
+//   * the bias comes through SCALAR loads (lgkmcnt): `bias` must be the kernel's own `const float* __restrict__`
+//     parameter (a pointer inside the by-value argument struct is not known to be unclobbered and gets vector loads); the
+//     8 values of a slot pair are wave-uniform, the lane's half is picked with kg;
+//   * XTRA = false (every forward layer without a residual): no vector load at all, the stores go out back to back;
+//   * XTRA = true: residual, in-place accumulation and mask planes are loaded for a whole GROUP of slots (MTG weight
+//     tiles x 4 slots) before the group's first store: one round trip per group.
+template <int MT, int R, int NT, int EPI, bool XTRA>
+__device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const float* __restrict__ bias, floatx16 (&acc)[MT][R],
+                                              int img, int row0, int tx0, int co0, bool first_col, int n, int kg,
+                                              long long plane_elems) {
     const int H = a.H, W = a.W;
     const int gx = tx0 + n;
+    auto bias4 = [&](int co_u, float (&bv)[4]) {       // co_u: wave-uniform first channel of an 8-channel slot
+        float b8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b8[j] = bias[co_u + j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[j] = kg ? b8[4 + j] : b8[j];
+    };
     if constexpr (EPI == BINHIP_EPI_FINAL) {
+        float bv[4];
+        bias4(co0, bv);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int gy = row0 + r;
             if (!((gy < H) && (gx < W)) || kg != 0 || !first_col) continue;
-            const float4 bv = *reinterpret_cast<const float4*>(a.bias);
-            const float v[4] = {acc[0][r][0] + bv.x, acc[0][r][1] + bv.y, acc[0][r][2] + bv.z, acc[0][r][3] + bv.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (j >= a.cout) break;
@@ -96,31 +115,35 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, floatx16 (&acc
                     for (int t = 1; t < a.nimg; ++t) s += a.img[t][idx];
                     s = s / (float)a.nimg;
                 }
-                a.out_f32[idx] = v[j] + s;
+                a.out_f32[idx] = (acc[0][r][j] + bv[j]) + s;
             }
         }
     } else {
         union H4 { half4 h; unsigned u[2]; };
         unsigned sat = 0;
         const int gxc = gx < W ? gx : W - 1;     // clamped coordinates: loads need no branch, stores are predicated
+        constexpr bool X = XTRA && (EPI == BINHIP_EPI_PLANES);
+        constexpr int MTG = (X && MT >= 6) ? 2 : 1;      // weight tiles per load group (<= 10 registers per slot)
+        const bool use_res = X && a.has_res;
+        const bool use_r2 = X && (a.r2_hi != nullptr);
+        const bool use_m = X && (a.m_hi != nullptr);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int gy = row0 + r;
             const bool ok = (gy < H) && (gx < W);
             const int gyc = gy < H ? gy : H - 1;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
+            for (int mt0 = 0; mt0 < MT; mt0 += MTG) {
+                // ---- phase 1: addresses and (XTRA) every load of the group
+                long long off[MTG][4];
+                half4 xr[MTG][4], xrl[MTG][4], x2[MTG][4], x2l[MTG][4], xm[MTG][4];
 #pragma unroll
-                for (int gp = 0; gp < 2; ++gp) {
-                    H4 hv[2], lv[2];
-                    long long o_slot = 0;        // element offset of this lane's 16-byte slot after the swap
+                for (int mi = 0; mi < MTG; ++mi) {
+                    const int mt = mt0 + mi;
+                    if (mt >= MT) continue;
 #pragma unroll
-                    for (int ge = 0; ge < 2; ++ge) {
-                        const int g = 2 * gp + ge;
+                    for (int g = 0; g < 4; ++g) {
                         const int co = co0 + mt * 32 + 8 * g + 4 * kg;
-                        const float4 bv = *reinterpret_cast<const float4*>(a.bias + co);
-                        float v[4] = {acc[mt][r][4 * g + 0] + bv.x, acc[mt][r][4 * g + 1] + bv.y,
-                                      acc[mt][r][4 * g + 2] + bv.z, acc[mt][r][4 * g + 3] + bv.w};
                         long long o;
                         if constexpr (EPI == BINHIP_EPI_SHUFFLE) {
                             const int cq = (a.cout + 3) / 4;      // channels after the shuffle
@@ -134,60 +157,96 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, floatx16 (&acc
                             o = (a.y_cpg > 0)
                                 ? (long long)(och / a.y_cpg) * a.y_group_stride + (long long)(och % a.y_cpg) * plane_elems + pix16
                                 : (long long)och * plane_elems + pix16;
-                            if (a.has_res && och < a.res_chunks && och < a.och_limit) {
-                                const half4 rh = *reinterpret_cast<const half4*>(a.r_hi + o);
+                            if constexpr (X) {
+                                const bool live = och < a.och_limit;
+                                if (use_res && och < a.res_chunks && live) {
+                                    xr[mi][g] = *reinterpret_cast<const half4*>(a.r_hi + o);
+                                    if constexpr (NT == 3) xrl[mi][g] = *reinterpret_cast<const half4*>(a.r_lo + o);
+                                }
+                                if (use_r2 && live) {
+                                    x2[mi][g] = *reinterpret_cast<const half4*>(a.r2_hi + o);
+                                    if constexpr (NT == 3) x2l[mi][g] = *reinterpret_cast<const half4*>(a.r2_lo + o);
+                                }
+                                if (use_m && och >= a.mask_from && live) xm[mi][g] = *reinterpret_cast<const half4*>(a.m_hi + o);
+                            }
+                        }
+                        off[mi][g] = o;
+                    }
+                }
+                // ---- phase 2: bias, extras, ReLU / mask, hi / lo split, lane swap, stores
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) v[j] += (float)rh[j];
-                                if constexpr (NT == 3) {
-                                    const half4 rl = *reinterpret_cast<const half4*>(a.r_lo + o);
+                for (int mi = 0; mi < MTG; ++mi) {
+                    const int mt = mt0 + mi;
+                    if (mt >= MT) continue;
 #pragma unroll
-                                    for (int j = 0; j < 4; ++j) v[j] += (float)rl[j];
+                    for (int gp = 0; gp < 2; ++gp) {
+                        H4 hv[2], lv[2];
+                        long long o_slot = 0;        // element offset of this lane's 16-byte slot after the swap
+#pragma unroll
+                        for (int ge = 0; ge < 2; ++ge) {
+                            const int g = 2 * gp + ge;
+                            float bv[4];
+                            bias4(co0 + mt * 32 + 8 * g, bv);
+                            float v[4] = {acc[mt][r][4 * g + 0] + bv[0], acc[mt][r][4 * g + 1] + bv[1],
+                                          acc[mt][r][4 * g + 2] + bv[2], acc[mt][r][4 * g + 3] + bv[3]};
+                            const long long o = off[mi][g];
+                            if constexpr (EPI != BINHIP_EPI_SHUFFLE) {
+                                const int och = (co0 + mt * 32 + 8 * g + 4 * kg) >> 4;
+                                const bool live = och < a.och_limit;
+                                if constexpr (X) {
+                                    if (use_res && och < a.res_chunks && live) {
+#pragma unroll
+                                        for (int j = 0; j < 4; ++j) v[j] += (float)xr[mi][g][j];
+                                        if constexpr (NT == 3) {
+#pragma unroll
+                                            for (int j = 0; j < 4; ++j) v[j] += (float)xrl[mi][g][j];
+                                        }
+                                    }
+                                    if (use_r2 && live) {
+#pragma unroll
+                                        for (int j = 0; j < 4; ++j) v[j] += (float)x2[mi][g][j];
+                                        if constexpr (NT == 3) {
+#pragma unroll
+                                            for (int j = 0; j < 4; ++j) v[j] += (float)x2l[mi][g][j];
+                                        }
+                                    }
+                                }
+                                if (a.relu) {
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                                }
+                                if constexpr (X) {
+                                    if (use_m && och >= a.mask_from && live) {
+#pragma unroll
+                                        for (int j = 0; j < 4; ++j) v[j] = ((float)xm[mi][g][j] > 0.f) ? v[j] : 0.f;
+                                    }
                                 }
                             }
-                            if (a.r2_hi && och < a.och_limit) {
-                                const half4 rh = *reinterpret_cast<const half4*>(a.r2_hi + o);
+                            // after the swap, lanes 0-31 own slot 0 (g even) and lanes 32-63 slot 1 (g odd) of pixel n:
+                            // the slot start is this (g, kg=0) element offset
+                            if (ge == kg) o_slot = o - 4 * kg;
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) v[j] += (float)rh[j];
-                                if constexpr (NT == 3) {
-                                    const half4 rl = *reinterpret_cast<const half4*>(a.r2_lo + o);
-#pragma unroll
-                                    for (int j = 0; j < 4; ++j) v[j] += (float)rl[j];
-                                }
-                            }
-                            if (a.relu) {
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-                            }
-                            if (a.m_hi && och >= a.mask_from && och < a.och_limit) {
-                                const half4 mh = *reinterpret_cast<const half4*>(a.m_hi + o);
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) v[j] = ((float)mh[j] > 0.f) ? v[j] : 0.f;
+                            for (int j = 0; j < 4; ++j) {
+                                const _Float16 hj = split_hi(v[j], sat);
+                                hv[ge].h[j] = hj;
+                                lv[ge].h[j] = split_lo(v[j], hj);
                             }
                         }
-                        // after the swap, lanes 0-31 own slot 0 (g even) and lanes 32-63 slot 1 (g odd) of pixel n:
-                        // the slot start is this (g, kg=0) element offset
-                        if (ge == kg) o_slot = o - 4 * kg;
+                        // vdst = even group, src = odd group: upper half of vdst <-> lower half of src
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const _Float16 hj = split_hi(v[j], sat);
-                            hv[ge].h[j] = hj;
-                            lv[ge].h[j] = split_lo(v[j], hj);
+                        for (int k = 0; k < 2; ++k) {
+                            auto sw = __builtin_amdgcn_permlane32_swap(hv[0].u[k], hv[1].u[k], false, false);
+                            hv[0].u[k] = sw[0]; hv[1].u[k] = sw[1];
+                            if constexpr (NT == 3) {
+                                auto sl = __builtin_amdgcn_permlane32_swap(lv[0].u[k], lv[1].u[k], false, false);
+                                lv[0].u[k] = sl[0]; lv[1].u[k] = sl[1];
+                            }
                         }
-                    }
-                    // vdst = even group, src = odd group: upper half of vdst <-> lower half of src
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        auto sw = __builtin_amdgcn_permlane32_swap(hv[0].u[k], hv[1].u[k], false, false);
-                        hv[0].u[k] = sw[0]; hv[1].u[k] = sw[1];
-                        if constexpr (NT == 3) {
-                            auto sl = __builtin_amdgcn_permlane32_swap(lv[0].u[k], lv[1].u[k], false, false);
-                            lv[0].u[k] = sl[0]; lv[1].u[k] = sl[1];
+                        if (ok && ((co0 + mt * 32 + 16 * gp) >> 4) < a.och_limit) {
+                            store16(a.y_hi, o_slot, make_uint4(hv[0].u[0], hv[0].u[1], hv[1].u[0], hv[1].u[1]), a.wt);
+                            if constexpr (NT == 3)
+                                store16(a.y_lo, o_slot, make_uint4(lv[0].u[0], lv[0].u[1], lv[1].u[0], lv[1].u[1]), a.wt);
                         }
-                    }
-                    if (ok && ((co0 + mt * 32 + 16 * gp) >> 4) < a.och_limit) {
-                        store16(a.y_hi, o_slot, make_uint4(hv[0].u[0], hv[0].u[1], hv[1].u[0], hv[1].u[1]), a.wt);
-                        if constexpr (NT == 3)
-                            store16(a.y_lo, o_slot, make_uint4(lv[0].u[0], lv[0].u[1], lv[1].u[0], lv[1].u[1]), a.wt);
                     }
                 }
             }

@@ -154,8 +154,9 @@ __device__ __forceinline__ void x3_compute(const char* pb, const char* wb, int a
 
 // One output tile (TH x 32 pixels, 32 output channels of column z) from prologue DMA to epilogue stores.  Every wave of
 // the workgroup calls it with the same arguments; LDS must be free of readers on entry.
-template <int KS, int R, int WN, int EPI>
-__device__ __forceinline__ void x3_tile(const ConvKArgs& a, char* smem, int img, int ty, int tx, int z) {
+template <int KS, int R, int WN, int EPI, bool XTRA>
+__device__ __forceinline__ void x3_tile(const ConvKArgs& a, const float* __restrict__ bias, char* smem, int img, int ty, int tx,
+                                        int z) {
     using C = X3Cfg<KS, R, WN>;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -220,14 +221,16 @@ __device__ __forceinline__ void x3_tile(const ConvKArgs& a, char* smem, int img,
         if (c + 1 < nchunks) x3_issue_patch<C>(a, smem, c + 1, 0, 0, wave, voff, plane_elems, plane_bytes);
         x3_compute<C, KS, R, false>(smem + C::PATCH_BYTES, wb, a_lane_off, b_lane_off, acc[0]);
     }
-    conv_epilogue<1, R, 3, EPI>(a, acc, img, ty0 + wave * R, tx0, z * 32, z == 0, n, kg, plane_elems);
+    conv_epilogue<1, R, 3, EPI, XTRA>(a, bias, acc, img, ty0 + wave * R, tx0, z * 32, z == 0, n, kg, plane_elems);
 }
 
 // WIDE only names the instantiation: 0 = one 32-row output block (the dense-block convs, UPNet.2), 1 = several workgroup
 // columns — same code, separate symbols, so per-kernel profiles keep the dominant dense-block conv apart from the wide layers
-template <int KS, int R, int WN, int EPI, int WIDE>
+// XTRA: the epilogue also reads residual / accumulator / ReLU-mask planes (the backward-data convs); `bias`: the layer's bias
+// as the kernel's own restrict parameter, for scalar loads (binhip_conv_common.h)
+template <int KS, int R, int WN, int EPI, int WIDE, bool XTRA>
 __global__ void __launch_bounds__(64 * WN) __attribute__((amdgpu_waves_per_eu(WN / 2, WN / 2)))
-conv_x3_kernel(const ConvKArgs a) {
+conv_x3_kernel(const ConvKArgs a, const float* __restrict__ bias) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // 1-D grid of tiles x output columns, column fastest: after the XCD banding the `ncol` workgroups that share one input
     // patch are neighbours on ONE XCD, so the patch is fetched into that L2 once (a (tiles, ncol) grid ran each column as a
@@ -241,7 +244,7 @@ conv_x3_kernel(const ConvKArgs a) {
     bid /= a.tiles_x;
     const int ty = bid % a.tiles_y;
     const int img = bid / a.tiles_y;
-    x3_tile<KS, R, WN, EPI>(a, smem, img, ty, tx, z);
+    x3_tile<KS, R, WN, EPI, XTRA>(a, bias, smem, img, ty, tx, z);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -269,7 +272,8 @@ constexpr unsigned RDB3_SPIN_LIMIT = 1u << 22;
 
 template <int R, int WN>
 __global__ void __launch_bounds__(64 * WN) __attribute__((amdgpu_waves_per_eu(WN / 2, WN / 2)))
-conv_x3_rdb3_kernel(const Rdb3Args a) {
+conv_x3_rdb3_kernel(const Rdb3Args a, const float* __restrict__ bias0, const float* __restrict__ bias1,
+                    const float* __restrict__ bias2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ unsigned s_idx;
     const int tiles_x = a.conv[0].tiles_x, tiles_y = a.conv[0].tiles_y;
@@ -302,7 +306,7 @@ conv_x3_rdb3_kernel(const Rdb3Args a) {
             }
         }
         __syncthreads();                      // also: every wave has read s_idx before lane 0 overwrites it
-        x3_tile<3, R, WN, BINHIP_EPI_PLANES>(a.conv[p], smem, img, ty, tx, 0);
+        x3_tile<3, R, WN, BINHIP_EPI_PLANES, false>(a.conv[p], p == 0 ? bias0 : (p == 1 ? bias1 : bias2), smem, img, ty, tx, 0);
         // publish: this wave's write-through stores have left (vmcnt(0)), then all waves', then the flag
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -312,19 +316,26 @@ conv_x3_rdb3_kernel(const Rdb3Args a) {
     }
 }
 
-template <int KS, int R, int WN, int EPI, int WIDE>
-static int launch_x3(const ConvKArgs& ka, int cout_pad, hipStream_t s) {
+template <int KS, int R, int WN, int EPI, int WIDE, bool XTRA>
+static int launch_x3_x(const ConvKArgs& ka, int cout_pad, hipStream_t s) {
     using C = X3Cfg<KS, R, WN>;
     static std::atomic<unsigned long long> lds_set{0};
-    if (int rc = bh_set_max_lds(&conv_x3_kernel<KS, R, WN, EPI, WIDE>, C::LDS_BYTES, lds_set)) return rc;
+    if (int rc = bh_set_max_lds(&conv_x3_kernel<KS, R, WN, EPI, WIDE, XTRA>, C::LDS_BYTES, lds_set)) return rc;
     ConvKArgs a = ka;
     a.tiles_x = (a.W + 31) / 32;
     a.tiles_y = (a.H + C::TH - 1) / C::TH;
     a.ncol = cout_pad / 32;
     dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N * a.ncol));
-    conv_x3_kernel<KS, R, WN, EPI, WIDE><<<grid, dim3(64 * C::NW), C::LDS_BYTES, s>>>(a);
+    conv_x3_kernel<KS, R, WN, EPI, WIDE, XTRA><<<grid, dim3(64 * C::NW), C::LDS_BYTES, s>>>(a, a.bias);
     BH_CHECK_LAUNCH();
     return 0;
+}
+template <int KS, int R, int WN, int EPI, int WIDE>
+static int launch_x3(const ConvKArgs& ka, int cout_pad, hipStream_t s) {
+    if constexpr (EPI == BINHIP_EPI_PLANES) {
+        if (ka.has_res || ka.r2_hi || ka.m_hi) return launch_x3_x<KS, R, WN, EPI, WIDE, true>(ka, cout_pad, s);
+    }
+    return launch_x3_x<KS, R, WN, EPI, WIDE, false>(ka, cout_pad, s);
 }
 
 // the three-phase dense-block launch: `convs` are the fully prepared kernel arguments of convs 0, 1, 2 (same N, H, W;
@@ -345,7 +356,8 @@ int bh_launch_rdb3_x3(const ConvKArgs* convs, unsigned* counter, unsigned* flags
     const long long items = 3ll * a.T;
     const long long slots = 2ll * (cus > 0 ? cus : 256);
     const unsigned grid = (unsigned)(items < slots ? items : slots);
-    conv_x3_rdb3_kernel<BINHIP_X3_R, BINHIP_X3_WN><<<dim3(grid), dim3(64 * C::NW), C::LDS_BYTES, s>>>(a);
+    conv_x3_rdb3_kernel<BINHIP_X3_R, BINHIP_X3_WN><<<dim3(grid), dim3(64 * C::NW), C::LDS_BYTES, s>>>(a, a.conv[0].bias, a.conv[1].bias,
+                                                                                                   a.conv[2].bias);
     BH_CHECK_LAUNCH();
     return 0;
 }

@@ -69,7 +69,9 @@ __device__ __forceinline__ void tail_issue(const TailKArgs& a, char* smem, int c
 
 template <int NT, int NBUF>
 __global__ void __launch_bounds__(512)
-rdb_tail_kernel(const TailKArgs a) {
+rdb_tail_kernel(const TailKArgs a, const float* __restrict__ bias_c, const float* __restrict__ bias_l) {
+    // (the biases again as the kernel's own restrict parameters: scalar loads in the epilogues instead of vector loads that would
+    //  have to wait for every earlier plane store — binhip_conv_common.h, conv_epilogue)
     using C = TailCfg<NT, NBUF>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -227,9 +229,11 @@ rdb_tail_kernel(const TailKArgs a) {
             for (int ge = 0; ge < 2; ++ge) {
                 const int g = 2 * gp + ge;
                 const int co = 8 * g + 4 * kg;
-                const float4 bv = *reinterpret_cast<const float4*>(a.bc + co);
-                const float v[4] = {fmaxf(accc[r][4 * g + 0] + bv.x, 0.f), fmaxf(accc[r][4 * g + 1] + bv.y, 0.f),
-                                    fmaxf(accc[r][4 * g + 2] + bv.z, 0.f), fmaxf(accc[r][4 * g + 3] + bv.w, 0.f)};
+                float b8[8];                              // wave-uniform slot of 8 biases, the lane's half picked by kg
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b8[j] = bias_c[8 * g + j];
+                const float v[4] = {fmaxf(accc[r][4 * g + 0] + (kg ? b8[4] : b8[0]), 0.f), fmaxf(accc[r][4 * g + 1] + (kg ? b8[5] : b8[1]), 0.f),
+                                    fmaxf(accc[r][4 * g + 2] + (kg ? b8[6] : b8[2]), 0.f), fmaxf(accc[r][4 * g + 3] + (kg ? b8[7] : b8[3]), 0.f)};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const _Float16 hj = split_hi(v[j], sat);
@@ -306,9 +310,11 @@ rdb_tail_kernel(const TailKArgs a) {
                 for (int ge = 0; ge < 2; ++ge) {
                     const int g = 2 * gp + ge;
                     const int co = mt * 32 + 8 * g + 4 * kg;
-                    const float4 bv = *reinterpret_cast<const float4*>(a.bl + co);
-                    float v[4] = {accl[mt][r][4 * g + 0] + bv.x, accl[mt][r][4 * g + 1] + bv.y,
-                                  accl[mt][r][4 * g + 2] + bv.z, accl[mt][r][4 * g + 3] + bv.w};
+                    float b8[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) b8[j] = bias_l[mt * 32 + 8 * g + j];
+                    float v[4] = {accl[mt][r][4 * g + 0] + (kg ? b8[4] : b8[0]), accl[mt][r][4 * g + 1] + (kg ? b8[5] : b8[1]),
+                                  accl[mt][r][4 * g + 2] + (kg ? b8[6] : b8[2]), accl[mt][r][4 * g + 3] + (kg ? b8[7] : b8[3])};
                     const long long o = (long long)(co >> 4) * plane_elems + ((((long long)img * H + gyc) * W + gxc) << 4) + (co & 15);
                     if (ge == kg) o_slot = o - 4 * kg;
 #pragma unroll
@@ -346,7 +352,7 @@ static int launch_tail(const TailKArgs& a0, hipStream_t s) {
     TailKArgs a = a0;
     a.tiles_x = (a.W + 31) / 32;
     a.tiles_y = (a.H + C::TH - 1) / C::TH;
-    rdb_tail_kernel<NT, NBUF><<<dim3((unsigned)(a.tiles_x * a.tiles_y * a.N)), dim3(512), C::LDS_BYTES, s>>>(a);
+    rdb_tail_kernel<NT, NBUF><<<dim3((unsigned)(a.tiles_x * a.tiles_y * a.N)), dim3(512), C::LDS_BYTES, s>>>(a, a.bc, a.bl);
     BH_CHECK_LAUNCH();
     return 0;
 }

@@ -158,7 +158,8 @@ __device__ __forceinline__ void tx_compute(const char* pb, const char* wb, int s
 }
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-rdb_tail_x3_kernel(const TailKArgs a) {
+rdb_tail_x3_kernel(const TailKArgs a, const float* __restrict__ bias_c, const float* __restrict__ bias_l) {
+    // (the two biases again as the kernel's own restrict parameters: scalar loads in the epilogues, binhip_conv_common.h)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -257,9 +258,11 @@ rdb_tail_x3_kernel(const TailKArgs a) {
             for (int ge = 0; ge < 2; ++ge) {
                 const int g = 2 * gp + ge;
                 const int co = 8 * g + 4 * kg;
-                const float4 bv = *reinterpret_cast<const float4*>(a.bc + co);
-                const float v[4] = {fmaxf(accc[r][4 * g + 0] + bv.x, 0.f), fmaxf(accc[r][4 * g + 1] + bv.y, 0.f),
-                                    fmaxf(accc[r][4 * g + 2] + bv.z, 0.f), fmaxf(accc[r][4 * g + 3] + bv.w, 0.f)};
+                float b8[8];                              // wave-uniform slot of 8 biases, the lane's half picked by kg
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b8[j] = bias_c[8 * g + j];
+                const float v[4] = {fmaxf(accc[r][4 * g + 0] + (kg ? b8[4] : b8[0]), 0.f), fmaxf(accc[r][4 * g + 1] + (kg ? b8[5] : b8[1]), 0.f),
+                                    fmaxf(accc[r][4 * g + 2] + (kg ? b8[6] : b8[2]), 0.f), fmaxf(accc[r][4 * g + 3] + (kg ? b8[7] : b8[3]), 0.f)};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const _Float16 hj = split_hi(v[j], sat);
@@ -323,7 +326,7 @@ rdb_tail_x3_kernel(const TailKArgs a) {
     e.N = a.N; e.H = H; e.W = W;
     e.relu = 0; e.has_res = 0; e.cout = 96; e.wt = a.wt;
     e.och_limit = 6; e.res_chunks = 0; e.mask_from = 0; e.y_cpg = 0; e.y_group_stride = 0;
-    conv_epilogue<3, TX::R, 3, BINHIP_EPI_PLANES>(e, accl, img, ty0 + wave * TX::R, tx0, 0, true, n, kg, plane_elems);
+    conv_epilogue<3, TX::R, 3, BINHIP_EPI_PLANES, false>(e, bias_l, accl, img, ty0 + wave * TX::R, tx0, 0, true, n, kg, plane_elems);
 }
 
 }  // namespace
@@ -334,7 +337,7 @@ int bh_launch_tail_x3(const TailKArgs& a0, hipStream_t s) {
     TailKArgs a = a0;
     a.tiles_x = (a.W + 31) / 32;
     a.tiles_y = (a.H + TX::TH - 1) / TX::TH;
-    rdb_tail_x3_kernel<<<dim3((unsigned)(a.tiles_x * a.tiles_y * a.N)), dim3(256), TX::LDS_BYTES, s>>>(a);
+    rdb_tail_x3_kernel<<<dim3((unsigned)(a.tiles_x * a.tiles_y * a.N)), dim3(256), TX::LDS_BYTES, s>>>(a, a.bc, a.bl);
     BH_CHECK_LAUNCH();
     return 0;
 }
