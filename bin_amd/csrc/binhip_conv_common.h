@@ -101,21 +101,33 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const float* _
     if constexpr (EPI == BINHIP_EPI_FINAL) {
         float bv[4];
         bias4(co0, bv);
+        // every frame load of the wave's R rows first, then the stores (a load behind a store would wait for the store)
+        const bool mine = (kg == 0) && first_col && (gx < W);
+        float sum[R][4];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int gy = row0 + r;
-            if (!((gy < H) && (gx < W)) || kg != 0 || !first_col) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float sj = 0.f;
+                if (mine && gy < H && j < a.cout && a.nimg > 0) {
+                    const long long idx = (((long long)img * a.cout + j) * H + gy) * W + gx;
+                    sj = a.img[0][idx];
+                    for (int t = 1; t < a.nimg; ++t) sj += a.img[t][idx];
+                    sj = sj / (float)a.nimg;
+                }
+                sum[r][j] = sj;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int gy = row0 + r;
+            if (!(mine && gy < H)) continue;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (j >= a.cout) break;
                 const long long idx = (((long long)img * a.cout + j) * H + gy) * W + gx;
-                float s = 0.f;
-                if (a.nimg > 0) {
-                    s = a.img[0][idx];
-                    for (int t = 1; t < a.nimg; ++t) s += a.img[t][idx];
-                    s = s / (float)a.nimg;
-                }
-                a.out_f32[idx] = (acc[0][r][j] + bv[j]) + s;
+                a.out_f32[idx] = (acc[0][r][j] + bv[j]) + sum[r][j];
             }
         }
     } else {

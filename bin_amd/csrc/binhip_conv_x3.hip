@@ -464,17 +464,23 @@ final_dot2_kernel(const ConvKArgs a, const unsigned* __restrict__ w_hi32, const 
     }
     const int gy = ty0 + py, gx = tx0 + px;
     if (gy < H && gx < W) {
+        float sum[3];                                 // the frame loads of all three channels first, then the stores
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float sj = 0.f;
+            if (j < a.cout && a.nimg > 0) {
+                const long long idx = (((long long)img * a.cout + j) * H + gy) * W + gx;
+                sj = a.img[0][idx];
+                for (int t = 1; t < a.nimg; ++t) sj += a.img[t][idx];
+                sj = sj / (float)a.nimg;
+            }
+            sum[j] = sj;
+        }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             if (j >= a.cout) break;
             const long long idx = (((long long)img * a.cout + j) * H + gy) * W + gx;
-            float s = 0.f;
-            if (a.nimg > 0) {
-                s = a.img[0][idx];
-                for (int t = 1; t < a.nimg; ++t) s += a.img[t][idx];
-                s = s / (float)a.nimg;
-            }
-            a.out_f32[idx] = (acc[j] + a.bias[j]) + s;
+            a.out_f32[idx] = (acc[j] + a.bias[j]) + sum[j];
         }
     }
 }

@@ -16,6 +16,13 @@
 // fixed order (deterministic), un-scales and scatters to OIHW fp32.
 #include "binhip_internal.h"
 #include <utility>
+// 3x3 weight gradient, tile walk of a workgroup: 1 (default) = row-major tiles at stride PB; 0 = a contiguous range, DOWN a
+// 32-pixel column first, so that two of a tile's ten patch rows are still in L2 from the tile before: round 3 measured 583 ->
+// 494 MB of HBM-side traffic per launch and NO gain in time (140.9 vs 142.8 us, training step 132.5 vs 132.9 ms, same box) —
+// like the XCD mapping of round 2, the bytes are not what this kernel waits for.
+#ifndef BINHIP_WG3_STRIDE_WALK
+#define BINHIP_WG3_STRIDE_WALK 1
+#endif
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef short short4_ __attribute__((ext_vector_type(4)));
@@ -470,9 +477,15 @@ __device__ __forceinline__ void wg3_issue(const WgradKArgs& a, char* smem, int t
     using G = Wg3Cfg<NT>;
     const int H = a.H, W = a.W;
     int b = tile;
+#if BINHIP_WG3_STRIDE_WALK      // (see the macro's comment at the top of the file)
     const int tx = b % a.tiles_x; b /= a.tiles_x;
     const int ty = b % a.tiles_y;
     const int img = b / a.tiles_y;
+#else
+    const int ty = b % a.tiles_y; b /= a.tiles_y;
+    const int tx = b % a.tiles_x;
+    const int img = b / a.tiles_x;
+#endif
     const int tx0 = tx * 32, ty0 = ty * C::TH;
     const int y0 = ty0 + dy0 - 1, x0 = tx0 - 1;
     const long long row0 = (long long)img * H;
@@ -571,15 +584,22 @@ wgrad3x3_db_kernel(const WgradKArgs a) {
     const int g_px = lane >> 1;
     const int g_src = (wave * W + g_px) * 32 + (((lane & 1) ^ ((g_px >> 3) & 1)) << 4);
 
+    // this workgroup's contiguous share of the tiles (balanced to within one tile)
+#if BINHIP_WG3_STRIDE_WALK
     int tile = pb;
-    if (tile < a.ntiles && !(a.dbg & 1))
+    const int tend = a.ntiles, tstep = a.PB;
+#else
+    int tile = (int)(((long long)pb * a.ntiles) / a.PB);
+    const int tend = (int)(((long long)(pb + 1) * a.ntiles) / a.PB), tstep = 1;
+#endif
+    if (tile < tend && !(a.dbg & 1))
         wg3_issue<NT>(a, smem, tile, 0, cp, cot, dy0, wave, x_py, x_px, x_src, g_px, g_src, plane_elems, plane_bytes);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
-    for (; tile < a.ntiles; tile += a.PB) {
-        const int nxt = tile + a.PB;
-        if (nxt < a.ntiles && !(a.dbg & 1))
+    for (; tile < tend; tile += tstep) {
+        const int nxt = tile + tstep;
+        if (nxt < tend && !(a.dbg & 1))
             wg3_issue<NT>(a, smem, nxt, cur ^ 1, cp, cot, dy0, wave, x_py, x_px, x_src, g_px, g_src, plane_elems, plane_bytes);
         if (!(a.dbg & 2)) {
             const unsigned st = lds_addr(smem + cur * G::STAGE);
