@@ -342,7 +342,7 @@ def kernel_roofline(prec, kern_ms, kern_n, hp, wp, ms, reuse_schedule):
     mf = rdb_conv_flops(1, hp // 2, wp // 2) * PRODUCTS[prec] / avg_s / 1e12
     assert ach <= HBM_PEAK_GBS, f"kernel algorithmic rate {ach:.0f} GB/s exceeds the HBM peak"
     assert whole_gbs <= HBM_PEAK_GBS, f"whole-forward algorithmic rate {whole_gbs:.0f} GB/s exceeds the HBM peak"
-    kname = ("conv_x3_kernel<3,2,8,0,0>" if prec == "f16x3" else "conv_mfma_kernel<3,1,1,2,8,1,1,2,0>")
+    kname = ("conv_x3_kernel<3,2,8,0,0,false>" if prec == "f16x3" else "conv_mfma_kernel<3,1,1,2,8,1,1,2,0,false>")
     return {"bound": "hbm", "kernel": kname + " (RDB conv3x3 Cin->32 +ReLU, convs 0-2 of each dense block)",
             "precision": prec, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4),
