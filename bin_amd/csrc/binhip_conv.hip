@@ -452,6 +452,10 @@ static int g_xcd_remap = 1, g_dbg = 0, g_wt = 1;
 #define BH_VARIANT(cls) (-1)
 #endif
 
+// waves (= tile rows) of the wide backward-data 1x1 tiles (LFF: 224 rows, GFF.0: 192): 8 = one workgroup per CU, 4 = two
+#ifndef BINHIP_K1_DGRAD_WN
+#define BINHIP_K1_DGRAD_WN 8
+#endif
 static int bh_dispatch_conv(const ConvKArgs& a0, int k, int cp, int nt, int e, hipStream_t s) {
     const int P = BINHIP_EPI_PLANES, S = BINHIP_EPI_SHUFFLE, F = BINHIP_EPI_FINAL;
     const int cb = bh_conv_cout_block(k, cp, nt);
@@ -507,8 +511,8 @@ static int bh_dispatch_conv(const ConvKArgs& a0, int k, int cp, int nt, int e, h
         if (e == S && k == 3 && cp == 256) return launch_cfg<3, 1, 2, 4, 2, 1, 3, 2, S>(a, cp, s);
         if (e == P && k == 3 && cb == 64)  return launch_cfg<3, 2, 1, 2, 4, 1, 3, 2, P>(a, cp, s);
         if (e == P && k == 3 && cb == 96)  return launch_cfg<3, 3, 1, 1, 8, 1, 3, 2, P>(a, cp, s);   // 8 waves x 1 row: 168 vs 184 us
-        if (e == P && k == 1 && cb == 224) return launch_cfg<1, 7, 1, 1, 8, 1, 3, 2, P>(a, cp, s);   // LFF dgrad
-        if (e == P && k == 1 && cb == 192) return launch_cfg<1, 6, 1, 1, 8, 1, 3, 2, P>(a, cp, s);   // GFF.0 dgrad
+        if (e == P && k == 1 && cb == 224) return launch_cfg<1, 7, 1, 1, BINHIP_K1_DGRAD_WN, 1, 3, 2, P>(a, cp, s);   // LFF dgrad
+        if (e == P && k == 1 && cb == 192) return launch_cfg<1, 6, 1, 1, BINHIP_K1_DGRAD_WN, 1, 3, 2, P>(a, cp, s);   // GFF.0 dgrad
         if (e == P && k == 1 && cb == 32)  return launch_cfg<1, 1, 1, 4, 4, 2, 3, 2, P>(a, cp, s);
         if (e == P && k == 1 && cb == 96) {
             if (a.nchunks >= 32) return launch_cfg<1, 3, 1, 2, 4, 1, 3, 2, P>(a, cp, s);
