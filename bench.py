@@ -214,6 +214,18 @@ def cpu_baseline(timeout_s=420):
             "sample": "cpu baseline failed: " + (err_txt.strip().splitlines() or ["?"])[-1][:200]}
 
 
+def max_over_ranks(dt, dev, world):
+    """Slowest rank's time (the contract's max-over-ranks).  nccl (= RCCL) reduces on the device; the gloo hook used to run
+    the N > 1 flow on ONE GPU (tests/test_gpu_round3.py) reduces a host tensor."""
+    import torch.distributed as dist
+    if world == 1:
+        return dt
+    host = dist.get_backend() != "nccl"
+    t = torch.tensor([dt], dtype=torch.float64, device="cpu" if host else dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def train_bench(args, rank, world, dev, steps=None, warmup=None, standalone=True):
     """Secondary metric (BASELINE.json config 4): training samples/s, one process per GPU, DP gradient all-reduce.
     standalone=False: called from the default inference run (rank 0, N = 1) to put a driver-timed training figure on
@@ -299,10 +311,7 @@ def train_bench(args, rank, world, dev, steps=None, warmup=None, standalone=True
                     kern = (kms.value / kn.value * 1e-3, kn.value)
                 else:
                     kern_overlapped = kms.value / kn.value * 1e-3
-    t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-    dt = float(t_max.item())
+    dt = max_over_ranks(dt, dev, world)
     line = {
         "metric": "training samples/sec (256x256 crops, 6-frame windows)", "value": round(world * B * steps / dt, 4),
         "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -311,6 +320,7 @@ def train_bench(args, rank, world, dev, steps=None, warmup=None, standalone=True
         "data": "synthetic", "loss": float(m.loss.detach()),
         "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2),
         "nccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1),
+        "backend": (dist.get_backend() if dist.is_initialized() else None),
         "power": power,
         "roofline": train_roofline(B, S, dt / steps, prec, bwd_prec, kern, kern_overlapped),
         "config": {"workload": f"Adobe240 training, 256x256 crops, batch {B} per GPU, Charbonnier x17, Adam, "
@@ -461,10 +471,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # One process per GPU over RCCL ("nccl") is the product path.  BIN_AMD_BENCH_BACKEND=gloo + BIN_AMD_BENCH_SHARE_GPU=1 is a test
+    # hook: RCCL refuses two ranks on one device, so the N > 1 flow (barriers, max-over-ranks time, whole-job value, the DP
+    # gradient all-reduce of --mode train) is exercised on a 1-GPU box with every rank on cuda:(local_rank % device_count).
+    backend = os.environ.get("BIN_AMD_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if os.environ.get("BIN_AMD_BENCH_SHARE_GPU") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     for v in args.variant:                   # side-build switches (never present in the product library)
         from bin_amd import _lib as _L
@@ -522,7 +540,7 @@ def main():
         # every CU, so another stream's kernels only slip into the ramp/drain.  Off by default.
         kw_in = {"input_events": []} if (net.resolved_streams() > 1 and not args.four_calls and args.pipeline) else {}
         from bin_amd.utils.smi import Sampler
-        smi = Sampler(local_rank)               # shader clock / package power DURING the timed region (host thread)
+        smi = Sampler(dev.index)                # shader clock / package power DURING the timed region (host thread)
         smi.start()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -611,10 +629,7 @@ def main():
     assert all(torch.isfinite(o).all() for o in out)
     del out
 
-    t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-    dt = float(t_max.item())
+    dt = max_over_ranks(dt, dev, world)
 
     # ---- BASELINE config 3/4 on this GPU: one driver-timed training figure on the same line (N = 1 default run)
     train = None
@@ -647,6 +662,7 @@ def main():
             "roofline": roof,
             "power": power,
             "nccl_ranks": (dist.get_world_size() if world > 1 else 1),
+            "backend": (dist.get_backend() if world > 1 else None),
             "tolerance_mode" if other == "f16" else "fp32_class": alt,
             "streaming": None if stream_fps is None else {
                 "value": round(stream_fps, 3), "unit": "interpolated frames/s",

@@ -177,6 +177,36 @@ def test_world2_folder_sharding_is_complete_and_duplicate_free(tmp_path):
     assert "ranks: 2" in log and "windows: 8" in log
 
 
+def _bench_as_the_driver_launches_it(n, extra, port):
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...` (the driver's N > 1 command),
+    with bench.py's test hook that puts every rank on the one GPU of the box over gloo (RCCL refuses two ranks per device)."""
+    import json
+    import subprocess
+    env = dict(os.environ, BIN_AMD_BENCH_BACKEND="gloo", BIN_AMD_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", str(n)] + extra
+    r = subprocess.run(cmd, env=env, cwd=REPO, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]                             # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_inference_line_is_whole_job_throughput():
+    d = _bench_as_the_driver_launches_it(2, ["--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline"], 29631)
+    assert d["n_gpus"] == 2 and d["nccl_ranks"] == 2 and d["backend"] == "gloo" and d["scaling"] == "weak"
+    assert d["steps"] == 2 and d["warmup"] == 1
+    assert abs(d["value"] - 2 * 2 / (d["ms_per_step"] * 2 * 1e-3)) < 1e-2 * d["value"]       # all ranks' windows / max time
+    assert d["roofline"]["frac"] <= 1.0 and d["power"]["samples"] >= 0
+
+
+def test_bench_two_ranks_training_line_reduces_gradients_across_ranks():
+    d = _bench_as_the_driver_launches_it(2, ["--mode", "train", "--batch", "1", "--steps", "2", "--warmup", "1"], 29633)
+    assert d["n_gpus"] == 2 and d["nccl_ranks"] == 2 and d["backend"] == "gloo"
+    assert abs(d["value"] - 2 * 1 * 2 / (d["ms_per_step"] * 2 * 1e-3)) < 1e-2 * d["value"]
+    assert np.isfinite(d["loss"]) and d["roofline"]["dominant_kernel"]["launches"] > 0
+
+
 # ------------------------------------------------------------------------------------------------ fp16 headroom
 def test_fp16_headroom_of_stored_planes_before_and_after_training_steps(tmp_path):
     """Every stored activation and gradient plane stays >= 8x below the fp16 limit — on the seeded init AND on weights
