@@ -396,7 +396,7 @@ def train_roofline(batch, size, step_s, prec, bwd_prec, kern, kern_overlapped=No
         kf, kb = wgrad3x3_launch_model(batch, h2, w2)
         kb *= BYTES_PER_ELEM[prec] / 4.0
         out["dominant_kernel"] = {
-            "kernel": "wgrad3x3_db_kernel (3x3 weight gradient of the dense-block convs, Cin = 96..192 -> 32)",
+            "kernel": "wgrad3x3_xrow_kernel (3x3 weight gradient of the dense-block convs, Cin = 96..192 -> 32)",
             "avg_kernel_us": round(avg_s * 1e6, 2), "launches": n, "launches_per_step": 4 * 48,
             "share_of_step": round(avg_s * 4 * 48 / step_s, 4),
             "avg_kernel_us_beside_backward_data": None if kern_overlapped is None else round(kern_overlapped * 1e6, 2),

@@ -23,6 +23,14 @@
 #ifndef BINHIP_WG3_STRIDE_WALK
 #define BINHIP_WG3_STRIDE_WALK 1
 #endif
+// 3x3 weight gradient: 1 = wave owns an X row (wgrad3x3_xrow_kernel), 0 = wave owns a gY row (wgrad3x3_db_kernel, round 2)
+#ifndef BINHIP_WG3_XROW
+#define BINHIP_WG3_XROW 1
+#endif
+// ... and its prefetch DMA: 1 = spread over the multiply steps of a tile, 0 = one burst at the top of the tile (side builds)
+#ifndef BINHIP_WG3_SPREAD_DMA
+#define BINHIP_WG3_SPREAD_DMA 1
+#endif
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef short short4_ __attribute__((ext_vector_type(4)));
@@ -606,6 +614,9 @@ wgrad3x3_db_kernel(const WgradKArgs a) {
             TrFrag Bh[2], Bl[2], Ah[3], Al[3];
             auto load = [&](auto SC) {
                 constexpr int s = decltype(SC)::value, ks = s / NTAP, t = s % NTAP, q = s % 3;
+#if BINHIP_TUNING
+                if (a.dbg & 8) return;                 // ablation: MFMAs on stale registers, no LDS fragment reads
+#endif
                 if constexpr (t == 0) {
                     tr_issue_pair<ks * 512>(Bh[ks], st + g_off, st + g_off + 128);
                     if constexpr (NT == 3) tr_issue_pair<ks * 512 + G::PLANE>(Bl[ks], st + g_off, st + g_off + 128);
@@ -649,6 +660,297 @@ wgrad3x3_db_kernel(const WgradKArgs a) {
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }, std::make_integer_sequence<int, NSTEP>{});
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    if (a.dbg & 4) { if (acc[0][0] == 12345.f) a.partial[0] = bsum; return; }
+    // ---- the eight rows are summed through LDS in a fixed order: one partial per workgroup and tap
+    float* red = reinterpret_cast<float*>(smem);          // [8 waves][32 m][32 n]
+    const int n = lane & 31, hi = lane >> 5;
+    const long long blk = ((long long)bz * a.ncp + cp) * a.PB + pb;
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[wave * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * hi) * 32 + n] = acc[t][e];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 512 * i;
+            a.partial[(blk * NTAP + t) * 1024 + idx] =
+                ((red[idx] + red[1024 + idx]) + (red[2048 + idx] + red[3072 + idx])) +
+                ((red[4096 + idx] + red[5120 + idx]) + (red[6144 + idx] + red[7168 + idx]));
+        }
+    }
+    if (do_bias) {
+        __syncthreads();
+        red[tid] = bsum;                              // [wave][kg][co]
+        __syncthreads();
+        if (tid < 32) {
+            float tsum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) tsum += red[k * 32 + tid];
+            a.partial_b[((long long)cot * a.PB + pb) * 32 + tid] = tsum;
+        }
+    }
+}
+
+// 3x3 layers, X-ROW form of the eight-wave kernel (round 3).  Above, wave w owns gY row w of the tile and reads, per K-step,
+// one gY fragment pair and NINE tap-shifted X fragments (rows w .. w + 2 of a 10-row halo patch): 20 fragments for 27 MFMAs —
+// fragment reads + DMA writes keep the LDS ~87 % busy, and the DMA prefetch measurably does not overlap with the multiply
+// (tools/bench_wgrad.py, 160 -> 32: MFMAs alone 104 us, + fragment reads 132, DMA alone 107, all together 210 = the SUM).
+// Here the tile is 8 X rows and the halo moves to the operand that needs no column shifts:
+//     dW[dy][dx] = sum_r sum_x X[r][x + dx - 1] * gY[r - dy + 1][x]
+// wave w owns X row r0 + w: three column-shifted X fragments per K-step, each used against the THREE gY rows r - dy + 1
+// (a 10-row gY patch, rows r0 - 1 .. r0 + 8, zero outside the image): 6 X + 6 gY = 12 fragments for the same 27 MFMAs
+// (-40 % LDS reads), identical for every wave, and the X halo rows are no longer fetched twice (X 8 x 34, gY 10 x 32 pixels per
+// tile and pair: the same 75 KB).  Every (X row, dy) product is counted in exactly one tile because the X rows are
+// partitioned; rows outside the image arrive as zeros from the DMA range check.  Step s = (ks, dy, dx): the reads of step
+// s + 2 are issued while step s multiplies, counted lgkmcnt as above; X fragments live in one buffer per dx (A[1][dx] is
+// fetched two steps after the last use of A[0][dx]), gY fragments alternate between two.
+template <int NT>
+struct Wg3xCfg {
+    static constexpr int NPL = (NT == 3) ? 2 : 1;
+    static constexpr int XR = 8, GR = 10, PW = 34;
+    static constexpr int XP = (XR * PW * 2 + 63) / 64;                   // 1-KiB DMA pieces of an X chunk patch (9)
+    static constexpr int GP = GR;                                        // one piece = one 32-pixel gY row
+    static constexpr int XS = XP * 1024 + 128, GS = GP * 1024 + 128;     // chunk strides (bank offset as in Wg3Cfg)
+    static constexpr int G0 = 2 * XS;
+    static constexpr int PLANE = 2 * XS + 2 * GS;
+    static constexpr int STAGE = NPL * PLANE;
+    static constexpr int LDS_BYTES = 2 * STAGE;
+    static constexpr int NXJ = (XP + 7) / 8, NGJ = (GP + 7) / 8;
+    static_assert(PLANE + 512 + 2 * 1024 + 128 < 65536, "lo plane / K-step / gY row reachable with the 16-bit DS offset");
+    static_assert(LDS_BYTES <= 160 * 1024 && LDS_BYTES >= 8 * 4096, "LDS budget; the final reduction needs 32 KB");
+};
+
+// DMA of one tile, in two halves so that the caller can spread the instructions over the multiply steps of the tile before
+// (see the kernel): wg3x_offsets() = the per-lane buffer offsets of the tile (VALU only), wg3x_issue_part(PL, H) = the
+// buffer_load ... lds instructions of plane PL, chunk H of the pair (X pieces, then gY pieces).
+template <int NT>
+struct Wg3xTile {
+    unsigned xvo[Wg3xCfg<NT>::NXJ], gvo[Wg3xCfg<NT>::NGJ];
+};
+template <int NT>
+__device__ __forceinline__ void wg3x_offsets(const WgradKArgs& a, int tile, int wave, const int* x_py, const int* x_px,
+                                             const int* x_src, int g_px, const int* g_src, Wg3xTile<NT>& o) {
+    using G = Wg3xCfg<NT>;
+    const int H = a.H, W = a.W;
+    int b = tile;
+#if BINHIP_WG3_STRIDE_WALK
+    const int tx = b % a.tiles_x; b /= a.tiles_x;
+    const int ty = b % a.tiles_y;
+    const int img = b / a.tiles_y;
+#else
+    const int ty = b % a.tiles_y; b /= a.tiles_y;
+    const int tx = b % a.tiles_x;
+    const int img = b / a.tiles_x;
+#endif
+    const int tx0 = tx * 32, ty0 = ty * G::XR;
+    const int x0 = tx0 - 1;
+    const long long row0 = (long long)img * H;
+    const int xbase = (int)(((row0 + ty0) * W + x0) * 32);          // may be negative at the image border (then !ok)
+    const int gbase = (int)(((row0 + ty0 - 1) * W + tx0) * 32);
+#pragma unroll
+    for (int j = 0; j < G::NXJ; ++j) {
+        const bool ok = (unsigned)(ty0 + x_py[j]) < (unsigned)H && (unsigned)(x0 + x_px[j]) < (unsigned)W;
+        o.xvo[j] = ok ? (unsigned)(xbase + x_src[j]) : 0x80000000u;
+    }
+#pragma unroll
+    for (int j = 0; j < G::NGJ; ++j) {
+        const bool ok = (wave + 8 * j < G::GP) && (unsigned)(ty0 - 1 + wave + 8 * j) < (unsigned)H && (tx0 + g_px < W);
+        o.gvo[j] = ok ? (unsigned)(gbase + g_src[j]) : 0x80000000u;
+    }
+}
+template <int NT>
+__device__ __forceinline__ void wg3x_issue_part(const WgradKArgs& a, char* stage, const int PL, const int HH, int cp, int cot,
+                                                int wave, const Wg3xTile<NT>& o, long long plane_elems, unsigned plane_bytes) {
+    using G = Wg3xCfg<NT>;
+    const int c = 2 * cp + HH;
+    const _Float16* xb = PL ? a.x_lo : a.x_hi;
+    const long long coff = (a.x_cpg > 0)
+        ? (long long)(c / a.x_cpg) * a.x_group_stride + (long long)(c % a.x_cpg) * plane_elems
+        : (long long)c * plane_elems;
+    const bool have = c < a.cin_chunks;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(have ? xb + coff : xb), 0,
+                                                                  have ? plane_bytes : 0u, 0x00020000);
+    char* lds = stage + PL * G::PLANE + HH * G::XS;
+#pragma unroll
+    for (int j = 0; j < G::NXJ; ++j)
+        if (wave + 8 * j < G::XP)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(lds + (wave + 8 * j) * 1024), 16, o.xvo[j], 0, 0, 0);
+    const int gc = 2 * cot + HH;
+    const bool haveg = gc < a.cout_chunks;
+    const _Float16* gb = PL ? a.g_lo : a.g_hi;
+    __amdgpu_buffer_rsrc_t gs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(haveg ? gb + (long long)gc * plane_elems : gb), 0, haveg ? plane_bytes : 0u, 0x00020000);
+    char* ldg = stage + PL * G::PLANE + G::G0 + HH * G::GS;
+#pragma unroll
+    for (int j = 0; j < G::NGJ; ++j)
+        if (wave + 8 * j < G::GP)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(gs, (lds_void_t*)(ldg + (wave + 8 * j) * 1024), 16, o.gvo[j], 0, 0, 0);
+}
+template <int NT>
+__device__ __forceinline__ void wg3x_issue_all(const WgradKArgs& a, char* stage, int cp, int cot, int wave,
+                                               const Wg3xTile<NT>& o, long long plane_elems, unsigned plane_bytes) {
+    wg3x_issue_part<NT>(a, stage, 0, 0, cp, cot, wave, o, plane_elems, plane_bytes);
+    wg3x_issue_part<NT>(a, stage, 0, 1, cp, cot, wave, o, plane_elems, plane_bytes);
+    if constexpr (NT == 3) {
+        wg3x_issue_part<NT>(a, stage, 1, 0, cp, cot, wave, o, plane_elems, plane_bytes);
+        wg3x_issue_part<NT>(a, stage, 1, 1, cp, cot, wave, o, plane_elems, plane_bytes);
+    }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(512)
+wgrad3x3_xrow_kernel(const WgradKArgs a) {
+    using G = Wg3xCfg<NT>;
+    constexpr int NTAP = 9, NSTEP = 2 * NTAP;
+    constexpr int NA = (NT == 3) ? 4 : 2;                                // read instructions of one fragment (pair x planes)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // = X row of the 8-row tile
+    int pb, cp, bz;
+    wg_block(a, pb, cp, bz);
+    const int cot = bz % a.ncot;
+    const int W = a.W;
+    const long long plane_elems = (long long)a.N * a.H * W * 16;
+    const unsigned plane_bytes = (unsigned)(plane_elems * 2);
+    const bool do_bias = (cp == 0);
+
+    floatx16 acc[NTAP];
+    float bsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    // ---- tile-invariant per-lane state: the two 4-pixel reads of the X fragment of column shift dx (K-step 0, hi plane)
+    unsigned xa[3], xb2[3];
+    {
+        const int tt = lane & 15, ch = (lane >> 4) & 1, kg = lane >> 5;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int p0 = wave * G::PW + dx;
+            const int pa = p0 + kg * 8 + (tt >> 2), pb4 = pa + 4;
+            const unsigned base = (unsigned)(ch * G::XS + ((tt & 1) << 3));
+            xa[dx] = base + pa * 32 + ((((tt & 3) >> 1) ^ ((pa >> 3) & 1)) << 4);
+            xb2[dx] = base + pb4 * 32 + ((((tt & 3) >> 1) ^ ((pb4 >> 3) & 1)) << 4);
+        }
+    }
+    // gY patch row `wave` (= image row r - 2); tap dy multiplies patch row wave + 2 - dy (an immediate)
+    const unsigned g_off = (unsigned)G::G0 + tr_lane_off(G::GS, lane) + wave * 32 * 32;
+    int x_py[G::NXJ], x_px[G::NXJ], x_src[G::NXJ], g_src[G::NGJ];
+#pragma unroll
+    for (int j = 0; j < G::NXJ; ++j) {
+        const int q = (wave + 8 * j) * 64 + lane;
+        const int p = q >> 1, sh = q & 1;
+        const bool in_patch = (wave + 8 * j < G::XP) && (p < G::XR * G::PW);
+        x_py[j] = in_patch ? p / G::PW : -(1 << 20);                       // out-of-patch lanes fail the range check
+        x_px[j] = p % G::PW;
+        x_src[j] = (x_py[j] * W + x_px[j]) * 32 + ((sh ^ ((p >> 3) & 1)) << 4);
+    }
+    const int g_px = lane >> 1;
+#pragma unroll
+    for (int j = 0; j < G::NGJ; ++j)
+        g_src[j] = ((wave + 8 * j) * W + g_px) * 32 + (((lane & 1) ^ ((g_px >> 3) & 1)) << 4);
+
+#if BINHIP_WG3_STRIDE_WALK
+    int tile = pb;
+    const int tend = a.ntiles, tstep = a.PB;
+#else
+    int tile = (int)(((long long)pb * a.ntiles) / a.PB);
+    const int tend = (int)(((long long)(pb + 1) * a.ntiles) / a.PB), tstep = 1;
+#endif
+    Wg3xTile<NT> to;
+    if (tile < tend && !(a.dbg & 1)) {
+        wg3x_offsets<NT>(a, tile, wave, x_py, x_px, x_src, g_px, g_src, to);
+        wg3x_issue_all<NT>(a, smem, cp, cot, wave, to, plane_elems, plane_bytes);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (; tile < tend; tile += tstep) {
+        const int nxt = tile + tstep;
+        // The next tile's DMA is NOT issued in one burst here: a wave executes in order, and a burst of buffer_load ... lds
+        // sits at the head of its instruction stream until the memory pipeline has accepted all of it — with one workgroup
+        // per CU nobody multiplies meanwhile, and prefetch and multiply ran one after the other (tools/bench_wgrad.py: DMA
+        // alone 110 us + MFMAs and reads alone 119 us = 214 us measured, 160 -> 32 channels).  One (plane, chunk) group of DMA
+        // instructions goes out behind the MFMAs of steps 1, 5, 9 and 13 instead.
+        const bool pre = nxt < tend && !(a.dbg & 1);
+        if (pre) wg3x_offsets<NT>(a, nxt, wave, x_py, x_px, x_src, g_px, g_src, to);
+        char* const stage_nxt = smem + (cur ^ 1) * G::STAGE;
+#if BINHIP_WG3_SPREAD_DMA == 0
+        if (pre) wg3x_issue_all<NT>(a, stage_nxt, cp, cot, wave, to, plane_elems, plane_bytes);
+#endif
+        if (!(a.dbg & 2)) {
+            const unsigned st = lds_addr(smem + cur * G::STAGE);
+            TrFrag Bh[2], Bl[2], Ah[3], Al[3];
+            auto load = [&](auto SC) {
+                constexpr int s = decltype(SC)::value, ks = s / NTAP, dy = (s % NTAP) / 3, dx = s % 3;
+#if BINHIP_TUNING
+                if (a.dbg & 8) return;                 // ablation: MFMAs on stale registers, no LDS fragment reads
+#endif
+                if constexpr (dx == 0) {
+                    constexpr int bb = (ks * 3 + dy) & 1, off = ks * 512 + (2 - dy) * 1024;
+                    tr_issue_pair<off>(Bh[bb], st + g_off, st + g_off + 128);
+                    if constexpr (NT == 3) tr_issue_pair<off + G::PLANE>(Bl[bb], st + g_off, st + g_off + 128);
+                }
+                if constexpr (dy == 0) {
+                    tr_issue_pair<ks * 512>(Ah[dx], st + xa[dx], st + xb2[dx]);
+                    if constexpr (NT == 3) tr_issue_pair<ks * 512 + G::PLANE>(Al[dx], st + xa[dx], st + xb2[dx]);
+                }
+            };
+            load(std::integral_constant<int, 0>{});
+            load(std::integral_constant<int, 1>{});
+            static_for([&](auto SC) {
+                constexpr int s = decltype(SC)::value, ks = s / NTAP, dy = (s % NTAP) / 3, dx = s % 3, t = dy * 3 + dx;
+                constexpr int bb = (ks * 3 + dy) & 1;
+                // outstanding: the reads of steps s and s + 1, in issue order -> leave step s + 1's in flight
+                constexpr int s1 = s + 1;
+                constexpr int later = (s1 < NSTEP) ? NA * ((s1 % 3 == 0 ? 1 : 0) + ((s1 % NTAP) / 3 == 0 ? 1 : 0)) : 0;
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(later) : "memory");
+                if constexpr (dy == 0) {
+                    tr_tie(Ah[dx]);
+                    if constexpr (NT == 3) tr_tie(Al[dx]);
+                }
+                if constexpr (dx == 0) {
+                    tr_tie(Bh[bb]);
+                    if constexpr (NT == 3) tr_tie(Bl[bb]);
+                }
+                if constexpr (s + 2 < NSTEP) load(std::integral_constant<int, s + 2>{});
+                __builtin_amdgcn_sched_barrier(0);
+                const half8 bh = tr_value(Bh[bb]);
+                half8 bl;
+                if constexpr (NT == 3) bl = tr_value(Bl[bb]);
+                if (dy == 1 && dx == 0 && do_bias) {           // patch row wave + 1 = the wave's own image row: once per gY row
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        bsum += (float)bh[e];
+                        if constexpr (NT == 3) bsum += (float)bl[e];
+                    }
+                }
+                const half8 ah = tr_value(Ah[dx]);
+                if constexpr (NT == 3) {
+                    const half8 al = tr_value(Al[dx]);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
+                }
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+#if BINHIP_WG3_SPREAD_DMA
+                if constexpr (s % 4 == 1 && s / 4 < (NT == 3 ? 4 : 2)) {
+                    constexpr int grp = s / 4;           // (plane, chunk) = (0,0) (0,1) (1,0) (1,1)
+                    if (pre) wg3x_issue_part<NT>(a, stage_nxt, grp / 2, grp % 2, cp, cot, wave, to, plane_elems, plane_bytes);
+                }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            }, std::make_integer_sequence<int, NSTEP>{});
+        } else if (BINHIP_WG3_SPREAD_DMA && pre) {
+            wg3x_issue_all<NT>(a, stage_nxt, cp, cot, wave, to, plane_elems, plane_bytes);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1615,6 +1917,15 @@ int launch_wg_sb(const WgradKArgs& a, const WgGeom& g, hipStream_t s) {
 }
 
 template <int NT>
+int launch_wg3x(const WgradKArgs& a, const WgGeom& g, hipStream_t s) {
+    static std::atomic<unsigned long long> lds_set{0};
+    if (int rc = bh_set_max_lds(&wgrad3x3_xrow_kernel<NT>, Wg3xCfg<NT>::LDS_BYTES, lds_set)) return rc;
+    wgrad3x3_xrow_kernel<NT><<<dim3((unsigned)(g.PB * g.ncp * g.ncot * g.ndyg)), dim3(512), Wg3xCfg<NT>::LDS_BYTES, s>>>(a);
+    BH_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int NT>
 int launch_wg3(const WgradKArgs& a, const WgGeom& g, hipStream_t s) {
     using C = WgCfg<3, 3, NT>;
     static std::atomic<unsigned long long> lds_set{0};
@@ -1760,7 +2071,10 @@ int bh_wgrad_partials(const BinConvDesc* d, const void* x_hi, const void* x_lo, 
         a.cgroups = rp.cgroups;
         rc = (d->nterms == 1) ? launch_r3<1>(a, g, rp, s) : launch_r3<3>(a, g, rp, s);
 #endif
-    } else if (d->ksize == 3) {                     // eight waves, two LDS stages, one workgroup per CU
+    } else if (d->ksize == 3 && ((BINHIP_WG3_XROW != 0) != (((WG_DBG >> 16) & 1) != 0))) {
+        // eight waves, two LDS stages, one workgroup per CU; wave = X row (tuning builds: debug bit 16 flips the choice)
+        rc = (d->nterms == 1) ? launch_wg3x<1>(a, g, s) : launch_wg3x<3>(a, g, s);
+    } else if (d->ksize == 3) {                     // the same with wave = gY row (round 2)
         rc = (d->nterms == 1) ? launch_wg3<1>(a, g, s) : launch_wg3<3>(a, g, s);
     } else if (d->ksize == 1) {                     // 1x1 with more than 96 outputs (not on the bin_stage4 path)
         rc = (d->nterms == 1) ? launch_wg<1, 1, 1>(a, g, s) : launch_wg<1, 1, 3>(a, g, s);

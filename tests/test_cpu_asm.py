@@ -27,6 +27,8 @@ def test_asm_transpose_reads_are_waited_for(tmp_path):
     assert kernels == 4 and n_reads > 100 and not bad, (kernels, n_reads, bad[:5])
     bad, kernels, n_reads = check(str(out), "wgrad3x3_db_kernel")     # the 3x3 kernel: 80 (f16x3) + 40 (f16) reads per tile
     assert kernels == 2 and n_reads == 120 and not bad, (kernels, n_reads, bad[:5])
+    bad, kernels, n_reads = check(str(out), "wgrad3x3_xrow_kernel")   # wave = X row (round 3): 48 + 24 reads per tile
+    assert kernels == 2 and n_reads == 72 and not bad, (kernels, n_reads, bad[:5])
     # and the reason for the asm: no compiler-inserted vmcnt(0) between the prefetch DMA and the fragment reads of a stage
     text = out.read_text()
     for name in ("_Z15wgrad1x1_kernelILi3ELi1ELi2EEv10WgradKArgs", "_Z15wgrad1x1_kernelILi3ELi2ELi1EEv10WgradKArgs"):

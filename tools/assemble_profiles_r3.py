@@ -15,7 +15,7 @@ G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 DOM_X3 = "conv_x3_kernel<3, 2, 8, 0, 0, false>"
 DOM_F16 = "conv_mfma_kernel<3, 1, 1, 2, 8, 1, 1, 2, 0, false>"
-WG3 = "wgrad3x3_db_kernel<3>"
+WG3 = "wgrad3x3_xrow_kernel<3>"
 
 
 def read(name):

@@ -12,8 +12,9 @@ g = torch.Generator().manual_seed(0)
 lib = L.lib()
 LAYERS = [tuple(int(v) for v in l.split(",")) for l in os.environ.get("WG_LAYERS", "3,96,32;3,160,32;3,192,32;3,96,96").split(";")]
 for ks, cin, cout in LAYERS:
-    x = ops.nchw_to_planes((torch.rand(n, cin, h, w, generator=g) - 0.3).to(dev), 3)
-    gy = ops.nchw_to_planes((torch.rand(n, cout, h, w, generator=g) - 0.5).to(dev), 3)
+    zero = 0.0 if os.environ.get("WG_ZERO") == "1" else 1.0          # all-zero operands: same instruction stream, idle datapaths
+    x = ops.nchw_to_planes(((torch.rand(n, cin, h, w, generator=g) - 0.3) * zero).to(dev), 3)
+    gy = ops.nchw_to_planes(((torch.rand(n, cout, h, w, generator=g) - 0.5) * zero).to(dev), 3)
     row = []
     for dbg in DBGS:
         if hasattr(lib, "binhip_wgrad_set_debug"):

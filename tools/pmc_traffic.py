@@ -50,7 +50,7 @@ def main():
         except Exception:
             doc = {}
         want = {"f16x3": "conv_x3_kernel<3, 2, 8, 0, 0, false>", "f16": "conv_mfma_kernel<3, 1, 1, 2, 8, 1, 1, 2, 0, false>",
-                "wgrad3x3": "wgrad3x3_db_kernel<3>"}[key]          # the dominant kernel of the profiled run
+                "wgrad3x3": "wgrad3x3_xrow_kernel<3>"}[key]          # the dominant kernel of the profiled run
         dom = [k for k in rows if want in k]
         doc[key] = {"kernel": dom[0] if dom else None,
                     "traffic_bytes_per_launch": int(rows[dom[0]]["traffic_MB"] * 1e6) if dom else None,
