@@ -1,5 +1,5 @@
 """Run ONE conv layer class a few times (for rocprofv3 --pmc / --kernel-trace passes on a single kernel).
-usage: pmc_one.py [rdb|tail] [nterms] [cin] [variant]   (variant needs BIN_AMD_LIB=tools/_abl/libbinhip_tuning.so)"""
+usage: pmc_one.py [rdb|tail|wgrad] [nterms] [cin] [variant]   (variant needs BIN_AMD_LIB=tools/_abl/libbinhip_tuning.so)"""
 import ctypes as C
 import os
 import sys
@@ -29,6 +29,10 @@ elif which == "tail":
     f = lambda: L.check(lib.binhip_rdb_tail_fwd(n, h, w, nt, p(x.hi), p(x.lo), p(cw3.w_hi), p(cw3.w_lo), p(cw3.bias),
                                                 p(cwl.w_hi), p(cwl.w_lo), p(cwl.bias), p(y.hi), p(y.lo), 0, None,
                                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)), "tail")
+elif which == "wgrad":          # 3x3 weight gradient cin -> 32 on the training working size (40 x 128 x 128)
+    xs = ops.nchw_to_planes((torch.rand(40, cin, 128, 128, generator=g) - 0.3).to(dev), nt)
+    gy = ops.nchw_to_planes((torch.rand(40, 32, 128, 128, generator=g) - 0.5).to(dev), nt)
+    f = lambda: ops.conv2d_bwd_weight(xs, gy, 32, cin, 3, nt)
 else:
     raise SystemExit("unknown")
 for _ in range(10):
