@@ -30,6 +30,7 @@ BIN_AMD_WGRAD_STREAM=0 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --o
 BIN_AMD_WGRAD_STREAM=0 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_tw -- $PT > /dev/null 2>&1
 python tools/pmc_traffic.py /tmp/pmc_tf /tmp/pmc_tw --json ${T}_pmc_traffic.json --key wgrad3x3 > ${T}_pmc_traffic_train.md
 find gpurun_out/prof_r3 -name "*kernel_trace.csv" -delete
+cp ${T}_pmc_traffic.json profiles/r03_pmc_traffic.json   # the bench lines below quote THIS run's PMC traffic (box-local copy)
 ( timeout 900 python bench.py --steps 20 --warmup 5 2>&1 | tail -1 ) > ${T}_bench.json 2>&1
 ( timeout 300 python bench.py --mode train 2>&1 | tail -1 ) > ${T}_bench_train.json 2>&1
 head -12 ${T}_stats_x3.md; head -8 ${T}_stats_train.md; head -8 ${T}_pmc_traffic_f16x3.md; head -8 ${T}_pmc_traffic_train.md
