@@ -254,6 +254,11 @@ def train_bench(args, rank, world, dev, steps=None, warmup=None, standalone=True
     B, S = args.batch, 256
     batch = {"LQs": torch.rand(B, 6, 3, S, S, generator=g), "GTenh": torch.rand(B, 6, 3, S, S, generator=g),
              "GTinp": torch.rand(B, 5, 3, S, S, generator=g)}
+    if args.zero_data:                       # diagnostic (invalid as a result): the same launches on all-zero operands
+        batch = {k: torch.zeros_like(v) for k, v in batch.items()}
+        with torch.no_grad():
+            for prm in m.netG.module.parameters():
+                prm.zero_()
     m.feed_data(batch)
 
     def sync_all():
@@ -317,7 +322,8 @@ def train_bench(args, rank, world, dev, steps=None, warmup=None, standalone=True
         "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": round(dt / steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": DTYPE[prec] + (" forward; single-product backward on the hi planes" if bwd_prec else ""),
-        "data": "synthetic", "loss": float(m.loss.detach()),
+        "data": ("all-zero operands (diagnostic, INVALID as a result)" if args.zero_data else "synthetic"),
+        "loss": float(m.loss.detach()),
         "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2),
         "nccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1),
         "backend": (dist.get_backend() if dist.is_initialized() else None),
@@ -650,7 +656,7 @@ def main():
             "unit": "interpolated frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE[prec],
-            "data": "synthetic",
+            "data": ("all-zero operands (diagnostic, INVALID as a result)" if args.zero_data else "synthetic"),
             "config": {"workload": "Adobe240 test_blur 1280x720 inference, batch=1 per GPU "
                                    "(6-frame window padded to 768x1344 by the test.py rule), window-sharded",
                        "schedule": "17 RDN calls + 6 ConvLSTM cells (exact reuse)" if net.reuse_schedule
