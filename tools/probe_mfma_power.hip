@@ -7,6 +7,8 @@
 //   6  32x32x16, both operands change on every MFMA (mode 0 keeps B for 4 consecutive MFMAs)
 //   7  32x32x16, A half zeros (post-ReLU), B = weights (+-1/38): mode 3 with the operands swapped
 //   8  32x32x16, both operands half zeros
+//   9  v_mfma_i32_32x32x32_i8, random int8 operands (ops counted like flops)      10  the same, all-zero operands
+//  11  i8, B half zeros (post-ReLU magnitudes), A = small signed "weight" bytes
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
@@ -14,6 +16,8 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef int intx4 __attribute__((ext_vector_type(4)));
+typedef int intx16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float u01(unsigned x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
@@ -44,7 +48,41 @@ __global__ void __launch_bounds__(256) probe(int iters, float* out) {
         B[i] = frag(lane_seed + 16 + i, MODE, true);
     }
     float sum = 0.f;
-    if constexpr (MODE == 1 || MODE == 5) {
+    if constexpr (MODE >= 9 && MODE <= 11) {
+        intx4 Ai[4], Bi[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned ra = 0, rb = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    int va = (int)(255.f * u01((lane_seed + i) * 64u + e * 4 + b)) - 128;
+                    int vb = (int)(255.f * u01((lane_seed + 16 + i) * 64u + e * 4 + b)) - 128;
+                    if (MODE == 10) va = vb = 0;
+                    if (MODE == 11) { vb = vb < 0 ? 0 : vb; va = va / 8; }
+                    ra |= (unsigned)(va & 0xff) << (8 * b);
+                    rb |= (unsigned)(vb & 0xff) << (8 * b);
+                }
+                Ai[i][e] = (int)ra; Bi[i][e] = (int)rb;
+            }
+        intx16 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0;
+#pragma unroll 1
+        for (int it = 0; it < iters; ++it) {
+            // 16 MFMAs of 32x32x32 = twice the multiply-adds of 16 MFMAs of 32x32x16
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(Ai[i], Bi[j], acc[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sum += (float)(acc[i][0] + acc[i][15]);
+    } else if constexpr (MODE == 1 || MODE == 5) {
         floatx4 acc[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -103,12 +141,15 @@ int main(int argc, char** argv) {
             case 5: probe<5><<<blocks, 256>>>(iters, out); break;
             case 6: probe<6><<<blocks, 256>>>(iters, out); break;
             case 7: probe<7><<<blocks, 256>>>(iters, out); break;
+            case 9: probe<9><<<blocks, 256>>>(iters, out); break;
+            case 10: probe<10><<<blocks, 256>>>(iters, out); break;
+            case 11: probe<11><<<blocks, 256>>>(iters, out); break;
             default: probe<8><<<blocks, 256>>>(iters, out); break;
         }
     };
     launch();
     hipDeviceSynchronize();
-    const double flop_per_launch = (double)blocks * 4 * iters * 16 * 2.0 * 32 * 32 * 16;
+    const double flop_per_launch = (double)blocks * 4 * iters * 16 * 2.0 * 32 * 32 * 16 * (mode >= 9 && mode <= 11 ? 2 : 1);
     auto t0 = std::chrono::steady_clock::now();
     double t_half = 0; long n = 0, n_half = 0;
     for (;;) {
