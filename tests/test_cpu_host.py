@@ -229,6 +229,43 @@ def test_three_training_steps_match_reference_golden(tmp_path):
             assert float((named[key[7:]].detach() - T(g[key])).abs().max()) <= 5e-6, key
 
 
+def _crit(kind):
+    """torch's own criteria, as the reference builds them (bin_model.py:52-60) — for the CPU run of OUR wrapper."""
+    return {"cb": _Cb(), "l1": torch.nn.L1Loss(reduction="sum"), "l2": torch.nn.MSELoss(reduction="sum")}[kind]
+
+
+@pytest.mark.parametrize("tag,version,crit,weight", __import__("loss_variants").VARIANTS)
+def test_loss_variants_match_reference_wrapper(tmp_path, tag, version, crit, weight):
+    """The other branches of the reference's loss (g11_loss_variants, tests/golden/make_golden_loss_variants.py): no cycle
+    terms unless version == 2, the 'l1' / 'l2' sum criteria, pixel_weight — one optimize_parameters() of OUR wrapper (CPU
+    generator) against the reference wrapper's."""
+    from bin_amd.models.bin_model import bin_model
+    from bin_amd.weights import reference_state_dict
+    from oracle_net import OracleNet
+    g = load_golden("g11_loss_variants")
+    opt = _opt(tmp_path)
+    opt["network_G"]["version"] = version
+    opt["train"]["pixel_criterion"], opt["train"]["pixel_weight"] = crit, weight
+    net = OracleNet()
+    net.load_state_dict(reference_state_dict(0), strict=True)
+    m = bin_model(opt, netG=net, cri_pix=_crit(crit))
+    m.feed_data({"LQs": T(g["LQs"]), "GTenh": T(g["GTenh"]), "GTinp": T(g["GTinp"]), "key": "x"})
+    m.optimize_parameters(1)
+    ref = float(g[tag + ".loss"])
+    assert abs(float(m.loss) - ref) <= 2e-6 * max(1.0, abs(ref)), (float(m.loss), ref)
+    assert len(m.loss_list) == 14
+    ll = np.array([float(l) for l in m.loss_list])
+    assert np.abs(ll - g[tag + ".loss_list"]).max() <= 2e-6 * max(1.0, np.abs(g[tag + ".loss_list"]).max())
+    named = dict(m.netG.module.named_parameters())
+    assert [str(n) for n in g["names"]] == list(named.keys())
+    norms = np.array([float(p.grad.double().norm()) if p.grad is not None else 0.0 for p in named.values()])
+    refn = g[tag + ".grad_norms"]
+    assert (np.abs(norms - refn) / (np.abs(refn) + 1e-8 * refn.max())).max() <= 2e-3
+    for key in g.files:
+        if key.startswith(tag + ".after."):
+            assert float((named[key[len(tag) + 7:]].detach() - T(g[key])).abs().max()) <= 2e-6, key
+
+
 def test_wrapper_api_surface(tmp_path):
     m = _cpu_model(tmp_path)
     for name in ("feed_data", "test_set_input", "test", "forward", "test_forward", "optimize_parameters", "get_loss",

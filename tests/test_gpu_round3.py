@@ -207,6 +207,36 @@ def test_bench_two_ranks_training_line_reduces_gradients_across_ranks():
     assert np.isfinite(d["loss"]) and d["roofline"]["dominant_kernel"]["launches"] > 0
 
 
+@pytest.mark.parametrize("tag,version,crit,weight", __import__("loss_variants").VARIANTS)
+def test_loss_variants_match_reference_wrapper_on_the_gpu(tmp_path, tag, version, crit, weight):
+    """g11_loss_variants (reference wrapper: version 1 / 2, 'cb' / 'l1' / 'l2', pixel_weight): one optimize_parameters() with
+    the HIP network and the device-side criteria — loss, the 14 terms, all 540 gradient norms, sampled post-Adam values."""
+    from bin_amd.models import create_model
+    from bin_amd.weights import reference_state_dict
+    from conftest import load_golden
+    g = load_golden("g11_loss_variants")
+    opt = _train_opt(tmp_path)
+    opt["network_G"]["version"] = version
+    opt["train"]["pixel_criterion"], opt["train"]["pixel_weight"] = crit, weight
+    m = create_model(opt)
+    m.netG.module.load_state_dict(reference_state_dict(0), strict=True)
+    m.feed_data({"LQs": torch.from_numpy(g["LQs"]), "GTenh": torch.from_numpy(g["GTenh"]), "GTinp": torch.from_numpy(g["GTinp"])})
+    m.optimize_parameters(1)
+    ref = float(g[tag + ".loss"])
+    assert abs(float(m.loss) - ref) <= 4e-6 * max(1.0, abs(ref)), (float(m.loss), ref)
+    ll = np.array([float(l) for l in m.loss_list])
+    assert len(ll) == 14 and np.abs(ll - g[tag + ".loss_list"]).max() <= 4e-6 * max(1.0, np.abs(g[tag + ".loss_list"]).max())
+    named = dict(m.netG.module.named_parameters())
+    norms = np.array([float(p.grad.double().norm()) if p.grad is not None else 0.0 for p in named.values()])
+    refn = g[tag + ".grad_norms"]
+    rel = np.abs(norms - refn) / (np.abs(refn) + 1e-6 * refn.max())
+    assert rel.max() <= 5e-3, (list(named.keys())[int(rel.argmax())], float(rel.max()))
+    for key in g.files:
+        if key.startswith(tag + ".after."):
+            d = (named[key[len(tag) + 7:]].detach().cpu() - torch.from_numpy(g[key])).abs()
+            assert float(d.mean()) <= 2e-6 and float((d > 5e-5).float().mean()) <= 0.01, (key, float(d.mean()), float(d.max()))
+
+
 # ------------------------------------------------------------------------------------------------ fp16 headroom
 def test_fp16_headroom_of_stored_planes_before_and_after_training_steps(tmp_path):
     """Every stored activation and gradient plane stays >= 8x below the fp16 limit — on the seeded init AND on weights
