@@ -64,12 +64,17 @@ class VideoBaseModel(BaseModel):
             raise NotImplementedError("Loss type [{:s}] is not recognized.".format(kind))
         self.l_pix_w = train_opt["pixel_weight"]
 
-        params = []
+        trainable = []
         for name, p in self.netG.named_parameters():
             if p.requires_grad:
-                params.append(p)
+                trainable.append((name, p))
             elif self.rank <= 0:
                 logger.warning("Params [%s] will not optimize.", name)
+        if _get(train_opt, "ft_tsa_only"):      # Video_base_model.py:61-83: normal parameters first, 'tsa_fusion' second
+            params = [{"params": [p for n, p in trainable if "tsa_fusion" not in n], "lr": train_opt["lr_G"]},
+                      {"params": [p for n, p in trainable if "tsa_fusion" in n], "lr": train_opt["lr_G"]}]
+        else:
+            params = [p for _, p in trainable]
         self.optimizer_G = torch.optim.Adam(params, lr=train_opt["lr_G"], weight_decay=_get(train_opt, "weight_decay_G", 0),
                                             betas=(train_opt["beta1"], train_opt["beta2"]))
         self.optimizers.append(self.optimizer_G)

@@ -254,12 +254,19 @@ class bin_model(BaseModel):
             self.l_pix_w = train_opt["pixel_weight"]
 
             wd_G = _get(train_opt, "weight_decay_G", 0)
-            optim_params = []
+            trainable = []
             for k, v in self.netG.named_parameters():
                 if v.requires_grad:
-                    optim_params.append(v)
+                    trainable.append((k, v))
                 elif self.rank <= 0:
                     logger.warning("Params [{:s}] will not optimize.".format(k))
+            if _get(train_opt, "ft_tsa_only"):
+                # bin_model.py:66-87: two groups — everything first, then the 'tsa_fusion' parameters (bin_stage4 has none, so
+                # the second group is empty): set_params_lr_zero() freezes group 0, and `.state` files carry both groups
+                optim_params = [{"params": [v for k, v in trainable if "tsa_fusion" not in k], "lr": train_opt["lr_G"]},
+                                {"params": [v for k, v in trainable if "tsa_fusion" in k], "lr": train_opt["lr_G"]}]
+            else:
+                optim_params = [v for _, v in trainable]
             self.optimizer_G = torch.optim.Adam(optim_params, lr=train_opt["lr_G"], weight_decay=wd_G,
                                                 betas=(train_opt["beta1"], train_opt["beta2"]))
             self.optimizers.append(self.optimizer_G)

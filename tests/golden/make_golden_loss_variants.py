@@ -58,5 +58,28 @@ for tag, version, crit, weight in VARIANTS:
     for n in SAMPLE:
         out[tag + ".after." + n] = named[n].detach().numpy().copy()
     print(tag, "loss", out[tag + ".loss"], "terms", len(model.loss_list))
+# ft_tsa_only = 3 (bin_model.py:66-87,131-132): two parameter groups (the second one empty for bin_stage4), steps 1 and 2 run
+# with group 0's rate forced to zero, step 3 trains — parameters must not move before step 3
+opt["network_G"]["version"], opt["train"]["pixel_criterion"], opt["train"]["pixel_weight"] = 2, "cb", 1.0
+opt["train"]["ft_tsa_only"] = 3
+model = create_model(opt)
+model.netG.module.load_state_dict(reference_state_dict(0), strict=True)
+named = dict(model.netG.module.named_parameters())
+probe = "model.model4_1.UPNet.2.weight"
+before = named[probe].detach().clone()
+moved = []
+for step in (1, 2, 3):
+    if step == 3:                                   # what a training loop does before the step it un-freezes (update_learning_rate)
+        for grp in model.optimizer_G.param_groups:
+            grp["lr"] = opt["train"]["lr_G"]
+    model.feed_data(batch)
+    model.optimize_parameters(step)
+    moved.append(float((named[probe].detach() - before).abs().max()))
+sd = model.optimizer_G.state_dict()
+out["ft.group_sizes"] = np.array([len(gp["params"]) for gp in sd["param_groups"]])
+out["ft.moved"] = np.array(moved)
+out["ft.loss3"] = np.float64(float(model.loss.detach()))
+out["ft.after3"] = named[probe].detach().numpy().copy()
+print("ft_tsa_only: groups", out["ft.group_sizes"], "moved", moved)
 out["names"] = np.array(list(named.keys()))
 np.savez_compressed(os.path.join(HERE, "g11_loss_variants.npz"), **out)

@@ -266,6 +266,37 @@ def test_loss_variants_match_reference_wrapper(tmp_path, tag, version, crit, wei
             assert float((named[key[len(tag) + 7:]].detach() - T(g[key])).abs().max()) <= 2e-6, key
 
 
+def test_ft_tsa_only_freezes_group_zero_like_the_reference(tmp_path):
+    """train.ft_tsa_only = 3 (bin_model.py:66-87,131-132): the optimizer gets the reference's TWO parameter groups (all 540
+    tensors, then the empty 'tsa_fusion' group — the layout `.state` files carry), steps 1 and 2 run with group 0's rate at
+    zero, step 3 trains with Adam moments that already saw three gradients.  Fixture g11_loss_variants ('ft.*')."""
+    from bin_amd.models.bin_model import bin_model
+    from bin_amd.weights import reference_state_dict
+    from oracle_net import OracleNet
+    g = load_golden("g11_loss_variants")
+    opt = _opt(tmp_path)
+    opt["train"]["ft_tsa_only"] = 3
+    net = OracleNet()
+    net.load_state_dict(reference_state_dict(0), strict=True)
+    m = bin_model(opt, netG=net, cri_pix=_Cb())
+    sd = m.optimizer_G.state_dict()
+    assert [len(gp["params"]) for gp in sd["param_groups"]] == list(g["ft.group_sizes"]) == [540, 0]
+    named = dict(m.netG.module.named_parameters())
+    probe = "model.model4_1.UPNet.2.weight"
+    before = named[probe].detach().clone()
+    batch = {"LQs": T(g["LQs"]), "GTenh": T(g["GTenh"]), "GTinp": T(g["GTinp"]), "key": "x"}
+    for step in (1, 2, 3):
+        if step == 3:
+            for grp in m.optimizer_G.param_groups:
+                grp["lr"] = opt["train"]["lr_G"]
+        m.feed_data(batch)
+        m.optimize_parameters(step)
+        moved = float((named[probe].detach() - before).abs().max())
+        assert (moved == 0.0) == (step < 3) and abs(moved - float(g["ft.moved"][step - 1])) <= 1e-6
+    assert abs(float(m.loss) - float(g["ft.loss3"])) <= 2e-6
+    assert float((named[probe].detach() - T(g["ft.after3"])).abs().max()) <= 2e-6
+
+
 def test_wrapper_api_surface(tmp_path):
     m = _cpu_model(tmp_path)
     for name in ("feed_data", "test_set_input", "test", "forward", "test_forward", "optimize_parameters", "get_loss",

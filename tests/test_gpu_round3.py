@@ -237,6 +237,35 @@ def test_loss_variants_match_reference_wrapper_on_the_gpu(tmp_path, tag, version
             assert float(d.mean()) <= 2e-6 and float((d > 5e-5).float().mean()) <= 0.01, (key, float(d.mean()), float(d.max()))
 
 
+def test_ft_tsa_only_freezes_group_zero_on_the_gpu(tmp_path):
+    """g11_loss_variants 'ft.*' (reference wrapper, train.ft_tsa_only = 3) with the HIP network: the reference's two
+    parameter groups, no parameter moves in steps 1-2, step 3 reproduces the reference's loss and update."""
+    from bin_amd.models import create_model
+    from bin_amd.weights import reference_state_dict
+    from conftest import load_golden
+    g = load_golden("g11_loss_variants")
+    opt = _train_opt(tmp_path)
+    opt["train"]["ft_tsa_only"] = 3
+    m = create_model(opt)
+    m.netG.module.load_state_dict(reference_state_dict(0), strict=True)
+    assert [len(gp["params"]) for gp in m.optimizer_G.state_dict()["param_groups"]] == [540, 0]
+    named = dict(m.netG.module.named_parameters())
+    probe = "model.model4_1.UPNet.2.weight"
+    before = named[probe].detach().clone()
+    batch = {"LQs": torch.from_numpy(g["LQs"]), "GTenh": torch.from_numpy(g["GTenh"]), "GTinp": torch.from_numpy(g["GTinp"])}
+    for step in (1, 2, 3):
+        if step == 3:
+            for grp in m.optimizer_G.param_groups:
+                grp["lr"] = opt["train"]["lr_G"]
+        m.feed_data(batch)
+        m.optimize_parameters(step)
+        moved = float((named[probe].detach() - before).abs().max())
+        assert (moved == 0.0) == (step < 3), (step, moved)
+    assert abs(float(m.loss) - float(g["ft.loss3"])) <= 4e-6
+    d = (named[probe].detach().cpu() - torch.from_numpy(g["ft.after3"])).abs()
+    assert float(d.mean()) <= 2e-6 and float((d > 5e-5).float().mean()) <= 0.01, (float(d.mean()), float(d.max()))
+
+
 # ------------------------------------------------------------------------------------------------ fp16 headroom
 def test_fp16_headroom_of_stored_planes_before_and_after_training_steps(tmp_path):
     """Every stored activation and gradient plane stays >= 8x below the fp16 limit — on the seeded init AND on weights
