@@ -72,7 +72,11 @@ class ConvLSTMCell(nn.Module):
         self.input_size, self.hidden_size = input_size, hidden_size
         self.Gates = nn.Conv2d(input_size + hidden_size, 4 * hidden_size, kernel_size, padding=padding, bias=True)
         self._forget_bias = forget_bias
-        weight_init.xavier_uniform_(self.Gates.weight.data)      # RDN.py:26-38
+        self._initialize_weights()
+
+    def _initialize_weights(self):
+        """RDN.py:26-38: Xavier-uniform gate weights, zero bias (the cell's only conv)."""
+        weight_init.xavier_uniform_(self.Gates.weight.data)
         self.Gates.bias.data.zero_()
 
     def forward(self, input_, prev_state):

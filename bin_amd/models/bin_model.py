@@ -334,6 +334,11 @@ class bin_model(BaseModel):
     def set_params_lr_zero(self):
         self.optimizers[0].param_groups[0]["lr"] = 0
 
+    def test_sharp_forward(self):
+        """bin_model.py:382-393 interpolates from the SHARP frames for nframes 1 / 3 / 4 / 5 only; with the one generator
+        the factory builds (nframes == 6) no branch is taken and `Ft_p` is left as it was — same here."""
+        return None
+
     # ------------------------------------------------------------------ data staging (bin_model.py:147-274)
     def feed_data(self, trainData, need_GT=True):
         LQs, GTenh, GTinp = trainData["LQs"], trainData["GTenh"], trainData["GTinp"]   # B N C H W

@@ -303,7 +303,7 @@ def test_wrapper_api_surface(tmp_path):
                  "get_info", "get_current_log", "get_current_visuals", "save", "load", "reset_state",
                  "train_AverageMeter", "train_AverageMeter_update", "val_AverageMeter_para", "update_learning_rate",
                  "save_network", "load_network", "save_training_state", "resume_training", "get_current_learning_rate",
-                 "compute_current_psnr_ssim", "print_network", "get_lr", "set_params_lr_zero"):
+                 "compute_current_psnr_ssim", "print_network", "get_lr", "set_params_lr_zero", "test_sharp_forward"):
         assert callable(getattr(m, name)), name
     frames = [torch.rand(1, 3, 32, 32) for _ in range(6)]
     m.test_set_input(frames + [torch.tensor([0])])
