@@ -25,7 +25,7 @@ from .rdn_plan import c_shape, layer_names, rdn_forward, workspace
 
 # Per-module switches (attributes of the RDN sub-network objects, models/archs/RDN.py::_RDNBase — nothing here is a mutable
 # module global, so two models in one process, or two host threads, never share them):
-#   module.direct_param_grads  (the wrappers turn it on around backward() through net.direct_param_grads()): the RDN's
+#   module._direct_grads  (the wrappers turn it on around backward() through net.direct_param_grads()): the RDN's
 #       weight gradients are written / accumulated by the kernels DIRECTLY into the parameters' .grad buffers
 #       (BINHIP_BWD_ACCUMULATE) and autograd gets None for them: the four weight sets are shared by 4/3/2/1 calls, so the
 #       default path costs ~1.7 k elementwise adds per step in autograd's AccumulateGrad.  Off by default:
@@ -116,7 +116,7 @@ class _RdnFn(torch.autograd.Function):
                            if module.wgrad_side_stream and not torch.cuda.is_current_stream_capturing() else None)
         plan.profiler = module.bwd_profiler if module.bwd_profiler else None
         params = ctx.params
-        direct = module.direct_param_grads and all(ctx.needs_input_grad[3 + k:])
+        direct = module._direct_grads and all(ctx.needs_input_grad[3 + k:])
         have = False
         if direct:
             states = [p.grad is not None for p in params]

@@ -3,20 +3,26 @@
 //
 // Same arithmetic as rdb_tail_kernel<3, 2> (binhip_fused.hip): o3 = relu(conv3x3(blk[0:192]) + b3);
 // y = LFF(cat(blk[0:192], o3)) + b + blk[0:96], with every 16-channel K-stage of conv #3 also feeding the LFF
-// accumulators (the 1x1's B operand is the conv's centre-tap fragment) and the residual as an identity MFMA.
+// accumulators (the 1x1's B operand is the conv's centre-tap fragment); the residual is a VALU add from that same
+// fragment (round 4; rounds 1-3: an identity MFMA) and o3 goes from the conv accumulators to the LFF's last two K-steps
+// through registers only (round 4; before: wave-private LDS tiles).
 // That kernel stages both precision planes per K-stage (141 KB of LDS) and its 8 waves hold 8 accumulator tiles + two
 // planes of fragments (~200 VGPRs): ONE workgroup owns a whole CU, so its DMA prologue, its o3 / output epilogues and
 // every barrier wait run with the matrix pipe idle, and no kernel of another stream can share the CU.
 // Here: 4 waves (256 threads), tile 8 rows x 32 cols (wave w owns rows 2w, 2w+1: still R = 2, so every weight fragment
 // feeds two MFMAs), K-stages split by precision plane as in binhip_conv_x3.hip:
-//     hi:  conv  += Wlo*Xhi, Whi*Xhi      LFF += Llo*Xhi(centre), Lhi*Xhi(centre)   [+ identity * Xhi, chunks 0-5]
-//     lo:  conv  += Whi*Xlo               LFF += Lhi*Xlo(centre)                    [+ identity * Xlo]
+//     hi:  conv  += Wlo*Xhi, Whi*Xhi      LFF += Llo*Xhi(centre), Lhi*Xhi(centre)   [acc += Xhi(centre), chunks 0-5]
+//     lo:  conv  += Whi*Xlo               LFF += Lhi*Xlo(centre)                    [acc += Xlo(centre)]
 // LDS: patch plane 11 KB double-buffered per sub-stage + (conv 9 + LFF 3 KB) x 2 planes double-buffered per chunk
 // = 70 KB; registers <= 256 at one wave per SIMD.  Two such workgroups — or one of them beside a workgroup of the
 // plane-split conv kernel from another stream — share a CU, each covering the other's waits.
 #include "binhip_fused.h"
+#include <type_traits>
 #ifndef BINHIP_X3_PRIO
 #define BINHIP_X3_PRIO 0      // bit 1: progress-ordered wave priority in this kernel (binhip_conv_x3.hip explains)
+#endif
+#ifndef BINHIP_TAIL_RES_MFMA
+#define BINHIP_TAIL_RES_MFMA 0   // side builds: 1 = the residual as an identity MFMA (rounds 1-3), for A/B runs
 #endif
 
 namespace {
@@ -32,13 +38,10 @@ struct TX {
     static constexpr int LDS_BYTES = W_OFF + 2 * WBUF_BYTES;    // 71 680 B
     static constexpr int NCHUNK = 12;
     static constexpr int NPJ = (PP + NW - 1) / NW;
-    // after the K-loop: LFF weights of chunks 12/13 sit in weight buffer 0 ([hi: 2 x 3 KiB][lo: 2 x 3 KiB]); the o3
-    // staging tiles (wave-private, 4 KiB per wave and plane) go to weight buffer 1 (hi) and the patch ring (lo)
+    // after the K-loop: LFF weights of chunks 12/13 sit in weight buffer 0 ([hi: 2 x 3 KiB][lo: 2 x 3 KiB]); o3 itself
+    // stays in registers (the swapped epilogue slots ARE the B fragments of those two K-steps)
     static constexpr int TAILW_OFF = W_OFF;
-    static constexpr int O3H_OFF = W_OFF + WBUF_BYTES;
-    static constexpr int O3L_OFF = 0;
     static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
-    static_assert(NW * R * 2 * 32 * 32 <= WBUF_BYTES && NW * R * 2 * 32 * 32 <= 2 * PATCH_BYTES, "o3 staging fits");
 };
 
 __device__ __forceinline__ half8 ld8(const char* p) { return *reinterpret_cast<const half8*>(p); }
@@ -93,9 +96,35 @@ __device__ __forceinline__ void tx_issue_tailw(const TailKArgs& a, char* smem, i
 // A flat list of 12 steps — conv taps of column 0, of column 1, the three LFF row blocks (their B operand is the centre
 // tap's fragment: row r+1 of column 1), conv taps of column 2 — with the A fragments of step s+1 and the patch rows of the
 // next column fetched before the MFMAs of step s.
-template <bool HI>
-__device__ __forceinline__ void tx_compute(const char* pb, const char* wb, int st, int a_lane_off, int b_lane_off,
-                                           const half8 (&ident)[2], floatx16 (&accc)[TX::R], floatx16 (&accl)[3][TX::R]) {
+// Residual (RDN.py:165, `+ x`): the block input IS the centre-tap B fragment of chunks 0-5 — lane (n, kg) holds channels
+// 8kg..8kg+7 of pixel n, the accumulator tile wants channels 8g + 4kg + j.  One v_permlane32_swap per dword pair hands
+// lanes n / n+32 each other's halves (the inverse of the store epilogue's swap), then 8 cvt + 8 fp32 adds per row — on
+// the VALU, in the shadow of the matrix pipe, instead of 24 identity MFMAs per wave and tile (rounds 1-3).
+// Row r of the residual of chunk RES (K = RES >> 1: accumulator tile, HF = RES & 1: its channel half).
+template <int RES>
+__device__ __forceinline__ void tx_add_residual_row(const half8& bc, floatx16 (&accl)[3][TX::R], int r) {
+    constexpr int K = RES >> 1, HF = RES & 1;
+    union H8 { half8 h; unsigned u[4]; };
+    H8 v;
+    v.h = bc;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        auto sw = __builtin_amdgcn_permlane32_swap(v.u[k], v.u[2 + k], false, false);
+        v.u[k] = sw[0]; v.u[2 + k] = sw[1];
+    }
+#pragma unroll
+    for (int ge = 0; ge < 2; ++ge)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) accl[K][r][4 * (2 * HF + ge) + j] += (float)v.h[4 * ge + j];
+}
+
+// RES: chunk index 0..5 when the sub-stage BEFORE this one left a residual to add (its centre-column fragments, `carry`),
+// else -1 — a compile-time constant (it names accumulator registers): the kernel peels chunks 0-6.  The ~16 VALU
+// instructions per row go between the issue of this sub-stage's first fragment reads and its first MFMA, i.e. under the
+// LDS latency the wave would otherwise sit out; every sub-stage leaves its own centre column in `carry`.
+template <bool HI, int RES>
+__device__ __forceinline__ void tx_compute(const char* pb, const char* wb, int a_lane_off, int b_lane_off,
+                                           floatx16 (&accc)[TX::R], floatx16 (&accl)[3][TX::R], half8 (&carry)[TX::R]) {
     constexpr int R = TX::R;
     constexpr int NSTEP = 12;
     half8 B[2][R + 2];
@@ -118,6 +147,15 @@ __device__ __forceinline__ void tx_compute(const char* pb, const char* wb, int s
         h = ld8(wb + off);
         if constexpr (HI) l = ld8(wb + TX::WPL + off);
     };
+#if BINHIP_TAIL_RES_MFMA
+    // rounds 1-3: the residual as an identity MFMA (row m of A selects input channel k of the chunk when m == 16 HF + k)
+    half8 ident;
+    {
+        const int n = threadIdx.x & 31, kg = (threadIdx.x >> 5) & 1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ident[e] = (n == (RES & 1) * 16 + kg * 8 + e) ? (_Float16)1.0f : (_Float16)0.0f;
+    }
+#endif
     load_b(0, B[0]);
     load_a(0, Ah[0], Al[0]);
 #pragma unroll
@@ -128,6 +166,15 @@ __device__ __forceinline__ void tx_compute(const char* pb, const char* wb, int s
         if (s == 0) load_b(1, B[1]);
         if (s == 3) load_b(2, B[0]);                           // column 0's rows are dead after step 2
         __builtin_amdgcn_sched_barrier(0);
+#if !BINHIP_TAIL_RES_MFMA
+        if constexpr (RES >= 0) {
+            if (s == 0) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) tx_add_residual_row<RES>(carry[r], accl, r);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#endif
         if (!lff) {
             const int set = dx & 1;
             if constexpr (HI) {
@@ -139,11 +186,15 @@ __device__ __forceinline__ void tx_compute(const char* pb, const char* wb, int s
             for (int r = 0; r < R; ++r)
                 accc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[s & 1], B[set][r + k], accc[r], 0, 0, 0);
         } else {
-            if (st < 6 && k == (st >> 1)) {   // residual: output channels 16*st .. 16*st+15 += x (exact: 1.0 * x, fp32 accumulate)
+#if BINHIP_TAIL_RES_MFMA
+            if constexpr (RES >= 0) {
+                if (k == (RES >> 1)) {
 #pragma unroll
-                for (int r = 0; r < R; ++r)
-                    accl[k][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ident[st & 1], B[1][r + 1], accl[k][r], 0, 0, 0);
+                    for (int r = 0; r < R; ++r)
+                        accl[k][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ident, B[1][r + 1], accl[k][r], 0, 0, 0);
+                }
             }
+#endif
             if constexpr (HI) {
 #pragma unroll
                 for (int r = 0; r < R; ++r)
@@ -155,6 +206,8 @@ __device__ __forceinline__ void tx_compute(const char* pb, const char* wb, int s
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+#pragma unroll
+    for (int r = 0; r < R; ++r) carry[r] = B[1][r + 1];
 }
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -201,16 +254,14 @@ rdb_tail_x3_kernel(const TailKArgs a, const float* __restrict__ bias_c, const fl
         }
     const int a_lane_off = n * 32 + ((kg ^ ((n >> 3) & 1)) << 4);
     const int b_lane_off = (kg * (TX::PH * TX::PW) + wave * TX::R * TX::PW + n) * 16;
-    // identity A fragments: row m selects input channel k of the chunk when m == 16*half + k (see binhip_fused.hip)
-    half8 ident[2];
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ident[hf][e] = (n == hf * 16 + kg * 8 + e) ? (_Float16)1.0f : (_Float16)0.0f;
 
     tx_issue_weights(a, smem, 0, 0, wave, lane);
     tx_issue_patch(a, smem, 0, 0, wave, voff, plane_elems, plane_bytes);
-    for (int c = 0; c < TX::NCHUNK; ++c) {
+    // one 16-channel chunk = a hi and a lo sub-stage.  Chunks 0-5 (the block input) also carry the residual, with their index
+    // as a compile-time constant (which accumulator registers it lands in): those six are peeled, 6-11 stay a loop.
+    half8 carry[TX::R];
+    auto chunk = [&](const int c, auto res_hi, auto res_lo) __attribute__((always_inline)) {
+        constexpr int RH = decltype(res_hi)::value, RL = decltype(res_lo)::value;
         const char* wb = smem + TX::W_OFF + (c & 1) * TX::WBUF_BYTES;
 #if BINHIP_X3_PRIO & 2
         {   // priority falls with progress (see binhip_conv_x3.hip): the workgroup that lags its CU neighbour issues first
@@ -228,25 +279,50 @@ rdb_tail_x3_kernel(const TailKArgs a, const float* __restrict__ bias_c, const fl
         tx_issue_patch(a, smem, c, 1, wave, voff, plane_elems, plane_bytes);
         if (c + 1 < TX::NCHUNK) tx_issue_weights(a, smem, c + 1, (c + 1) & 1, wave, lane);
         else tx_issue_tailw(a, smem, wave, lane);                // weight buffer 0: chunk 10's, read for the last time in lo(10)
-        tx_compute<true>(smem, wb, c, a_lane_off, b_lane_off, ident, accc, accl);
+        tx_compute<true, RH>(smem, wb, a_lane_off, b_lane_off, accc, accl, carry);
         // ---- lo sub-stage; meanwhile the next chunk's hi plane lands
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < TX::NCHUNK) tx_issue_patch(a, smem, c + 1, 0, wave, voff, plane_elems, plane_bytes);
-        tx_compute<false>(smem + TX::PATCH_BYTES, wb, c, a_lane_off, b_lane_off, ident, accc, accl);
-    }
+        tx_compute<false, RL>(smem + TX::PATCH_BYTES, wb, a_lane_off, b_lane_off, accc, accl, carry);
+    };
+    using std::integral_constant;
+#if BINHIP_TAIL_RES_MFMA
+    // (identity-MFMA form: a sub-stage adds its OWN chunk's plane)
+    chunk(0, integral_constant<int, 0>{}, integral_constant<int, 0>{});
+    chunk(1, integral_constant<int, 1>{}, integral_constant<int, 1>{});
+    chunk(2, integral_constant<int, 2>{}, integral_constant<int, 2>{});
+    chunk(3, integral_constant<int, 3>{}, integral_constant<int, 3>{});
+    chunk(4, integral_constant<int, 4>{}, integral_constant<int, 4>{});
+    chunk(5, integral_constant<int, 5>{}, integral_constant<int, 5>{});
+    chunk(6, integral_constant<int, -1>{}, integral_constant<int, -1>{});
+#else
+    // hi(c) adds the lo plane of chunk c - 1, lo(c) the hi plane of chunk c: each one sub-stage after it was read
+    chunk(0, integral_constant<int, -1>{}, integral_constant<int, 0>{});
+    chunk(1, integral_constant<int, 0>{}, integral_constant<int, 1>{});
+    chunk(2, integral_constant<int, 1>{}, integral_constant<int, 2>{});
+    chunk(3, integral_constant<int, 2>{}, integral_constant<int, 3>{});
+    chunk(4, integral_constant<int, 3>{}, integral_constant<int, 4>{});
+    chunk(5, integral_constant<int, 4>{}, integral_constant<int, 5>{});
+    chunk(6, integral_constant<int, 5>{}, integral_constant<int, -1>{});
+#endif
+    for (int c = 7; c < TX::NCHUNK; ++c) chunk(c, integral_constant<int, -1>{}, integral_constant<int, -1>{});
     // every wave has finished reading the patch ring and weight buffer 1 (the o3 staging area); the o3 LFF weights landed
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- conv #3 epilogue: bias + ReLU -> wave-private o3 tiles in LDS ([chunk][row][pixel][16 ch], slot-swizzled) ----
-    char* o3h = smem + TX::O3H_OFF + wave * (TX::R * 2 * 32 * 32);
-    char* o3l = smem + TX::O3L_OFF + wave * (TX::R * 2 * 32 * 32);
+    // ---- conv #3 epilogue: bias + ReLU + hi/lo split; o3 never leaves the registers -------------------------------------
+    // The accumulator tile gives lane (n, kg) channels 8g + 4kg + j; after the store epilogue's v_permlane32_swap of a
+    // (g even, g odd) pair lane (n, kg) owns the full 16-byte slot kg of 16-channel group gp — channels 16gp + 8kg .. +7 of
+    // pixel n — which is exactly the B fragment (k = 8kg .. 8kg+7 of chunk 12 + gp) the LFF's last two K-steps want.
+    // (Round 2 staged o3 through wave-private LDS tiles with 8-byte stores: 258 048 bank conflicts per launch.)
     const int gx = tx0 + n;
     union H4 { half4 h; unsigned u[2]; };
+    union H8 { half8 h; unsigned u[4]; };
     unsigned sat = 0;
+    half8 Bh[2][TX::R], Bl[2][TX::R];
 #pragma unroll
     for (int r = 0; r < TX::R; ++r) {
         const int gy = ty0 + wave * TX::R + r;
@@ -257,7 +333,6 @@ rdb_tail_x3_kernel(const TailKArgs a, const float* __restrict__ bias_c, const fl
 #pragma unroll
             for (int ge = 0; ge < 2; ++ge) {
                 const int g = 2 * gp + ge;
-                const int co = 8 * g + 4 * kg;
                 float b8[8];                              // wave-uniform slot of 8 biases, the lane's half picked by kg
 #pragma unroll
                 for (int j = 0; j < 8; ++j) b8[j] = bias_c[8 * g + j];
@@ -269,40 +344,31 @@ rdb_tail_x3_kernel(const TailKArgs a, const float* __restrict__ bias_c, const fl
                     hv[ge].h[j] = hj;
                     lv[ge].h[j] = split_lo(v[j], hj);
                 }
-                const int off = ((gp * TX::R + r) * 32 + n) * 32 + ((ge ^ ((n >> 3) & 1)) << 4) + kg * 8;
-                *reinterpret_cast<half4*>(o3h + off) = hv[ge].h;
-                *reinterpret_cast<half4*>(o3l + off) = lv[ge].h;
             }
-            if (a.o3_hi) {      // training only: keep o3 for the backward pass (16-byte coalesced stores)
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    auto sw = __builtin_amdgcn_permlane32_swap(hv[0].u[k], hv[1].u[k], false, false);
-                    hv[0].u[k] = sw[0]; hv[1].u[k] = sw[1];
-                    auto sl = __builtin_amdgcn_permlane32_swap(lv[0].u[k], lv[1].u[k], false, false);
-                    lv[0].u[k] = sl[0]; lv[1].u[k] = sl[1];
-                }
-                if (ok) {
-                    const long long o = (long long)gp * plane_elems + ((((long long)img * H + gy) * W + gx) << 4) + kg * 8;
-                    *reinterpret_cast<uint4*>(a.o3_hi + o) = make_uint4(hv[0].u[0], hv[0].u[1], hv[1].u[0], hv[1].u[1]);
-                    *reinterpret_cast<uint4*>(a.o3_lo + o) = make_uint4(lv[0].u[0], lv[0].u[1], lv[1].u[0], lv[1].u[1]);
-                }
+            for (int k = 0; k < 2; ++k) {
+                auto sw = __builtin_amdgcn_permlane32_swap(hv[0].u[k], hv[1].u[k], false, false);
+                hv[0].u[k] = sw[0]; hv[1].u[k] = sw[1];
+                auto sl = __builtin_amdgcn_permlane32_swap(lv[0].u[k], lv[1].u[k], false, false);
+                lv[0].u[k] = sl[0]; lv[1].u[k] = sl[1];
+            }
+            H8 fh, fl;
+            fh.u[0] = hv[0].u[0]; fh.u[1] = hv[0].u[1]; fh.u[2] = hv[1].u[0]; fh.u[3] = hv[1].u[1];
+            fl.u[0] = lv[0].u[0]; fl.u[1] = lv[0].u[1]; fl.u[2] = lv[1].u[0]; fl.u[3] = lv[1].u[1];
+            Bh[gp][r] = fh.h;
+            Bl[gp][r] = fl.h;
+            if (a.o3_hi && ok) {      // training only: keep o3 for the backward pass (16-byte coalesced stores)
+                const long long o = (long long)gp * plane_elems + ((((long long)img * H + gy) * W + gx) << 4) + kg * 8;
+                *reinterpret_cast<uint4*>(a.o3_hi + o) = make_uint4(fh.u[0], fh.u[1], fh.u[2], fh.u[3]);
+                *reinterpret_cast<uint4*>(a.o3_lo + o) = make_uint4(fl.u[0], fl.u[1], fl.u[2], fl.u[3]);
             }
         }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
 
-    // ---- LFF K-steps 12, 13: o3 straight from LDS (hi sub-stage products first, then the lo plane: same order as above)
+    // ---- LFF K-steps 12, 13 on the o3 fragments (hi sub-stage products first, then the lo plane: same order as above)
     const char* tailw = smem + TX::TAILW_OFF;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        half8 Bh[TX::R], Bl[TX::R];
-#pragma unroll
-        for (int r = 0; r < TX::R; ++r) {
-            const int off = ((t * TX::R + r) * 32 + n) * 32 + ((kg ^ ((n >> 3) & 1)) << 4);
-            Bh[r] = ld8(o3h + off);
-            Bl[r] = ld8(o3l + off);
-        }
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt) {
             const int off = (t * 96 + mt * 32) * 32 + a_lane_off;
@@ -310,9 +376,9 @@ rdb_tail_x3_kernel(const TailKArgs a, const float* __restrict__ bias_c, const fl
             const half8 Al = ld8(tailw + 6 * 1024 + off);
 #pragma unroll
             for (int r = 0; r < TX::R; ++r) {
-                accl[mt][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh[r], accl[mt][r], 0, 0, 0);
-                accl[mt][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh[r], accl[mt][r], 0, 0, 0);
-                accl[mt][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl[r], accl[mt][r], 0, 0, 0);
+                accl[mt][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh[t][r], accl[mt][r], 0, 0, 0);
+                accl[mt][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh[t][r], accl[mt][r], 0, 0, 0);
+                accl[mt][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl[t][r], accl[mt][r], 0, 0, 0);
             }
         }
     }

@@ -48,14 +48,14 @@ class _DirectParamGrads:
         self.mods, self.on = mods, bool(on)
 
     def __enter__(self):
-        self.prev = [m.direct_param_grads for m in self.mods]
+        self.prev = [m._direct_grads for m in self.mods]
         for m in self.mods:
-            m.direct_param_grads = self.on
+            m._direct_grads = self.on
         return self
 
     def __exit__(self, *a):
         for m, v in zip(self.mods, self.prev):
-            m.direct_param_grads = v
+            m._direct_grads = v
         return False
 
 
@@ -145,7 +145,7 @@ class _RDNBase(nn.Module):
         from ...autograd import default_backward_precision, default_wgrad_side_stream
         from ...rdn_plan import default_plan_flags
         self.backward_precision = default_backward_precision()   # "f16" = single-product backward behind an f16x3 forward
-        self.direct_param_grads = False                          # kernels accumulate weight gradients straight into .grad
+        self._direct_grads = False                               # kernels accumulate weight gradients straight into .grad
         self.wgrad_side_stream = default_wgrad_side_stream()     # weight-gradient kernels beside the backward-data chain
         self.plan_flags = default_plan_flags()                   # BINHIP_PLAN_* bits of every call of this sub-network
         self.profiler = None                                     # BinhipProfiler handle (bench.py's roofline leg)
@@ -154,6 +154,11 @@ class _RDNBase(nn.Module):
                                                                  # forward / backward (tools/fp16_headroom.py)
         self._wcache = None            # (key, RdnWeights)
         self._wgen = 0                 # bumped by invalidate_kernel_weights()
+
+    def direct_param_grads(self, on=True):
+        """Context (same name as on the whole network, so a bare RDN sub-network can be a wrapper's netG): while active the
+        backward kernels of this RDN write / accumulate their weight gradients straight into the parameters' .grad."""
+        return _DirectParamGrads([self], on)
 
     def _weights_key(self, nterms):
         params = list(self.parameters())
@@ -449,7 +454,10 @@ def _forward_streams(self, B, stage1_cache=None, input_events=None):
             # its capture ends, is reused by the next call's); graphs of different streams replay concurrently and
             # must not.
             g = torch.cuda.CUDAGraph()
-            pool = pools.setdefault(si % len(streams), torch.cuda.graph_pool_handle())
+            k = si % len(streams)
+            if k not in pools:                      # (setdefault would build a fresh pool handle on every call)
+                pools[k] = torch.cuda.graph_pool_handle()
+            pool = pools[k]
             with torch.cuda.graph(g, stream=s, pool=pool):
                 out = fn()
             self._call_graphs.append((g, out))

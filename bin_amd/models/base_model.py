@@ -33,7 +33,8 @@ def _direct_param_grads(network):
     """The generator's own `direct_param_grads()` context (bin_amd/models/archs/RDN.py) when it has one — an injected
     CPU test generator does not — else a no-op."""
     net = unwrap(network)
-    return net.direct_param_grads() if hasattr(net, "direct_param_grads") else _NoCtx()
+    ctx = getattr(net, "direct_param_grads", None)
+    return ctx() if callable(ctx) else _NoCtx()
 
 
 def clean_state_dict_keys(loaded, strict):

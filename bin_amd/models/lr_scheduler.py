@@ -59,8 +59,11 @@ class _RestartSchedule(_LRScheduler):
             self._on_restart(cycle)
             return [g["initial_lr"] * wgt for g in groups]
         num, den = self.curve(cycle, e - start, start), self.curve(cycle, e - 1 - start, start)
-        if den == 0.0:                  # the curve sat on its floor: re-enter it from the starting rate
-            return [self.floor + (b - self.floor) * num for b in self.base_lrs]
+        if den == 0.0:
+            # the curve sat on its floor, a ratio says nothing: the reference leaves the floor by an INCREMENT on the rate
+            # the group has now (lr_scheduler.py:57-61) — the first step of the unweighted curve — so a rate somebody
+            # rescaled at the bottom keeps its offset
+            return [g["lr"] + (b - self.floor) * num for b, g in zip(self.base_lrs, groups)]
         return self._ratio_step(groups, num, den)
 
     def _ratio_step(self, groups, num, den):

@@ -17,14 +17,15 @@ sys.path.insert(0, "/root/reference")
 import models.lr_scheduler as REF_LRS          # noqa: E402
 
 sys.path.insert(0, os.path.dirname(HERE))
-from lr_cases import CASES, drive              # noqa: E402
+from lr_cases import CASES, drive, unpack              # noqa: E402
 
 
 if __name__ == "__main__":
     curves = {}
-    for tag, (kind, kw, warm) in CASES.items():
-        a = drive(REF_LRS, kind, kw, warm, False)
-        b = drive(REF_LRS, kind, kw, warm, True)
+    for tag, case in CASES.items():
+        kind, kw, warm, rescale = unpack(case)
+        a = drive(REF_LRS, kind, kw, warm, False, rescale)
+        b = drive(REF_LRS, kind, kw, warm, True, rescale)
         assert np.array_equal(a, b), tag                  # the reference's own state_dict round trip is exact
         curves[tag] = a
     np.savez(os.path.join(HERE, "g6b_lr.npz"), **curves)

@@ -10,11 +10,20 @@ CASES = {
                                              clear_state=False), 0),
     "cosine_warm": ("cosine", dict(T_period=[8, 12, 6], restarts=[8, 20], weights=[0.7, 1.5], eta_min=3e-7), 5),
     "cosine_long": ("cosine", dict(T_period=[5, 5], restarts=[24], weights=[1.0], eta_min=1e-7), 0),
+    # somebody rescales the rates while the cosine sits on its floor (iterations 16 and 24 are bottoms of these cycles):
+    # the reference leaves the floor by an INCREMENT on the rate the group has (lr_scheduler.py:57-61)
+    "cosine_bottom_rescale": ("cosine", dict(T_period=[16, 8], restarts=[19], weights=[0.5], eta_min=1e-7), 0,
+                              {16: 0.1, 28: 3.0}),
 }
 STEPS, RESUME_AT = 32, 11
 
 
-def drive(mod, kind, kw, warm, resume):
+def unpack(case):
+    """(kind, kwargs, warm-up iterations, {iteration: factor applied to every group's rate after that iteration})."""
+    return case if len(case) == 4 else (*case, {})
+
+
+def drive(mod, kind, kw, warm, resume, rescale=None):
     """The reference loop: optimizer.step(); scheduler.step(); warm-up override (base_model.py:76-87)."""
     def make():
         ps = [torch.nn.Parameter(torch.zeros(1)), torch.nn.Parameter(torch.zeros(1))]
@@ -29,6 +38,9 @@ def drive(mod, kind, kw, warm, resume):
         if it < warm:
             for g in o.param_groups:
                 g["lr"] = g["initial_lr"] / warm * it
+        if rescale and it in rescale:
+            for g in o.param_groups:
+                g["lr"] *= rescale[it]
         out.append([g["lr"] for g in o.param_groups])
         if resume and it == RESUME_AT:
             so, ss = o.state_dict(), s.state_dict()

@@ -372,9 +372,10 @@ def test_lr_schedulers_in_the_training_loop_match_reference():
     from bin_amd.models import lr_scheduler as LRS
     import lr_cases
     g = load_golden("g6b_lr")
-    for tag, (kind, kw, warm) in lr_cases.CASES.items():
+    for tag, case in lr_cases.CASES.items():
+        kind, kw, warm, rescale = lr_cases.unpack(case)     # (cosine_bottom_rescale: rates rescaled ON the cosine's floor)
         for resume in (False, True):
-            got = lr_cases.drive(LRS, kind, kw, warm, resume)
+            got = lr_cases.drive(LRS, kind, kw, warm, resume, rescale)
             assert np.allclose(got, g[tag], rtol=1e-12, atol=0), (tag, resume, np.abs(got / g[tag] - 1).max())
 
 

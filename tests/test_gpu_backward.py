@@ -265,7 +265,7 @@ def test_direct_param_grads_equal_autograd_accumulation():
         loss = sum((o * o).mean() for o in out)
         with net.direct_param_grads(direct):
             loss.backward()
-        assert not any(m.direct_param_grads for m in net.rdn_modules())
+        assert not any(m._direct_grads for m in net.rdn_modules())
         return {n: p.grad.clone() for n, p in net.named_parameters()}
 
     base = run(False, False)
