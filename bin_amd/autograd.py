@@ -224,12 +224,16 @@ class _ConvFn(torch.autograd.Function):
         xp = ops.nchw_to_planes(x, nt)
         y = ops.planes_to_nchw(ops.conv2d(xp, cw), weight.shape[0])
         ctx.xp, ctx.weight, ctx.has_bias = xp, weight, bias is not None
+        ctx.weight_version = weight._version        # (the backward-data pass re-lays-out `weight` as it is THEN)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         from . import ops
         nt = GENERAL_NTERMS
+        if ctx.weight._version != ctx.weight_version:
+            raise RuntimeError("bin_amd: a ConvLSTM gate weight was modified in place between forward and backward "
+                               "(optimizer step / broadcast / load_state_dict): its gradient would not belong to the forward")
         cout, cin, ks, _ = ctx.weight.shape
         gp, sc = ops.grad_planes(gy, nt)
         dw = db = gx = None

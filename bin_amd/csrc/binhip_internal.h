@@ -4,8 +4,6 @@
 #include <stdint.h>
 #include "../../include/binhip.h"
 
-#define BINHIP_VERSION 300
-
 // BINHIP_TUNING (side builds for tools/: kernel-variant sweeps and ablations; 0 in the product): compiles the
 // alternative tile configurations and the process-global switches that select them.  The product library has neither.
 #ifndef BINHIP_TUNING

@@ -1,14 +1,16 @@
 """Single-tensor wrapper API over the same generator (reference Video_base_model.py:22-335).
 
 The reference class cannot be imported (it needs `CharbonnierLossPlusSSIM`, which models/loss.py does not define),
-so no reference outputs exist for it: PARITY UNPINNED.  What is kept is its surface — `feed_data({'LQs', 'GT'})`,
+so no reference outputs exist for its training step: PARITY UNPINNED there.  What is kept is its surface — `feed_data({'LQs', 'GT'})`,
 `optimize_parameters`, `test`, `test_stitch`, `get_current_log`, `get_loss`, `get_current_visuals`, `load`, `save` —
 over a `var_L [B,N,C,H,W]` tensor.  The frames along N are handed to bin_stage4 as its six inputs and the 14
 outputs come back stacked as `fake_H [B,14,C,H,W]`; `GT` is the matching [B,14,C,H,W] stack.
 
 `test_stitch` is the tiled forward for frames that do not fit in one pass: the reference hard-codes a 960x540 ->
 4K SR geometry (scale 4, 320x180 tiles, 32 px halo); here the tile size, halo and scale (1 for bin_stage4) are
-arguments with those defaults' roles."""
+arguments with those defaults' roles.  ITS geometry IS pinned (round 4): fixture g12_stitch is the reference's own
+`test_stitch` (imported with the one missing loss name injected, tests/golden/make_golden_stitch.py) over a stand-in
+single-tensor x4 generator; `test_stitch((180, 320), 32, 4)` over the same generator reproduces it bit for bit."""
 import logging
 import os.path as osp
 from collections import OrderedDict
@@ -103,7 +105,12 @@ class VideoBaseModel(BaseModel):
             self.real_H = data["GT"].to(self.device)
 
     def _net(self, var_L):
-        """[B,N,C,H,W] -> [B,14,C,H,W]: frames along N are the generator's positional inputs."""
+        """[B,N,C,H,W] -> [B,14,C,H,W]: frames along N are bin_stage4's positional inputs.  A generator of the kind the
+        reference class was written for (`takes_stacked_frames`: ONE [B,N,C,H,W] tensor in, one tensor out,
+        Video_base_model.py:139) gets var_L as it is."""
+        from .base_model import unwrap
+        if getattr(unwrap(self.netG), "takes_stacked_frames", False):
+            return self.netG(var_L)
         return torch.stack(self.netG(*var_L.unbind(dim=1)), dim=1)
 
     def _pix_loss(self):
@@ -168,9 +175,9 @@ class VideoBaseModel(BaseModel):
             for j in range(ny):
                 for i in range(nx):
                     crop = xp[..., j * th:(j + 1) * th + 2 * halo, i * tw:(i + 1) * tw + 2 * halo]
-                    y = self._net(crop.contiguous())
+                    y = self._net(crop.contiguous())          # [B,K,C,h',w'], or [B,C,h',w'] from a single-output generator
                     if out is None:
-                        out = torch.zeros((B, y.shape[1], C, ny * th * scale, nx * tw * scale), device=y.device)
+                        out = torch.zeros(tuple(y.shape[:-2]) + (ny * th * scale, nx * tw * scale), device=y.device)
                     out[..., j * th * scale:(j + 1) * th * scale, i * tw * scale:(i + 1) * tw * scale] = \
                         y[..., halo * scale:(halo + th) * scale, halo * scale:(halo + tw) * scale]
             self.fake_H = out[..., :H * scale, :W * scale]

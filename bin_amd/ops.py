@@ -417,8 +417,9 @@ def lstm_gates(gates, c_prev, forget_bias, hidden):
 
 
 def lstm_gates_grad(gates, c_prev, g_h, g_c, forget_bias, hidden, need_cprev):
+    gates = gates.contiguous()                      # the kernel indexes plain NCHW
     n, _, h, w = gates.shape
-    dg = torch.empty_like(gates)
+    dg = torch.empty(gates.shape, dtype=gates.dtype, device=gates.device)
     gcp = torch.empty((n, hidden, h, w), dtype=torch.float32, device=gates.device) if need_cprev else None
     cp = c_prev.contiguous().float() if c_prev is not None else None
     gh = g_h.contiguous().float() if g_h is not None else None

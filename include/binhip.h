@@ -46,6 +46,12 @@ extern "C" {
  * symbols (tests/test_cpu_host.py checks `nm -D` against this header). */
 #define BINHIP_API __attribute__((visibility("default")))
 
+/* Interface version = what binhip_version() of a matching library returns (100 x round + revision); a binder checks
+ * `binhip_version() == BINHIP_VERSION` after dlopen.  BINHIP_ABI_EXPORTS = number of BINHIP_API entry points below
+ * (tests/test_cpu_host.py keeps it equal to the declarations and to `nm -D`). */
+#define BINHIP_VERSION 400
+#define BINHIP_ABI_EXPORTS 43
+
 #define BINHIP_E_ARG      (-1)   /* null pointer / bad enum */
 #define BINHIP_E_SHAPE    (-2)   /* unsupported shape */
 #define BINHIP_E_WORKSPACE (-3)  /* workspace too small */

@@ -222,6 +222,41 @@ def test_video_base_model_surface(tmp_path):
     assert _wrappers()["video_base"] is VideoBaseModel
 
 
+def test_video_base_model_stitch_geometry_matches_the_reference(tmp_path):
+    """Row a17's only non-trivial logic, pinned (round 4): fixture g12_stitch is the REFERENCE's VideoBaseModel.test_stitch
+    (Video_base_model.py:189-280; imported with the one missing loss name injected, tests/golden/make_golden_stitch.py) on a
+    seeded 960x540 two-frame input over the stand-in x4 generator of tests/stitch_cases.py.  bin_amd's stitcher with the
+    reference's hard-wired geometry as ARGUMENTS — 320x180 tiles, 32-px halo, scale 4 — makes the same 9 generator calls on the
+    same crops and assembles the same [1,3,2160,3840] image, bit for bit (SHA-256 of the whole tensor)."""
+    import hashlib
+    import stitch_cases as SC
+    from conftest import load_golden
+    from bin_amd.models.Video_base_model import VideoBaseModel
+    g = load_golden("g12_stitch")
+    calls = []
+
+    class Recording(SC.StubSR):
+        def forward(self, x):
+            calls.append(tuple(x.shape))
+            return super().forward(x)
+
+    opt = {**_vopt(tmp_path), "is_train": False}
+    m = VideoBaseModel(opt, netG=Recording().eval())
+    m.feed_data({"LQs": SC.frame()}, need_GT=False)
+    with torch.no_grad():
+        m.test_stitch(tile_hw=SC.TILE_HW, halo=SC.HALO, scale=SC.SCALE)
+    y = m.fake_H
+    assert tuple(y.shape) == (1, 3, SC.LR_H * SC.SCALE, SC.LR_W * SC.SCALE)
+    assert len(calls) == int(g["n_calls"]) and set(calls) == {tuple(int(v) for v in g["crop_shape"])}
+    for k, v in SC.sample(y).items():
+        assert np.array_equal(v.numpy(), g[k]), k
+    assert hashlib.sha256(y.contiguous().numpy().tobytes()).digest() == bytes(g["sha256"])
+    # a different halo or a shifted interior would NOT reproduce it (the stand-in's blur and crop ramp see to that)
+    with torch.no_grad():
+        m.test_stitch(tile_hw=SC.TILE_HW, halo=SC.HALO // 2, scale=SC.SCALE)
+    assert not np.array_equal(SC.sample(m.fake_H)["seam_rows"].numpy(), g["seam_rows"])
+
+
 # ------------------------------------------------------------------ the training loop (bin_amd.train) on CPU
 def _train_yml(tmp, adobe, resume=None, niter=6):
     y = OPTION_YML.replace("~/data/adobe", adobe).replace("/tmp/bin_amd_runs", str(tmp))

@@ -25,7 +25,7 @@ def test_library_exports_every_header_symbol():
     for sym in sorted(declared):
         assert hasattr(lib, sym), f"libbinhip.so does not export {sym}"
     assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
-    assert _lib.lib().binhip_version() >= 200
+    assert _lib.lib().binhip_version() >= 400
     # the product library has no process-global switches (SURVEY §8b "no globals except immutable tables"): the
     # tuning / ablation setters exist only in BINHIP_TUNING side builds and are not declared in the public header
     for sym in _lib._TUNING_SIGNATURES:
@@ -42,6 +42,39 @@ def test_library_exports_nothing_but_the_abi():
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     dyn = {ln.split()[-1].split("@")[0] for ln in out.splitlines() if ln.strip()}
     assert dyn == set(build.abi_symbols()) == set(_lib.exported_symbols()), dyn ^ set(build.abi_symbols())
+
+
+def test_header_version_and_export_count_match_the_library():
+    """include/binhip.h carries BINHIP_VERSION (what binhip_version() returns) and BINHIP_ABI_EXPORTS (the number of
+    BINHIP_API declarations): a binder can check both at compile / load time."""
+    import re
+    from bin_amd import _lib, build
+    hdr = open(os.path.join(REPO, "include", "binhip.h")).read()
+    ver = int(re.search(r"#define\s+BINHIP_VERSION\s+(\d+)", hdr).group(1))
+    n = int(re.search(r"#define\s+BINHIP_ABI_EXPORTS\s+(\d+)", hdr).group(1))
+    assert _lib.lib().binhip_version() == ver
+    assert n == len(build.abi_symbols()) == len(set(build.abi_symbols()))
+    assert "BINHIP_VERSION" not in open(os.path.join(REPO, "bin_amd", "csrc", "binhip_internal.h")).read()
+
+
+def test_integration_doc_names_exist_in_the_header():
+    """Every BINHIP_* constant and binhip_* entry point INTEGRATION.md mentions is declared in include/binhip.h (round 3's
+    document promised an error code that did not exist)."""
+    import re
+    from bin_amd import build
+    hdr = open(os.path.join(REPO, "include", "binhip.h")).read()
+    doc = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    macros = set(re.findall(r"#define\s+(BINHIP_\w+)", hdr)) | set(re.findall(r"\b(BINHIP_\w+)\s*=", hdr))
+    macros |= set(re.findall(r"\b(BINHIP_\w+)\b", hdr))                      # enum members, too
+    side_build = {"BINHIP_TUNING", "BINHIP_E_"}                                # the -D switch of tools/ builds; a prefix in prose
+    for name in set(re.findall(r"\b(BINHIP_\w+)", doc)) - side_build:
+        assert name in macros, f"INTEGRATION.md mentions {name}, which include/binhip.h does not define"
+    entries = set(build.abi_symbols())
+    for name in set(re.findall(r"\b(binhip_[a-z0-9_]+)\b", doc)):
+        if name.endswith(("_fwd/bwd", "_")) or name in entries:
+            continue
+        # prose shorthands like `binhip_pixel_loss_fwd/bwd` are split by the regex into existing prefixes
+        assert any(e.startswith(name) for e in entries), f"INTEGRATION.md mentions {name}(), not in the ABI"
 
 
 def test_library_host_queries():

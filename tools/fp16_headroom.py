@@ -2,6 +2,13 @@
 """Measured fp16 headroom of the stored planes: the 720p window and a short synthetic training run.
 
   python tools/fp16_headroom.py [--steps 200] [--out gpurun_out/r03_fp16_headroom]
+  python tools/fp16_headroom.py --checkpoint adobe_bin.pth --steps 0      # a holder of the trained weights: one command
+
+--checkpoint PATH: load a reference checkpoint (the `.pth` of model_weights/download_adobe_bin.txt; `module.` / `InterpNet.`
+prefixes are cleaned as the reference's load_network does, strict) instead of the seeded initialisation, for the 720p
+window and as the starting point of the training part (--steps 0 skips that part).  The pretrained file is not available
+in this build environment, so the committed tables are for the seeded weights; the exit code is 1 when any stored plane has
+less than 8x headroom.
 
 Part 1: ONE 6-frame 720p window (768x1344 padded, synthetic U[0,1) frames, seeded init) run through the training-forward
         path (four RDN calls with BINHIP_PLAN_KEEP_ACTS, forward values identical to inference): every stored activation
@@ -25,9 +32,22 @@ from bin_amd.utils import util  # noqa: E402
 from bin_amd.weights import reference_state_dict, synthetic_frames  # noqa: E402
 
 
-def window_720p():
+def load_weights(net, checkpoint):
+    """Seeded initialisation, or a reference checkpoint with the reference's key clean-up (base_model.py:93-102), strict."""
+    if not checkpoint:
+        net.load_state_dict(reference_state_dict(0), strict=True)
+        return "seeded initialisation (bin_amd/weights.py, seed 0)"
+    from bin_amd.models.base_model import clean_state_dict_keys
+    sd = torch.load(checkpoint, map_location="cpu")
+    if isinstance(sd, dict) and "state_dict" in sd and not any(torch.is_tensor(v) for v in sd.values()):
+        sd = sd["state_dict"]
+    net.load_state_dict(clean_state_dict_keys(sd, True), strict=True)
+    return f"checkpoint {os.path.basename(checkpoint)}"
+
+
+def window_720p(checkpoint=None):
     net = bin_stage4_lstm()
-    net.load_state_dict(reference_state_dict(0), strict=True)
+    load_weights(net, checkpoint)
     net = net.cuda().train()
     rec = RS.Recorder().attach(net)
     rec.armed, rec.tag = True, "720p "
@@ -41,7 +61,7 @@ def window_720p():
     return rec.rows
 
 
-def training(steps, marks, batch=8, size=256):
+def training(steps, marks, batch=8, size=256, checkpoint=None):
     tmp = tempfile.mkdtemp()
     opt = {"model": "bin", "gpu_ids": [0], "is_train": True, "dist": False,
            "network_G": {"which_model_G": "bin_stage4", "nframes": 6, "version": 2, "precision": "f16x3",
@@ -52,7 +72,7 @@ def training(steps, marks, batch=8, size=256):
                      "restarts": None, "restart_weights": None, "lr_gamma": 0.5, "clear_state": False}}
     m = create_model(opt)
     net = m.netG.module
-    net.load_state_dict(reference_state_dict(0), strict=True)
+    load_weights(net, checkpoint)
     g = torch.Generator().manual_seed(7)
     m.feed_data({"LQs": torch.rand(batch, 6, 3, size, size, generator=g),
                  "GTenh": torch.rand(batch, 6, 3, size, size, generator=g),
@@ -95,15 +115,17 @@ def main():
     ap.add_argument("--marks", default="1,50,200")
     ap.add_argument("--out", default="gpurun_out/r03_fp16_headroom")
     ap.add_argument("--skip-720p", action="store_true")
+    ap.add_argument("--checkpoint", default=None, help="reference .pth to measure instead of the seeded initialisation")
     args = ap.parse_args()
     marks = {int(x) for x in args.marks.split(",") if int(x) <= args.steps}
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
-    result, md = {}, ["# fp16 headroom of the stored planes, measured (tools/fp16_headroom.py)", ""]
+    src = f"checkpoint {os.path.basename(args.checkpoint)}" if args.checkpoint else "seeded initialisation"
+    result, md = {}, [f"# fp16 headroom of the stored planes, measured (tools/fp16_headroom.py; weights: {src})", ""]
     if not args.skip_720p:
-        rows = window_720p()
+        rows = window_720p(args.checkpoint)
         result["window_720p"] = rows
         md.append(md_table("720p window (768x1344), seeded init, forward activations of all 17 call-equivalents (4 batched calls)", rows))
-    tr, losses = training(args.steps, marks)
+    tr, losses = training(args.steps, marks, checkpoint=args.checkpoint) if args.steps > 0 else ({}, {})
     for step in sorted(tr):
         rows = tr[step]
         result[f"train_step_{step}"] = rows
@@ -115,7 +137,10 @@ def main():
     json.dump(result, open(args.out + ".json", "w"))
     open(args.out + ".md", "w").write("\n".join(md))
     print("\n".join(md))
+    worst = min((RS.summarize(rows)["min_headroom"] for rows in result.values() if rows), default=float("inf"))
+    print(f"worst headroom over everything measured: {worst:.3g}x")
+    return 0 if worst >= 8.0 else 1
 
 
 if __name__ == "__main__":
-    main()
+    raise SystemExit(main())
