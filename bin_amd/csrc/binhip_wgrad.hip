@@ -23,7 +23,8 @@
 #ifndef BINHIP_WG3_STRIDE_WALK
 #define BINHIP_WG3_STRIDE_WALK 1
 #endif
-// 3x3 weight gradient: 1 = wave owns an X row (wgrad3x3_xrow_kernel), 0 = wave owns a gY row (wgrad3x3_db_kernel, round 2)
+// 3x3 weight gradient, BINHIP_TUNING side builds only: 1 = wave owns an X row (wgrad3x3_xrow_kernel, the product's only form),
+// 0 = wave owns a gY row (wgrad3x3_db_kernel, round 2; tools/experiments/wgrad_experiments.inc)
 #ifndef BINHIP_WG3_XROW
 #define BINHIP_WG3_XROW 1
 #endif
@@ -351,354 +352,15 @@ wgrad_mfma_kernel(const WgradKArgs a) {
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------
-// Lean variant of the kernel above: ONE LDS buffer (no intra-workgroup double buffering), fragments fetched per tap,
-// bias as per-lane VALU sums, <= 256 registers -> two workgroups share a CU and overlap each other's DMA waits.
-template <int KS, int TR, int NT>
-__global__ void __launch_bounds__(256, 2)
-wgrad_mfma_sb_kernel(const WgradKArgs a) {
-    using C = WgCfg<KS, TR, NT>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int pb, cp, bz;
-    wg_block(a, pb, cp, bz);
-    const int cot = bz % a.ncot;
-    const int dyg = bz / a.ncot;
-    const int dy0 = dyg * TR;
-    const long long plane_elems = (long long)a.N * a.H * a.W * 16;
-    const unsigned plane_bytes = (unsigned)(plane_elems * 2);
-    const bool do_bias = (cp == 0) && (dyg == 0);
-
-    floatx16 acc[C::NTAP];
-    float bsum = 0.f;
-#pragma unroll
-    for (int t = 0; t < C::NTAP; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-
-    if ((blockIdx.x >> 8) & 1)
-        for (int i = 0; i < ((a.dbg >> 8) & 255); ++i) __builtin_amdgcn_s_sleep(16);
-    for (int tile = pb; tile < a.ntiles; tile += a.PB) {
-        if (!(a.dbg & 1)) wg_issue<KS, TR, NT>(a, smem, 0, tile, cp, cot, dy0, wave, lane, plane_elems, plane_bytes);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (!(a.dbg & 2)) {
-            const char* xb = smem;
-            const char* gb = xb + 2 * C::XBYTES;
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const int row = wave * 2 + (s4 >> 1), x0 = (s4 & 1) * 16;
-                const half8 Bh = tr_frag(gb, C::GBYTES, row * 32 + x0, lane);
-                half8 Bl;
-                if constexpr (NT == 3) Bl = tr_frag(gb + C::PLANE_BYTES, C::GBYTES, row * 32 + x0, lane);
-                if (do_bias) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        bsum += (float)Bh[e];
-                        if constexpr (NT == 3) bsum += (float)Bl[e];
-                    }
-                }
-#pragma unroll
-                for (int t = 0; t < C::NTAP; ++t) {
-                    const int p0 = (row + t / KS) * C::PW + x0 + t % KS;
-                    const half8 Ah = tr_frag(xb, C::XBYTES, p0, lane);
-                    if constexpr (NT == 3) {
-                        const half8 Al = tr_frag(xb + C::PLANE_BYTES, C::XBYTES, p0, lane);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, acc[t], 0, 0, 0);
-                    }
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, acc[t], 0, 0, 0);
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if (a.dbg & 4) { if (acc[0][0] == 12345.f) a.partial[0] = bsum; return; }
-    float* red = reinterpret_cast<float*>(smem);
-    const int n = lane & 31, hi = lane >> 5;
-    const long long blk = ((long long)bz * a.ncp + cp) * a.PB + pb;
-#pragma unroll
-    for (int t = 0; t < C::NTAP; ++t) {
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int m = (e & 3) + 8 * (e >> 2) + 4 * hi;
-            red[wave * 1024 + m * 32 + n] = acc[t][e];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i;
-            a.partial[(blk * C::NTAP + t) * 1024 + idx] = (red[idx] + red[1024 + idx]) + (red[2048 + idx] + red[3072 + idx]);
-        }
-    }
-    if (do_bias) {
-        __syncthreads();
-        red[tid] = bsum;                              // [wave][kg][co]
-        __syncthreads();
-        if (tid < 32) {
-            float tsum = 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) tsum += red[k * 32 + tid];
-            a.partial_b[((long long)cot * a.PB + pb) * 32 + tid] = tsum;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// 3x3 layers, default: EIGHT waves and TWO LDS stages per workgroup.  The lean kernel above relies on two co-resident
-// workgroups covering each other's DMA waits, but the two start together, wait together and multiply together: measured
-// alone (tools/bench_wgrad.py, 160 -> 32 channels, 40 x 128 x 128), DMA-only 97 us + MFMA-only 137 us = 234 us against 224 us
-// for the real thing — no overlap at all (a one-off start stagger of one of the two recovers 17 %).  Here the overlap is
-// structural: the tile t + PB planes land in the other stage while the eight waves (one pixel row each, the K-split of the
-// lean kernel) multiply tile t; the transpose reads come from asm (see tr_issue) so nothing fences that prefetch.
-//   * Per wave and tile: 2 K-steps x 9 taps; the fragments of steps s + 1 and s + 2 are in flight while step s multiplies
-//     (counted lgkmcnt: LDS reads return in order).  The 18 per-lane tap addresses are tile-invariant and live in registers;
-//     K-step 1 and the lo plane are immediate offsets of the same address.
-//   * LDS layout of a stage: per plane [X chunk 0][X chunk 1][gY chunk 0][gY chunk 1], every second chunk 128 B further than
-//     its size: the two 16-lane halves of a transpose read address the two chunks of a pair, and with chunk sizes that are
-//     multiples of 256 B (the bank row) they met on the same banks — SQ_LDS_BANK_CONFLICT = 48 % of SQ_LDS_IDX_ACTIVE.
-//   * DMA issue per tile is a handful of VALU ops: the per-lane source offsets are tile-invariant too, a tile adds one
-//     wave-uniform base and two range checks.
-template <int NT>
-struct Wg3Cfg {
-    using C = WgCfg<3, 3, NT>;
-    static constexpr int XS = C::XBYTES + 128, GS = C::GBYTES + 128;     // chunk strides (bank offset, see above)
-    static constexpr int G0 = 2 * XS;                                   // gY chunks behind the two X chunks
-    static constexpr int PLANE = 2 * XS + 2 * GS;
-    static constexpr int STAGE = C::NPL * PLANE;
-    static constexpr int LDS_BYTES = 2 * STAGE;
-    static constexpr int NXJ = (C::XP + 7) / 8;                           // X pieces per wave (8 waves)
-    static_assert(C::GP == 8, "one gY piece (= one pixel row) per wave");
-    static_assert(PLANE + 512 + 128 < 65536, "lo plane / K-step reachable with the 16-bit DS offset");
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-};
-
-// DMA of one tile's planes into stage `buf` (8 waves; the tile-invariant per-lane parts come from the caller's registers)
-template <int NT>
-__device__ __forceinline__ void wg3_issue(const WgradKArgs& a, char* smem, int tile, int buf, int cp, int cot, int dy0, int wave,
-                                          const int* x_py, const int* x_px, const int* x_src, int g_px, int g_src,
-                                          long long plane_elems, unsigned plane_bytes) {
-    using C = WgCfg<3, 3, NT>;
-    using G = Wg3Cfg<NT>;
-    const int H = a.H, W = a.W;
-    int b = tile;
-#if BINHIP_WG3_STRIDE_WALK      // (see the macro's comment at the top of the file)
-    const int tx = b % a.tiles_x; b /= a.tiles_x;
-    const int ty = b % a.tiles_y;
-    const int img = b / a.tiles_y;
-#else
-    const int ty = b % a.tiles_y; b /= a.tiles_y;
-    const int tx = b % a.tiles_x;
-    const int img = b / a.tiles_x;
-#endif
-    const int tx0 = tx * 32, ty0 = ty * C::TH;
-    const int y0 = ty0 + dy0 - 1, x0 = tx0 - 1;
-    const long long row0 = (long long)img * H;
-    const int xbase = (int)(((row0 + y0) * W + x0) * 32);           // may be negative at the image border (then !ok)
-    const int gbase = (int)(((row0 + ty0) * W + tx0) * 32);
-    unsigned xvo[G::NXJ];
-#pragma unroll
-    for (int j = 0; j < G::NXJ; ++j) {
-        const bool ok = (unsigned)(y0 + x_py[j]) < (unsigned)H && (unsigned)(x0 + x_px[j]) < (unsigned)W;
-        xvo[j] = ok ? (unsigned)(xbase + x_src[j]) : 0x80000000u;
-    }
-    const bool gok = (ty0 + wave < H) && (tx0 + g_px < W);
-    const unsigned gvo = gok ? (unsigned)(gbase + g_src) : 0x80000000u;
-    char* stage = smem + buf * G::STAGE;
-#pragma unroll
-    for (int pl = 0; pl < C::NPL; ++pl)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int c = 2 * cp + h;
-            const _Float16* xb = pl ? a.x_lo : a.x_hi;
-            const long long coff = (a.x_cpg > 0)
-                ? (long long)(c / a.x_cpg) * a.x_group_stride + (long long)(c % a.x_cpg) * plane_elems
-                : (long long)c * plane_elems;
-            const bool have = c < a.cin_chunks;
-            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(have ? xb + coff : xb), 0,
-                                                                          have ? plane_bytes : 0u, 0x00020000);
-            char* lds = stage + pl * G::PLANE + h * G::XS;
-#pragma unroll
-            for (int j = 0; j < G::NXJ; ++j)
-                if (wave + 8 * j < C::XP)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(lds + (wave + 8 * j) * 1024), 16, xvo[j], 0, 0, 0);
-            const int gc = 2 * cot + h;
-            const bool haveg = gc < a.cout_chunks;
-            const _Float16* gb = pl ? a.g_lo : a.g_hi;
-            __amdgpu_buffer_rsrc_t gs = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(haveg ? gb + (long long)gc * plane_elems : gb), 0, haveg ? plane_bytes : 0u, 0x00020000);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(gs, (lds_void_t*)(stage + pl * G::PLANE + G::G0 + h * G::GS + wave * 1024),
-                                                     16, gvo, 0, 0, 0);
-        }
-}
-
-template <int NT>
-__global__ void __launch_bounds__(512)
-wgrad3x3_db_kernel(const WgradKArgs a) {
-    using C = WgCfg<3, 3, NT>;
-    using G = Wg3Cfg<NT>;
-    constexpr int KS = 3, NTAP = 9, NSTEP = 2 * NTAP;
-    constexpr int NA = (NT == 3) ? 4 : 2;                                // read instructions of one step's A fragments
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // = pixel row of the 8 x 32 tile
-    int pb, cp, bz;
-    wg_block(a, pb, cp, bz);
-    const int cot = bz % a.ncot;
-    const int dy0 = (bz / a.ncot) * 3;
-    const int H = a.H, W = a.W;
-    const long long plane_elems = (long long)a.N * H * W * 16;
-    const unsigned plane_bytes = (unsigned)(plane_elems * 2);
-    const bool do_bias = (cp == 0) && (dy0 == 0);
-
-    floatx16 acc[NTAP];
-    float bsum = 0.f;
-#pragma unroll
-    for (int t = 0; t < NTAP; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-
-    // ---- tile-invariant per-lane state -------------------------------------------------------------------------
-    // fragment reads: LDS offsets (relative to a stage) of the two 4-pixel reads of tap t, K-step 0, hi plane
-    unsigned xa[NTAP], xb2[NTAP];
-    {
-        const int tt = lane & 15, ch = (lane >> 4) & 1, kg = lane >> 5;
-#pragma unroll
-        for (int t = 0; t < NTAP; ++t) {
-            const int p0 = (wave + t / KS) * C::PW + t % KS;
-            const int pa = p0 + kg * 8 + (tt >> 2), pb4 = pa + 4;
-            const unsigned base = (unsigned)(ch * G::XS + ((tt & 1) << 3));
-            xa[t] = base + pa * 32 + ((((tt & 3) >> 1) ^ ((pa >> 3) & 1)) << 4);
-            xb2[t] = base + pb4 * 32 + ((((tt & 3) >> 1) ^ ((pb4 >> 3) & 1)) << 4);
-        }
-    }
-    const unsigned g_off = (unsigned)G::G0 + tr_lane_off(G::GS, lane) + wave * 32 * 32;
-    // DMA pieces of this wave: X patch pieces wave, wave + 8 (10 x 34 pixels, 32 B each, 64 lanes x 16 B per piece) and gY
-    // piece `wave` = pixel row `wave` of the tile.  Source offset = tile base (wave-uniform) + lane part.
-    int x_py[G::NXJ], x_px[G::NXJ], x_src[G::NXJ];
-#pragma unroll
-    for (int j = 0; j < G::NXJ; ++j) {
-        const int q = (wave + 8 * j) * 64 + lane;
-        const int p = q >> 1, sh = q & 1;
-        const bool in_patch = (wave + 8 * j < C::XP) && (p < C::PH * C::PW);
-        x_py[j] = in_patch ? p / C::PW : -(1 << 20);                       // out-of-patch lanes fail the range check
-        x_px[j] = p % C::PW;
-        x_src[j] = (x_py[j] * W + x_px[j]) * 32 + ((sh ^ ((p >> 3) & 1)) << 4);
-    }
-    const int g_px = lane >> 1;
-    const int g_src = (wave * W + g_px) * 32 + (((lane & 1) ^ ((g_px >> 3) & 1)) << 4);
-
-    // this workgroup's contiguous share of the tiles (balanced to within one tile)
-#if BINHIP_WG3_STRIDE_WALK
-    int tile = pb;
-    const int tend = a.ntiles, tstep = a.PB;
-#else
-    int tile = (int)(((long long)pb * a.ntiles) / a.PB);
-    const int tend = (int)(((long long)(pb + 1) * a.ntiles) / a.PB), tstep = 1;
-#endif
-    if (tile < tend && !(a.dbg & 1))
-        wg3_issue<NT>(a, smem, tile, 0, cp, cot, dy0, wave, x_py, x_px, x_src, g_px, g_src, plane_elems, plane_bytes);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int cur = 0;
-    for (; tile < tend; tile += tstep) {
-        const int nxt = tile + tstep;
-        if (nxt < tend && !(a.dbg & 1))
-            wg3_issue<NT>(a, smem, nxt, cur ^ 1, cp, cot, dy0, wave, x_py, x_px, x_src, g_px, g_src, plane_elems, plane_bytes);
-        if (!(a.dbg & 2)) {
-            const unsigned st = lds_addr(smem + cur * G::STAGE);
-            TrFrag Bh[2], Bl[2], Ah[3], Al[3];
-            auto load = [&](auto SC) {
-                constexpr int s = decltype(SC)::value, ks = s / NTAP, t = s % NTAP, q = s % 3;
+constexpr int R3_SEG = 16;     // rolling-row kernel (side builds): pixel rows per column segment
 #if BINHIP_TUNING
-                if (a.dbg & 8) return;                 // ablation: MFMAs on stale registers, no LDS fragment reads
+// round 1-3 kernels that the product does not dispatch (lean single-stage, wave = gY row, rolling rows): side builds only
+#include "../../tools/experiments/wgrad_experiments.inc"
 #endif
-                if constexpr (t == 0) {
-                    tr_issue_pair<ks * 512>(Bh[ks], st + g_off, st + g_off + 128);
-                    if constexpr (NT == 3) tr_issue_pair<ks * 512 + G::PLANE>(Bl[ks], st + g_off, st + g_off + 128);
-                }
-                tr_issue_pair<ks * 512>(Ah[q], st + xa[t], st + xb2[t]);
-                if constexpr (NT == 3) tr_issue_pair<ks * 512 + G::PLANE>(Al[q], st + xa[t], st + xb2[t]);
-            };
-            load(std::integral_constant<int, 0>{});
-            load(std::integral_constant<int, 1>{});
-            static_for([&](auto SC) {
-                constexpr int s = decltype(SC)::value, ks = s / NTAP, t = s % NTAP, q = s % 3;
-                // outstanding: the reads of steps s and s + 1, in issue order -> leave step s + 1's in flight
-                constexpr int later = (s + 1 < NSTEP) ? NA + (((s + 1) % NTAP == 0) ? NA : 0) : 0;
-                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(later) : "memory");
-                tr_tie(Ah[q]);
-                if constexpr (NT == 3) tr_tie(Al[q]);
-                if constexpr (t == 0) {
-                    tr_tie(Bh[ks]);
-                    if constexpr (NT == 3) tr_tie(Bl[ks]);
-                }
-                if constexpr (s + 2 < NSTEP) load(std::integral_constant<int, s + 2>{});
-                __builtin_amdgcn_sched_barrier(0);
-                const half8 bh = tr_value(Bh[ks]);
-                half8 bl;
-                if constexpr (NT == 3) bl = tr_value(Bl[ks]);
-                if (t == 0 && do_bias) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        bsum += (float)bh[e];
-                        if constexpr (NT == 3) bsum += (float)bl[e];
-                    }
-                }
-                const half8 ah = tr_value(Ah[q]);
-                if constexpr (NT == 3) {
-                    const half8 al = tr_value(Al[q]);
-                    // (the three products of a tap chain on one accumulator; spreading them over three accumulators in a
-                    //  timing-only build changed nothing: 237.6 vs 241.8 us — the chain is not what stalls the waves)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
-                }
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }, std::make_integer_sequence<int, NSTEP>{});
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        cur ^= 1;
-    }
 
-    if (a.dbg & 4) { if (acc[0][0] == 12345.f) a.partial[0] = bsum; return; }
-    // ---- the eight rows are summed through LDS in a fixed order: one partial per workgroup and tap
-    float* red = reinterpret_cast<float*>(smem);          // [8 waves][32 m][32 n]
-    const int n = lane & 31, hi = lane >> 5;
-    const long long blk = ((long long)bz * a.ncp + cp) * a.PB + pb;
-#pragma unroll
-    for (int t = 0; t < NTAP; ++t) {
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 16; ++e) red[wave * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * hi) * 32 + n] = acc[t][e];
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 512 * i;
-            a.partial[(blk * NTAP + t) * 1024 + idx] =
-                ((red[idx] + red[1024 + idx]) + (red[2048 + idx] + red[3072 + idx])) +
-                ((red[4096 + idx] + red[5120 + idx]) + (red[6144 + idx] + red[7168 + idx]));
-        }
-    }
-    if (do_bias) {
-        __syncthreads();
-        red[tid] = bsum;                              // [wave][kg][co]
-        __syncthreads();
-        if (tid < 32) {
-            float tsum = 0.f;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) tsum += red[k * 32 + tid];
-            a.partial_b[((long long)cot * a.PB + pb) * 32 + tid] = tsum;
-        }
-    }
-}
-
-// 3x3 layers, X-ROW form of the eight-wave kernel (round 3).  Above, wave w owns gY row w of the tile and reads, per K-step,
+// 3x3 layers, X-ROW form of the eight-wave kernel (round 3; the product's 3x3 weight gradient).  Its round-2 predecessor
+// (wgrad3x3_db_kernel, now in tools/experiments/wgrad_experiments.inc: eight waves, two LDS stages fed by LDS-DMA, transpose
+// reads issued from asm, chunk pairs 128 B apart against bank conflicts) gave wave w gY row w of the tile; it read, per K-step,
 // one gY fragment pair and NINE tap-shifted X fragments (rows w .. w + 2 of a 10-row halo patch): 20 fragments for 27 MFMAs —
 // fragment reads + DMA writes keep the LDS ~87 % busy, and the DMA prefetch measurably does not overlap with the multiply
 // (tools/bench_wgrad.py, 160 -> 32: MFMAs alone 104 us, + fragment reads 132, DMA alone 107, all together 210 = the SUM).
@@ -989,534 +651,6 @@ wgrad3x3_xrow_kernel(const WgradKArgs a) {
     }
 }
 
-constexpr int R3_SEG = 16;     // rolling-row kernel (side builds): pixel rows per column segment
-#if BINHIP_TUNING
-// ---------------------------------------------------------------------------------------------------------------
-// 3x3 layers, ROLLING-ROW kernel — an experiment kept in BINHIP_TUNING side builds (flag 128), NOT the product path: correct
-// (tests/test_gpu_backward.py passes against it) but slower than the eight-wave kernel above, see the numbers at the end.  Both kernels above load a halo patch
-// and a gY tile per (pixel tile, channel pair): 76 KB of LDS traffic for 32 ci x 32 co x 9 taps x 256 pixels, the gY tile
-// once per channel pair, the X rows 1.25x — 0.97 GB through L2 -> LDS for 0.39 GB of operands in a 160 -> 32 layer at
-// 40 x 128 x 128, and that path (~9 TB/s with nothing else running), not HBM and not the matrix cores, set their time
-// (tools/bench_wgrad.py: DMA alone 108 us, fragment reads + MFMAs alone 132 us, together 217-254 us).
-// Here one workgroup owns ALL channel pairs of its group (<= 6 = 192 channels) and walks DOWN a 32-pixel-wide column
-// segment of one image, one pixel row per stage:
-//   * LDS holds a ring of four X rows (34 pixels x all chunks x hi/lo, a flat list of 16-byte units so that the DMA pieces are
-//     dense: unit u = chunk u / 68, pixel (u % 68) / 2 - 1) and two gY rows; stage y multiplies gY row y with X rows y-1, y, y+1
-//     while X row y + 2 and gY row y + 1 land.  Every operand byte enters LDS once per column segment (+ 2 halo rows per 16).
-//   * wave w owns the (pair, tap) output tiles w * TPW .. w * TPW + TPW - 1 of the group's ppg * 9: no K-split, no
-//     cross-wave reduction, 16 * TPW accumulator registers; per K-step it reads the gY fragment once and one X fragment per
-//     tile (tap (dy, dx) = ring slot y + dy - 1, pixel offset dx — per-tile lane addresses are loop invariants).
-//   * chunk offsets ride in the 32-bit buffer offset (one descriptor per plane), hence r3_usable(): contiguous chunks and
-//     cin_chunks * plane bytes < 4 GiB; everything else takes the eight-wave kernel above.
-// Measured (tools/bench_wgrad.py, 40 x 128 x 128, f16x3, us per layer incl. ~24 us of reduction; lean / eight-wave / rolling):
-//     96 -> 32: 145 / 129 / 186      160 -> 32: 217 / 206 / 284      192 -> 32: 264 / 252 / 324      96 -> 96: 342 / 365 / 518
-// HBM-side and L2 -> LDS traffic are 2.5x lower, but a stage is ONE pixel row = 36 MFMAs per wave between barriers, and the
-// per-stage costs (barrier skew, the first two fragment loads that cannot be issued before the barrier, DMA issue) take
-// ~40 % of it: fragment reads + MFMAs alone run 174 us against 123 us for the eight-wave kernel.  Two rows per stage would
-// need a 6-row ring = 168 KB of LDS at 192 channels.
-
-template <int NT, int TPW>
-struct R3Cfg {
-    static constexpr int NPL = (NT == 3) ? 2 : 1;
-    static constexpr int PPG = (8 * TPW) / 9;                                   // channel pairs per workgroup
-    static_assert((PPG * 9 + 7) / 8 == TPW && PPG >= 1 && PPG <= 6, "tiles per wave <-> pairs per group");
-    static constexpr int CU = 72;                                               // 16-byte units per chunk row: 68 (34 pixels) + 4 of
-                                                                                // padding, so that the chunk stride is 128 mod 256 B
-                                                                                // (the two halves of a transpose read on disjoint banks)
-    static constexpr int UNITS = CU * 2 * PPG;                                  // units of one plane row
-    static constexpr int XP = (UNITS + 63) / 64;                                // DMA pieces per plane row
-    static constexpr int XROW = XP * 1024;
-    static constexpr int XSLOT = NPL * XROW;                                    // one ring slot: hi row, lo row
-    static constexpr int GCH = 1024 + 128;                                      // gY chunk stride (bank offset)
-    static constexpr int GSLOT = NPL * 2 * GCH;
-    static constexpr int NXS = 5, NGS = 3;                                      // ring depths: X rows y-1..y+1 in use + 2 landing
-    static constexpr int G_BASE = NXS * XSLOT;
-    static constexpr int LDS_BYTES = G_BASE + NGS * GSLOT;
-    static constexpr int NXJ = (NPL * XP + 7) / 8;                              // X pieces per wave and row (upper bound)
-    static constexpr int NX_MIN = (NPL * XP) / 8;                               // ... lower bound: what every wave issues per stage
-    static_assert(XROW + 512 + 128 < 65536 && 2 * GCH + 512 + 128 < 65536, "plane / K-step offsets fit the DS immediate");
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-};
-
-// DMA of X row y0 - 1 + q into ring slot q % 5 (this wave's pieces) / of gY row y0 + j into slot j % 3 (waves 0..3)
-template <int NT, int TPW>
-__device__ __forceinline__ void r3_issue_x(char* smem, int q, int wave, int y0, int H, int W, unsigned imgrow,
-                                           __amdgpu_buffer_rsrc_t rs0, __amdgpu_buffer_rsrc_t rs1, const bool* xok,
-                                           const unsigned* xcol) {
-    using R = R3Cfg<NT, TPW>;
-    const int y = y0 - 1 + q;
-    const bool rowok = (unsigned)y < (unsigned)H;
-    const unsigned rowbase = (imgrow + (unsigned)y) * (unsigned)W * 32u;
-    char* slot = smem + (q % R::NXS) * R::XSLOT;
-#pragma unroll
-    for (int j = 0; j < R::NXJ; ++j) {
-        const int piece = wave + 8 * j;
-        if (piece < R::NPL * R::XP) {
-            const unsigned vo = (rowok && xok[j]) ? rowbase + xcol[j] : 0xfffffff0u;
-            if (NT == 3 && piece >= R::XP)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_void_t*)(slot + piece * 1024), 16, vo, 0, 0, 0);
-            else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_void_t*)(slot + piece * 1024), 16, vo, 0, 0, 0);
-        }
-    }
-}
-template <int NT, int TPW>
-__device__ __forceinline__ void r3_issue_g(char* smem, int j, int wave, int y0, int H, int W, unsigned imgrow,
-                                           __amdgpu_buffer_rsrc_t rs, bool gcol, unsigned gcolsrc, int piece) {
-    using R = R3Cfg<NT, TPW>;
-    if (wave < 2 * R::NPL) {
-        const int y = y0 + j;
-        const unsigned vo = ((y < H) && gcol) ? (imgrow + (unsigned)y) * (unsigned)W * 32u + gcolsrc : 0xfffffff0u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(smem + R::G_BASE + (j % R::NGS) * R::GSLOT + piece * R::GCH), 16, vo, 0, 0, 0);
-    }
-}
-
-template <int NT, int TPW>
-__global__ void __launch_bounds__(512)
-wgrad3x3_roll_kernel(const WgradKArgs a) {
-    using R = R3Cfg<NT, TPW>;
-    constexpr int NSTEP = 2 * TPW;
-    constexpr int NA = (NT == 3) ? 4 : 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pb = blockIdx.x;
-    const int cgroups = a.cgroups;
-    const int cg = blockIdx.y % cgroups, cot = blockIdx.y / cgroups;
-    const int cp0 = cg * R::PPG;
-    const int H = a.H, W = a.W;
-    const long long plane_elems = (long long)a.N * H * W * 16;
-    const unsigned plane_bytes = (unsigned)(plane_elems * 2);
-    const bool bias_wave = (cg == 0) && (wave == 7);
-
-    // ---- this wave's output tiles
-    int t_dy[TPW];
-    bool t_ok[TPW];
-    unsigned xa[TPW], xb[TPW];                          // per-lane LDS offsets (within a ring slot) of the two 4-pixel reads, K-step 0, hi
-    {
-        const int tt = lane & 15, ch = (lane >> 4) & 1, kg = lane >> 5;
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            const int k = wave * TPW + i;
-            const int pr = k / 9, tap = k % 9;
-            t_ok[i] = (k < R::PPG * 9) && (cp0 + pr < a.ncp);
-            t_dy[i] = tap / 3;
-            const int dx = tap % 3;
-            const int pa = dx + kg * 8 + (tt >> 2), pb4 = pa + 4;      // pixel slot 0..33 of the row (slot 0 = column tx0 - 1)
-            const unsigned base = (unsigned)(((t_ok[i] ? pr : 0) * 2 + ch) * (R::CU * 16) + ((tt & 1) << 3));
-            xa[i] = base + pa * 32 + ((((tt & 3) >> 1) ^ ((pa >> 3) & 1)) << 4);
-            xb[i] = base + pb4 * 32 + ((((tt & 3) >> 1) ^ ((pb4 >> 3) & 1)) << 4);
-        }
-    }
-    const unsigned g_off = tr_lane_off(R::GCH, lane);
-    const int* dyp = t_dy;                              // (lambdas below capture pointers: arrays with template-dependent
-                                                        //  bounds captured by reference break hipcc's host pass)
-    const unsigned *xap = xa, *xbp = xb;
-
-    floatx16 acc[TPW];
-    floatx16* accp = acc;
-    float bsum = 0.f;
-#pragma unroll
-    for (int i = 0; i < TPW; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-
-    // ---- tile-invariant DMA state: X pieces wave, wave + 8, ... of the NPL * XP pieces of a ring slot; gY pieces on waves 0..3
-    int x_px[R::NXJ];                                   // pixel slot, or a large negative = no such unit
-    unsigned x_src[R::NXJ];                             // chunk offset + pixel-slot part of the source offset
-#pragma unroll
-    for (int j = 0; j < R::NXJ; ++j) {
-        const int piece = wave + 8 * j;
-        const int u = (piece % R::XP) * 64 + lane;
-        const int cl = u / R::CU, within = u % R::CU;
-        const int pp = within >> 1, sh = within & 1;
-        const int c = 2 * cp0 + cl;
-        const bool have = (piece < R::NPL * R::XP) && (within < 68) && (cl < 2 * R::PPG) && (c < a.cin_chunks);
-        x_px[j] = have ? pp : -(1 << 20);
-        x_src[j] = (unsigned)c * plane_bytes + (unsigned)(pp * 32 + ((sh ^ ((pp >> 3) & 1)) << 4));
-    }
-    const int g_px = lane >> 1;
-    const unsigned g_src = (unsigned)(g_px * 32 + (((lane & 1) ^ ((g_px >> 3) & 1)) << 4));
-    const int g_pl = (wave >> 1) & 1, g_h = wave & 1;   // gY piece of waves 0..3: plane, chunk of the output tile
-    const int g_c = 2 * cot + g_h;
-    const bool g_have = (wave < 2 * R::NPL) && (g_c < a.cout_chunks);
-
-    const unsigned xbytes = (unsigned)a.cin_chunks * plane_bytes;              // < 4 GiB - 16 (r3_usable)
-    __amdgpu_buffer_rsrc_t x_rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x_hi, 0, xbytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t x_rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(NT == 3 ? a.x_lo : a.x_hi), 0, xbytes, 0x00020000);
-    const _Float16* g_ptr = (g_pl ? a.g_lo : a.g_hi) + (long long)(g_have ? g_c : 0) * plane_elems;
-    __amdgpu_buffer_rsrc_t g_rs = __builtin_amdgcn_make_buffer_rsrc((void*)g_ptr, 0, g_have ? plane_bytes : 0u, 0x00020000);
-
-    for (int unit = pb; unit < a.ntiles; unit += a.PB) {
-        int b = unit;
-        const int seg = b % a.tiles_y; b /= a.tiles_y;
-        const int tx = b % a.tiles_x;
-        const int img = b / a.tiles_x;
-        const int tx0 = tx * 32, y0 = seg * R3_SEG;
-        const int rows = (H - y0 < R3_SEG) ? H - y0 : R3_SEG;
-        // column part of the source offsets of this unit (modular unsigned arithmetic: tx0 - 1 may be -1)
-        unsigned xcol[R::NXJ];
-        bool xok[R::NXJ];
-#pragma unroll
-        for (int j = 0; j < R::NXJ; ++j) {
-            xok[j] = (unsigned)(tx0 - 1 + x_px[j]) < (unsigned)W;
-            xcol[j] = x_src[j] + (unsigned)((tx0 - 1) * 32);
-        }
-        const bool gcol = tx0 + g_px < W;
-        const unsigned gcolsrc = g_src + (unsigned)(tx0 * 32);
-        const unsigned imgrow = (unsigned)img * (unsigned)H;
-        // X row y0 - 1 + q lives in ring slot q % 5, gY row y0 + j in slot j % 3.  Stage j multiplies rows q = j, j+1, j+2 while
-        // q = j+3 (issued during stage j-1) and q = j+4 (issued now) land: two stages of flight time per row.
-        if (!(a.dbg & 1)) {
-            for (int q = 0; q < 4; ++q) r3_issue_x<NT, TPW>(smem, q, wave, y0, H, W, imgrow, x_rs0, x_rs1, xok, xcol);
-            r3_issue_g<NT, TPW>(smem, 0, wave, y0, H, W, imgrow, g_rs, gcol, gcolsrc, g_pl * 2 + g_h);
-            r3_issue_g<NT, TPW>(smem, 1, wave, y0, H, W, imgrow, g_rs, gcol, gcolsrc, g_pl * 2 + g_h);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (int j = 0; j < rows; ++j) {
-            if (!(a.dbg & 1)) {
-                r3_issue_x<NT, TPW>(smem, j + 4, wave, y0, H, W, imgrow, x_rs0, x_rs1, xok, xcol);
-                if (j + 2 < rows) r3_issue_g<NT, TPW>(smem, j + 2, wave, y0, H, W, imgrow, g_rs, gcol, gcolsrc, g_pl * 2 + g_h);
-            }
-            if (!(a.dbg & 2)) {
-                const unsigned x0s = lds_addr(smem);
-                unsigned sb[3];
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy) sb[dy] = x0s + ((j + dy) % R::NXS) * R::XSLOT;
-                const unsigned gs = x0s + R::G_BASE + (j % R::NGS) * R::GSLOT + g_off;
-                TrFrag Bh[2], Bl[2], Ah[3], Al[3];
-                auto load = [&](auto SC) {
-                    constexpr int s = decltype(SC)::value, ks = s / TPW, i = s % TPW, q = s % 3;
-                    if constexpr (i == 0) {
-                        tr_issue_pair<ks * 512>(Bh[ks], gs, gs + 128);
-                        if constexpr (NT == 3) tr_issue_pair<ks * 512 + 2 * R::GCH>(Bl[ks], gs, gs + 128);
-                    }
-                    const unsigned rb = dyp[i] == 0 ? sb[0] : (dyp[i] == 1 ? sb[1] : sb[2]);
-                    tr_issue_pair<ks * 512>(Ah[q], rb + xap[i], rb + xbp[i]);
-                    if constexpr (NT == 3) tr_issue_pair<ks * 512 + R::XROW>(Al[q], rb + xap[i], rb + xbp[i]);
-                };
-                load(std::integral_constant<int, 0>{});
-                load(std::integral_constant<int, 1>{});
-                static_for([&](auto SC) {
-                    constexpr int s = decltype(SC)::value, ks = s / TPW, i = s % TPW, q = s % 3;
-                    constexpr int later = (s + 1 < NSTEP) ? NA + (((s + 1) % TPW == 0) ? NA : 0) : 0;
-                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(later) : "memory");
-                    tr_tie(Ah[q]);
-                    if constexpr (NT == 3) tr_tie(Al[q]);
-                    if constexpr (i == 0) {
-                        tr_tie(Bh[ks]);
-                        if constexpr (NT == 3) tr_tie(Bl[ks]);
-                    }
-                    if constexpr (s + 2 < NSTEP) load(std::integral_constant<int, s + 2>{});
-                    __builtin_amdgcn_sched_barrier(0);
-                    const half8 bh = tr_value(Bh[ks]);
-                    half8 bl;
-                    if constexpr (NT == 3) bl = tr_value(Bl[ks]);
-                    if (i == 0 && bias_wave) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            bsum += (float)bh[e];
-                            if constexpr (NT == 3) bsum += (float)bl[e];
-                        }
-                    }
-                    {   // unused tile slots multiply too (never stored): no branch in the MFMA stream
-                        const half8 ah = tr_value(Ah[q]);
-                        if constexpr (NT == 3) {
-                            const half8 al = tr_value(Al[q]);
-                            accp[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accp[i], 0, 0, 0);
-                            accp[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accp[i], 0, 0, 0);
-                        }
-                        accp[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accp[i], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }, std::make_integer_sequence<int, NSTEP>{});
-            }
-            // what the NEXT stage reads was issued one stage ago: leave this stage's own pieces in flight.  Every wave issues at
-            // least NX_MIN X pieces per stage and they are its newest requests, so vmcnt(NX_MIN) covers all older ones.
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R::NX_MIN) : "memory");
-            __syncthreads();
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // rows beyond the segment: drain before the ring is refilled
-        __syncthreads();
-    }
-
-    if (a.dbg & 4) { if (acc[0][0] == 12345.f) a.partial[0] = bsum; return; }
-    // ---- every tile is complete in its wave: straight to the partial buffer (layout of the other 3x3 kernels: block
-    // (z = cot, cp, pb), 9 taps of [32 ci][32 co])
-    const int n = lane & 31, hi = lane >> 5;
-#pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        if (!t_ok[i]) continue;
-        const int k = wave * TPW + i;
-        const int cp = cp0 + k / 9, tap = k % 9;
-        float* dst = a.partial + ((((long long)cot * a.ncp + cp) * a.PB + pb) * 9 + tap) * 1024 + n;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2) + 4 * hi) * 32] = acc[i][e];
-    }
-    if (bias_wave) {
-        const float t = bsum + __shfl_xor(bsum, 32);
-        if (lane < 32) a.partial_b[((long long)cot * a.PB + pb) * 32 + lane] = t;
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------
-// 3x3 layers, rolling rows with TWO pixel rows per stage (round 3; BINHIP_TUNING flag 64).  Same walk and LDS images as
-// the one-row kernel above, but a stage multiplies output rows j and j + 1 (X rows j-1 .. j+2 of a six-slot ring, gY rows
-// j, j+1 of a four-slot ring) while the next stage's two X rows and two gY rows land: twice the MFMAs between barriers
-// (4 * TPW steps x 3 products) for 1.2x the ring.  The ring only fits for <= 4 channel pairs per workgroup (6 x 18 KB +
-// 4 x 4.6 KB = 126 KB), so layers with 5 / 6 pairs run as two channel groups (3 + 2 / 3 + 3) and read their gY twice —
-// against five / six times in the eight-wave kernel.
-template <int NT, int TPW>
-struct R3Cfg2 {
-    static constexpr int NPL = (NT == 3) ? 2 : 1;
-    static constexpr int PPG = (8 * TPW) / 9;
-    static_assert((PPG * 9 + 7) / 8 == TPW && PPG >= 1 && PPG <= 4, "tiles per wave <-> pairs per group");
-    static constexpr int CU = 72;
-    static constexpr int UNITS = CU * 2 * PPG;
-    static constexpr int XP = (UNITS + 63) / 64;
-    static constexpr int XROW = XP * 1024;
-    static constexpr int XSLOT = NPL * XROW;
-    static constexpr int GCH = 1024 + 128;
-    static constexpr int GSLOT = NPL * 2 * GCH;
-    static constexpr int NXS = 6, NGS = 4;
-    static constexpr int G_BASE = NXS * XSLOT;
-    static constexpr int LDS_BYTES = G_BASE + NGS * GSLOT;
-    static constexpr int NXJ = (NPL * XP + 7) / 8;
-    static_assert(XROW + 512 + 128 < 65536 && 2 * GCH + 512 + 128 < 65536, "plane / K-step offsets fit the DS immediate");
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-};
-
-template <class R, int NT>
-__device__ __forceinline__ void r32_issue_x(char* smem, int q, int wave, int y0, int H, int W, unsigned imgrow,
-                                            __amdgpu_buffer_rsrc_t rs0, __amdgpu_buffer_rsrc_t rs1, const bool* xok,
-                                            const unsigned* xcol) {
-    const int y = y0 - 1 + q;
-    const bool rowok = (unsigned)y < (unsigned)H;
-    const unsigned rowbase = (imgrow + (unsigned)y) * (unsigned)W * 32u;
-    char* slot = smem + (q % R::NXS) * R::XSLOT;
-#pragma unroll
-    for (int j = 0; j < R::NXJ; ++j) {
-        const int piece = wave + 8 * j;
-        if (piece < R::NPL * R::XP) {
-            const unsigned vo = (rowok && xok[j]) ? rowbase + xcol[j] : 0xfffffff0u;
-            if (NT == 3 && piece >= R::XP)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_void_t*)(slot + piece * 1024), 16, vo, 0, 0, 0);
-            else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_void_t*)(slot + piece * 1024), 16, vo, 0, 0, 0);
-        }
-    }
-}
-template <class R>
-__device__ __forceinline__ void r32_issue_g(char* smem, int j, int wave, int y0, int H, int W, unsigned imgrow,
-                                            __amdgpu_buffer_rsrc_t rs, bool gcol, unsigned gcolsrc, int piece) {
-    if (wave < 2 * R::NPL) {
-        const int y = y0 + j;
-        const unsigned vo = ((y < H) && gcol) ? (imgrow + (unsigned)y) * (unsigned)W * 32u + gcolsrc : 0xfffffff0u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(smem + R::G_BASE + (j % R::NGS) * R::GSLOT + piece * R::GCH), 16, vo, 0, 0, 0);
-    }
-}
-
-template <int NT, int TPW>
-__global__ void __launch_bounds__(512)
-wgrad3x3_roll2_kernel(const WgradKArgs a) {
-    using R = R3Cfg2<NT, TPW>;
-    constexpr int NSTEP = 4 * TPW;                      // 2 rows x 2 K-steps x TPW tiles
-    constexpr int NA = (NT == 3) ? 4 : 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pb = blockIdx.x;
-    const int cgroups = a.cgroups;
-    const int cg = blockIdx.y % cgroups, cot = blockIdx.y / cgroups;
-    const int cp0 = cg * a.ppg;                         // balanced groups: ppg = ceil(ncp / cgroups) <= R::PPG
-    const int H = a.H, W = a.W;
-    const long long plane_elems = (long long)a.N * H * W * 16;
-    const unsigned plane_bytes = (unsigned)(plane_elems * 2);
-    const bool bias_wave = (cg == 0) && (wave == 0);
-
-    // ---- this wave's output tiles (pair, tap): slots wave * TPW .. + TPW - 1 of the group's ppg * 9
-    int t_dy[TPW];
-    bool t_ok[TPW];
-    unsigned xa[TPW], xb[TPW];
-    {
-        const int tt = lane & 15, ch = (lane >> 4) & 1, kg = lane >> 5;
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            const int k = wave * TPW + i;
-            const int pr = k / 9, tap = k % 9;
-            t_ok[i] = (pr < a.ppg) && (cp0 + pr < a.ncp);
-            t_dy[i] = tap / 3;
-            const int dx = tap % 3;
-            const int pa = dx + kg * 8 + (tt >> 2), pb4 = pa + 4;
-            const unsigned base = (unsigned)(((t_ok[i] ? pr : 0) * 2 + ch) * (R::CU * 16) + ((tt & 1) << 3));
-            xa[i] = base + pa * 32 + ((((tt & 3) >> 1) ^ ((pa >> 3) & 1)) << 4);
-            xb[i] = base + pb4 * 32 + ((((tt & 3) >> 1) ^ ((pb4 >> 3) & 1)) << 4);
-        }
-    }
-    const bool wave_has = t_ok[0];                      // slots are filled in order: an empty first slot = an idle wave
-    const unsigned g_off = tr_lane_off(R::GCH, lane);
-    const int* dyp = t_dy;
-    const bool* okp = t_ok;
-    const unsigned *xap = xa, *xbp = xb;
-
-    floatx16 acc[TPW];
-    floatx16* accp = acc;
-    float bsum = 0.f;
-#pragma unroll
-    for (int i = 0; i < TPW; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-
-    int x_px[R::NXJ];
-    unsigned x_src[R::NXJ];
-#pragma unroll
-    for (int j = 0; j < R::NXJ; ++j) {
-        const int piece = wave + 8 * j;
-        const int u = (piece % R::XP) * 64 + lane;
-        const int cl = u / R::CU, within = u % R::CU;
-        const int pp = within >> 1, sh = within & 1;
-        const int c = 2 * cp0 + cl;
-        const bool have = (piece < R::NPL * R::XP) && (within < 68) && (cl < 2 * a.ppg) && (c < a.cin_chunks);
-        x_px[j] = have ? pp : -(1 << 20);
-        x_src[j] = (unsigned)c * plane_bytes + (unsigned)(pp * 32 + ((sh ^ ((pp >> 3) & 1)) << 4));
-    }
-    const int g_px = lane >> 1;
-    const unsigned g_src = (unsigned)(g_px * 32 + (((lane & 1) ^ ((g_px >> 3) & 1)) << 4));
-    const int g_pl = (wave >> 1) & 1, g_h = wave & 1;
-    const int g_c = 2 * cot + g_h;
-    const bool g_have = (wave < 2 * R::NPL) && (g_c < a.cout_chunks);
-
-    const unsigned xbytes = (unsigned)a.cin_chunks * plane_bytes;
-    __amdgpu_buffer_rsrc_t x_rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x_hi, 0, xbytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t x_rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(NT == 3 ? a.x_lo : a.x_hi), 0, xbytes, 0x00020000);
-    const _Float16* g_ptr = (g_pl ? a.g_lo : a.g_hi) + (long long)(g_have ? g_c : 0) * plane_elems;
-    __amdgpu_buffer_rsrc_t g_rs = __builtin_amdgcn_make_buffer_rsrc((void*)g_ptr, 0, g_have ? plane_bytes : 0u, 0x00020000);
-
-    for (int unit = pb; unit < a.ntiles; unit += a.PB) {
-        int b = unit;
-        const int seg = b % a.tiles_y; b /= a.tiles_y;
-        const int tx = b % a.tiles_x;
-        const int img = b / a.tiles_x;
-        const int tx0 = tx * 32, y0 = seg * R3_SEG;
-        const int rows = (H - y0 < R3_SEG) ? H - y0 : R3_SEG;
-        const int nst = (rows + 1) >> 1;
-        unsigned xcol[R::NXJ];
-        bool xok[R::NXJ];
-#pragma unroll
-        for (int j = 0; j < R::NXJ; ++j) {
-            xok[j] = (unsigned)(tx0 - 1 + x_px[j]) < (unsigned)W;
-            xcol[j] = x_src[j] + (unsigned)((tx0 - 1) * 32);
-        }
-        const bool gcol = tx0 + g_px < W;
-        const unsigned gcolsrc = g_src + (unsigned)(tx0 * 32);
-        const unsigned imgrow = (unsigned)img * (unsigned)H;
-        // X row y0 - 1 + q lives in ring slot q % 6, gY row y0 + j in slot j % 4.  Stage st (rows j = 2 st, j + 1) multiplies X
-        // rows q = j .. j + 3 and gY rows j, j + 1 while q = j + 4, j + 5 and gY rows j + 2, j + 3 (issued at its start) land.
-        if (!(a.dbg & 1)) {
-            for (int q = 0; q < 4; ++q) r32_issue_x<R, NT>(smem, q, wave, y0, H, W, imgrow, x_rs0, x_rs1, xok, xcol);
-            r32_issue_g<R>(smem, 0, wave, y0, H, W, imgrow, g_rs, gcol, gcolsrc, g_pl * 2 + g_h);
-            r32_issue_g<R>(smem, 1, wave, y0, H, W, imgrow, g_rs, gcol, gcolsrc, g_pl * 2 + g_h);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (int st = 0; st < nst; ++st) {
-            const int j = 2 * st;
-            if (!(a.dbg & 1) && st + 1 < nst) {
-                r32_issue_x<R, NT>(smem, j + 4, wave, y0, H, W, imgrow, x_rs0, x_rs1, xok, xcol);
-                r32_issue_x<R, NT>(smem, j + 5, wave, y0, H, W, imgrow, x_rs0, x_rs1, xok, xcol);
-                r32_issue_g<R>(smem, j + 2, wave, y0, H, W, imgrow, g_rs, gcol, gcolsrc, g_pl * 2 + g_h);
-                r32_issue_g<R>(smem, j + 3, wave, y0, H, W, imgrow, g_rs, gcol, gcolsrc, g_pl * 2 + g_h);
-            }
-            if (!(a.dbg & 2) && wave_has) {
-                const unsigned x0s = lds_addr(smem);
-                // ring slots of X rows j-1 .. j+2 (four scalars: a runtime-indexed array would live in scratch) and, per tile,
-                // the slot of its tap row for the stage's first / second output row
-                const unsigned s0 = x0s + ((j + 0) % R::NXS) * R::XSLOT, s1 = x0s + ((j + 1) % R::NXS) * R::XSLOT;
-                const unsigned s2 = x0s + ((j + 2) % R::NXS) * R::XSLOT, s3 = x0s + ((j + 3) % R::NXS) * R::XSLOT;
-                unsigned rb0[TPW], rb1[TPW];
-#pragma unroll
-                for (int i = 0; i < TPW; ++i) {
-                    rb0[i] = dyp[i] == 0 ? s0 : (dyp[i] == 1 ? s1 : s2);
-                    rb1[i] = dyp[i] == 0 ? s1 : (dyp[i] == 1 ? s2 : s3);
-                }
-                const unsigned g0 = x0s + R::G_BASE + ((j + 0) % R::NGS) * R::GSLOT + g_off;
-                const unsigned g1 = x0s + R::G_BASE + ((j + 1) % R::NGS) * R::GSLOT + g_off;
-                const unsigned *rb0p = rb0, *rb1p = rb1;
-                TrFrag Bh[2], Bl[2], Ah[3], Al[3];
-                auto load = [&](auto SC) {
-                    constexpr int s = decltype(SC)::value, blk = s / TPW, r = blk / 2, ks = blk % 2, i = s % TPW, q = s % 3;
-                    const unsigned gs = r == 0 ? g0 : g1;
-                    if constexpr (i == 0) {
-                        tr_issue_pair<ks * 512>(Bh[blk & 1], gs, gs + 128);
-                        if constexpr (NT == 3) tr_issue_pair<ks * 512 + 2 * R::GCH>(Bl[blk & 1], gs, gs + 128);
-                    }
-                    const unsigned rb = r == 0 ? rb0p[i] : rb1p[i];
-                    tr_issue_pair<ks * 512>(Ah[q], rb + xap[i], rb + xbp[i]);
-                    if constexpr (NT == 3) tr_issue_pair<ks * 512 + R::XROW>(Al[q], rb + xap[i], rb + xbp[i]);
-                };
-                load(std::integral_constant<int, 0>{});
-                load(std::integral_constant<int, 1>{});
-                static_for([&](auto SC) {
-                    constexpr int s = decltype(SC)::value, blk = s / TPW, i = s % TPW, q = s % 3;
-                    constexpr int later = (s + 1 < NSTEP) ? NA + (((s + 1) % TPW == 0) ? NA : 0) : 0;
-                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(later) : "memory");
-                    tr_tie(Ah[q]);
-                    if constexpr (NT == 3) tr_tie(Al[q]);
-                    if constexpr (i == 0) {
-                        tr_tie(Bh[blk & 1]);
-                        if constexpr (NT == 3) tr_tie(Bl[blk & 1]);
-                    }
-                    if constexpr (s + 2 < NSTEP) load(std::integral_constant<int, s + 2>{});
-                    __builtin_amdgcn_sched_barrier(0);
-                    const half8 bh = tr_value(Bh[blk & 1]);
-                    half8 bl;
-                    if constexpr (NT == 3) bl = tr_value(Bl[blk & 1]);
-                    if (i == 0 && bias_wave) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            bsum += (float)bh[e];
-                            if constexpr (NT == 3) bsum += (float)bl[e];
-                        }
-                    }
-                    if (okp[i]) {                       // wave-uniform: empty tile slots cost their (already issued) reads only
-                        const half8 ah = tr_value(Ah[q]);
-                        if constexpr (NT == 3) {
-                            const half8 al = tr_value(Al[q]);
-                            accp[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accp[i], 0, 0, 0);
-                            accp[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accp[i], 0, 0, 0);
-                        }
-                        accp[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accp[i], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }, std::make_integer_sequence<int, NSTEP>{});
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-    }
-
-    if (a.dbg & 4) { if (acc[0][0] == 12345.f) a.partial[0] = bsum; return; }
-    const int n = lane & 31, hi = lane >> 5;
-#pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        if (!t_ok[i]) continue;
-        const int k = wave * TPW + i;
-        const int cp = cp0 + k / 9, tap = k % 9;
-        float* dst = a.partial + ((((long long)cot * a.ncp + cp) * a.PB + pb) * 9 + tap) * 1024 + n;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2) + 4 * hi) * 32] = acc[i][e];
-    }
-    if (bias_wave) {
-        const float t = bsum + __shfl_xor(bsum, 32);
-        if (lane < 32) a.partial_b[((long long)cot * a.PB + pb) * 32 + lane] = t;
-    }
-}
-
-#endif  // BINHIP_TUNING (rolling-row experiment)
 
 // ---------------------------------------------------------------------------------------------------------------
 // 1x1 convolutions (LFF 224->96, GFF.0 1152->96).  A 1x1 weight gradient does 2*Cin*Cout flops per pixel for
@@ -1904,6 +1038,7 @@ int launch_wg(const WgradKArgs& a, const WgGeom& g, hipStream_t s) {
     return 0;
 }
 
+#if BINHIP_TUNING
 template <int KS, int TR, int NT>
 int launch_wg_sb(const WgradKArgs& a, const WgGeom& g, hipStream_t s) {
     using C = WgCfg<KS, TR, NT>;
@@ -1915,6 +1050,7 @@ int launch_wg_sb(const WgradKArgs& a, const WgGeom& g, hipStream_t s) {
     BH_CHECK_LAUNCH();
     return 0;
 }
+#endif
 
 template <int NT>
 int launch_wg3x(const WgradKArgs& a, const WgGeom& g, hipStream_t s) {
@@ -1925,6 +1061,7 @@ int launch_wg3x(const WgradKArgs& a, const WgGeom& g, hipStream_t s) {
     return 0;
 }
 
+#if BINHIP_TUNING
 template <int NT>
 int launch_wg3(const WgradKArgs& a, const WgGeom& g, hipStream_t s) {
     using C = WgCfg<3, 3, NT>;
@@ -1934,6 +1071,7 @@ int launch_wg3(const WgradKArgs& a, const WgGeom& g, hipStream_t s) {
     BH_CHECK_LAUNCH();
     return 0;
 }
+#endif
 
 #if BINHIP_TUNING
 template <int NT, int TPW>
@@ -2071,11 +1209,14 @@ int bh_wgrad_partials(const BinConvDesc* d, const void* x_hi, const void* x_lo, 
         a.cgroups = rp.cgroups;
         rc = (d->nterms == 1) ? launch_r3<1>(a, g, rp, s) : launch_r3<3>(a, g, rp, s);
 #endif
-    } else if (d->ksize == 3 && ((BINHIP_WG3_XROW != 0) != (((WG_DBG >> 16) & 1) != 0))) {
-        // eight waves, two LDS stages, one workgroup per CU; wave = X row (tuning builds: debug bit 16 flips the choice)
-        rc = (d->nterms == 1) ? launch_wg3x<1>(a, g, s) : launch_wg3x<3>(a, g, s);
-    } else if (d->ksize == 3) {                     // the same with wave = gY row (round 2)
+#if BINHIP_TUNING
+    } else if (d->ksize == 3 && ((BINHIP_WG3_XROW != 0) == (((WG_DBG >> 16) & 1) != 0))) {
+        // side builds: the round-2 form, wave = gY row (debug bit 16, or -DBINHIP_WG3_XROW=0 to make it the side build's default)
         rc = (d->nterms == 1) ? launch_wg3<1>(a, g, s) : launch_wg3<3>(a, g, s);
+#endif
+    } else if (d->ksize == 3) {
+        // eight waves, two LDS stages, one workgroup per CU; wave = X row
+        rc = (d->nterms == 1) ? launch_wg3x<1>(a, g, s) : launch_wg3x<3>(a, g, s);
     } else if (d->ksize == 1) {                     // 1x1 with more than 96 outputs (not on the bin_stage4 path)
         rc = (d->nterms == 1) ? launch_wg<1, 1, 1>(a, g, s) : launch_wg<1, 1, 3>(a, g, s);
     } else {                                        // 5x5 (SFENet1)

@@ -25,8 +25,7 @@ def test_asm_transpose_reads_are_waited_for(tmp_path):
     assert not bad, bad[:5]
     bad, kernels, n_reads = check(str(out), "wgrad_mfma_kernel")      # the generic double-buffered kernel (5x5, wide 1x1)
     assert kernels == 4 and n_reads > 100 and not bad, (kernels, n_reads, bad[:5])
-    bad, kernels, n_reads = check(str(out), "wgrad3x3_db_kernel")     # the 3x3 kernel: 80 (f16x3) + 40 (f16) reads per tile
-    assert kernels == 2 and n_reads == 120 and not bad, (kernels, n_reads, bad[:5])
+    assert "wgrad3x3_db_kernel" not in out.read_text()               # round 2's form lives in tools/experiments (side builds)
     bad, kernels, n_reads = check(str(out), "wgrad3x3_xrow_kernel")   # wave = X row (round 3): 48 + 24 reads per tile
     assert kernels == 2 and n_reads == 72 and not bad, (kernels, n_reads, bad[:5])
     # and the reason for the asm: no compiler-inserted vmcnt(0) between the prefetch DMA and the fragment reads of a stage

@@ -44,6 +44,21 @@ def test_library_exports_nothing_but_the_abi():
     assert dyn == set(build.abi_symbols()) == set(_lib.exported_symbols()), dyn ^ set(build.abi_symbols())
 
 
+def test_product_library_contains_only_dispatched_weight_gradient_kernels():
+    """The experimental weight-gradient kernels of rounds 1-3 (lean single-stage, wave = gY row, rolling rows) live in
+    tools/experiments/wgrad_experiments.inc and are compiled by `--tuning` side builds only: neither their host stubs nor
+    their device symbols are in the product .so, and the product source stays under 1 500 lines."""
+    from bin_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for name in (b"wgrad3x3_db_kernel", b"wgrad3x3_roll", b"wgrad_mfma_sb_kernel"):
+        assert name not in blob, name
+    for name in (b"wgrad3x3_xrow_kernel", b"wgrad1x1_kernel", b"wgrad_mfma_kernel", b"wgrad_reduce_kernel"):
+        assert name in blob, name
+    src = os.path.join(REPO, "bin_amd", "csrc", "binhip_wgrad.hip")
+    assert sum(1 for _ in open(src)) < 1500
+    assert os.path.exists(os.path.join(REPO, "tools", "experiments", "wgrad_experiments.inc"))
+
+
 def test_header_version_and_export_count_match_the_library():
     """include/binhip.h carries BINHIP_VERSION (what binhip_version() returns) and BINHIP_ABI_EXPORTS (the number of
     BINHIP_API declarations): a binder can check both at compile / load time."""
