@@ -19,6 +19,11 @@ Extra objects on the JSON line:
                  measured with HIP events on the launch stream; `traffic` from the committed per-precision PMC passes
   cpu_baseline — the oracle (CPU restatement, kind "port") on the host cores: ONE full-size 768x1344 forward
   train        — BASELINE config 3/4 (8 x 256x256 crops per GPU, fwd + Charbonnier + bwd + Adam), own sub-object
+  power        — shader clock / package power of the SAME work repeated right after the timed region (nothing samples inside it)
+  power_bound  — the same forwards (and training steps) on ALL-ZERO operands right after: same instruction streams, idle
+                 datapaths; ms / ms_zero next to the two clocks is the evidence for "this mode sits on the package power cap"
+  harness      — N1 end to end: PNG files -> decode -> device u8 kernel -> net -> u8 kernel -> PNG files (bin_amd.test's folder
+                 pipeline, f16x3, IO threads beside the GPU work) next to the same schedule with frames resident in HBM
 """
 import argparse
 import ctypes
@@ -110,13 +115,19 @@ def pmc_traffic(precision):
     this same command (profiles/r03_pmc_traffic.json, else r02_: separate FETCH_SIZE / WRITE_SIZE runs per precision, FETCH
     doubled per the gfx950 calibration).  PMC counters cannot be read from inside the process, so bench.py reports the
     profiled figure, or null when no pass for this precision is committed."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in PMC_FILES:
         try:
             with open(os.path.join(REPO, "profiles", name)) as f:
-                return int(json.load(f)[precision]["traffic_bytes_per_launch"])
+                return int(json.load(f)[precision]["traffic_bytes_per_launch"]), "profiles/" + name
         except Exception:
             pass
-    return None
+    return None, None
+
+
+PMC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")
+TRAFFIC_NOTE = ("HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same command (separate FETCH_SIZE / "
+                "WRITE_SIZE runs, gfx950 corrections per MI355X_MICROARCH.md); PMC counters cannot be read in-process, so this "
+                "is NOT measured by this run — `traffic_source` names the file")
 
 
 def cpu_model():
@@ -214,6 +225,27 @@ def cpu_baseline(timeout_s=420):
             "sample": "cpu baseline failed: " + (err_txt.strip().splitlines() or ["?"])[-1][:200]}
 
 
+def power_bound_object(ms, power, zero, what):
+    """`power`: sampler summary of the real-data power pass, `zero`: of the all-zero-operand pass (both carry ms_per_repetition)."""
+    def mean(d, k):
+        v = (d or {}).get(k)
+        return v.get("mean") if isinstance(v, dict) else None
+    ms_zero = zero.get("ms_per_repetition")
+    ms_data = power.get("ms_per_repetition")
+    return {"what": f"{what}: the same launches on all-zero operands (same instruction streams, idle datapaths), right after the "
+                    "timed region",
+            "ms": round(ms, 3), "ms_data_pass": ms_data, "ms_zero": ms_zero,
+            "ratio": None if not ms_zero else round(ms / ms_zero, 4),
+            "clock_mhz": {"data": mean(power, "clock_mhz"), "zero": mean(zero, "clock_mhz")},
+            "clock_ratio": (None if not (mean(power, "clock_mhz") and mean(zero, "clock_mhz"))
+                            else round(mean(zero, "clock_mhz") / mean(power, "clock_mhz"), 4)),
+            "power_w": {"data": mean(power, "power_w"), "zero": mean(zero, "power_w")},
+            "power_cap_w": power.get("power_cap_w"),
+            "reading": "ratio ~ clock_ratio > 1 with power_w.data at the cap and power_w.zero below it: the real-data run is "
+                       "limited by the clock the package power cap leaves, not by its instruction schedule",
+            "zero_pass_repetitions": zero.get("repetitions")}
+
+
 def max_over_ranks(dt, dev, world):
     """Slowest rank's time (the contract's max-over-ranks).  nccl (= RCCL) reduces on the device; the gloo hook used to run
     the N > 1 flow on ONE GPU (tests/test_gpu_round3.py) reduces a host tensor."""
@@ -224,6 +256,77 @@ def max_over_ranks(dt, dev, world):
     t = torch.tensor([dt], dtype=torch.float64, device="cpu" if host else dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+HARNESS_YML = """\
+name: bench_harness
+model: bin
+distortion: blur
+scale: 4
+gpu_ids: [0]
+use_tb_logger: false
+datasets:
+  val:
+    name: test
+    mode: BIN
+    dataroot_GT: {tmp}
+    dataroot_LQ: {tmp}
+network_G:
+  which_model_G: bin_stage4
+  nframes: 6
+  version: 2
+path:
+  pretrain_model_G: ~
+  save_path: {tmp}
+  strict_load: true
+  resume_state: ~
+"""
+
+
+def harness_bench(precision, n_frames, gpu_only_fps, io_threads=12):
+    """SURVEY 8f N1 end to end, what a user of the reference's test.py runs (test.py:334-402): a folder of 720p PNG frames in, the
+    interpolated + deblurred PNG frames out, through `bin_amd.test` (decode on a thread pool -> device u8 kernel + padding ->
+    net with the exact stage-1 reuse -> device clamp/round/crop kernel -> D2H on a copy stream -> PNG encode on the pool).
+    The frames are written to TMPDIR BEFORE anything is timed (smooth seeded images + mild noise, so the PNG codec sees
+    realistic entropy); the folder is run twice into fresh output folders, the second pass (warm kernels, page cache) is the
+    one reported; its wall time includes every decode, copy, encode and file write.  `gpu_only` = the same schedule with the
+    frames resident in HBM (this line's `streaming` leg, same precision)."""
+    import shutil
+    import tempfile
+    import numpy as np
+    from PIL import Image
+    from bin_amd import test as run_test
+    tmp = tempfile.mkdtemp(prefix="bin_amd_harness_")
+    try:
+        g = np.random.Generator(np.random.PCG64(1))
+        yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+        clip = os.path.join(tmp, "test_blur", "clip0")
+        os.makedirs(clip)
+        for k in range(n_frames):
+            img = np.stack([127 + 100 * np.sin((xx + 9 * k) / 37.0 + c) * np.cos((yy - 5 * k) / 53.0 - c) for c in range(3)], -1)
+            img = (img + g.normal(0, 2.0, img.shape)).clip(0, 255).astype(np.uint8)
+            Image.fromarray(img).save(os.path.join(clip, f"{8 * k:05d}.png"), compress_level=1)
+        yml = os.path.join(tmp, "o.yml")
+        with open(yml, "w") as f:
+            f.write(HARNESS_YML.format(tmp=tmp))
+        stats = None
+        for rep in range(2):
+            stats = {}
+            run_test.main(["--input_path", os.path.join(tmp, "test_blur"), "--output_path", os.path.join(tmp, f"out{rep}"),
+                           "--opt", yml, "--precision", precision, "--io_threads", str(io_threads)], stats=stats)
+        n_png = sum(1 for _, _, fs in os.walk(os.path.join(tmp, "out1")) for x in fs if x.endswith(".png"))
+        fps = stats["windows"] / stats["wall"]
+        return {"frames_per_s": round(fps, 3), "unit": "interpolated frames/s, PNG files in -> PNG files out",
+                "gpu_only_frames_per_s": None if gpu_only_fps is None else round(gpu_only_fps, 3),
+                "io_overlap_frac": None if not gpu_only_fps else round(fps / gpu_only_fps, 4),
+                "windows": stats["windows"], "input_frames": n_frames, "wall_s": round(stats["wall"], 3),
+                "net_and_glue_ms_per_window": round(stats["net_s_per_window"] * 1e3, 2), "png_files_written": n_png,
+                "precision": precision, "io_threads": io_threads,
+                "note": "second of two passes over the same folder into a fresh output folder; wall time covers decode, H2D, the "
+                        "u8 kernels, the net (13 RDN calls per window: exact stage-1 reuse), D2H, PNG encode and file writes; "
+                        "gpu_only = the `streaming` leg of this line (frames resident in HBM, same schedule and precision)"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def train_bench(args, rank, world, dev, steps=None, warmup=None, standalone=True):
@@ -268,19 +371,26 @@ def train_bench(args, rank, world, dev, steps=None, warmup=None, standalone=True
         torch.cuda.synchronize()
 
     from bin_amd import ops, _lib as L
-    from bin_amd.utils.smi import Sampler
+    from bin_amd.utils.smi import power_pass
     torch.cuda.reset_peak_memory_stats()
     for i in range(warmup):
         m.optimize_parameters(i + 1)
     sync_all()
-    smi = Sampler(dev.index or 0).start()
     t0 = time.perf_counter()
     for i in range(steps):
         m.optimize_parameters(warmup + i + 1)
     sync_all()
     dt = time.perf_counter() - t0
-    power = smi.stop()
     ops.check_status()                       # no activation / gradient left the fp16 storage range
+    loss_value = float(m.loss.detach())
+    # clock / package power of the same steps, sampled in a pass of its own (every rank runs it: collectives stay matched)
+    counter = [warmup + steps]
+
+    def one_step():
+        counter[0] += 1
+        m.optimize_parameters(counter[0])
+    # (a FIXED number of steps: every rank must issue the same collectives)
+    power = power_pass(one_step, dev, repetitions=(1 if args.no_power else 6), sync=torch.cuda.synchronize)
     # ---- roofline of the step and of its dominant kernel (3x3 weight gradient): two more steps AFTER the timed region
     # with the weight-gradient launches bracketed by HIP events on the stream they run on (BINHIP_PROF_WGRAD)
     # Two passes of two steps: (a) as in the timed steps (weight gradients on the side stream, sharing the chip with the
@@ -290,7 +400,7 @@ def train_bench(args, rank, world, dev, steps=None, warmup=None, standalone=True
     lib = L.lib()
     net = m.netG.module
     prof_steps = 2
-    step_no = warmup + steps
+    step_no = counter[0]
     for exclusive in (False, True):
         handle = ctypes.c_void_p(0)
         if rank == 0:                        # every rank runs the extra steps (collectives stay matched); rank 0 times them
@@ -317,17 +427,32 @@ def train_bench(args, rank, world, dev, steps=None, warmup=None, standalone=True
                 else:
                     kern_overlapped = kms.value / kn.value * 1e-3
     dt = max_over_ranks(dt, dev, world)
+    # ---- zero-operand control: the SAME steps with all-zero batch and weights — identical launches
+    # and instruction streams, idle datapaths.  Last thing this model does (its weights are gone afterwards).
+    power_bound = None
+    if not args.zero_data and not args.no_power:
+        with torch.no_grad():
+            for prm in m.netG.module.parameters():
+                prm.zero_()
+        m.feed_data({k: torch.zeros_like(v) for k, v in batch.items()})
+        for _ in range(2):
+            one_step()
+        torch.cuda.synchronize()
+        zero = power_pass(one_step, dev, repetitions=5, sync=torch.cuda.synchronize)
+        power_bound = power_bound_object(dt / steps * 1e3, power, zero, "training step")
+        ops.check_status()
     line = {
         "metric": "training samples/sec (256x256 crops, 6-frame windows)", "value": round(world * B * steps / dt, 4),
         "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": round(dt / steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": DTYPE[prec] + (" forward; single-product backward on the hi planes" if bwd_prec else ""),
         "data": ("all-zero operands (diagnostic, INVALID as a result)" if args.zero_data else "synthetic"),
-        "loss": float(m.loss.detach()),
+        "loss": loss_value,
         "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2),
         "nccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1),
         "backend": (dist.get_backend() if dist.is_initialized() else None),
         "power": power,
+        "power_bound": power_bound,
         "roofline": train_roofline(B, S, dt / steps, prec, bwd_prec, kern, kern_overlapped),
         "config": {"workload": f"Adobe240 training, 256x256 crops, batch {B} per GPU, Charbonnier x17, Adam, "
                                f"DP flat gradient all-reduce (45.77 MB)", "precision": prec,
@@ -359,19 +484,36 @@ def kernel_roofline(prec, kern_ms, kern_n, hp, wp, ms, reuse_schedule):
     assert ach <= HBM_PEAK_GBS, f"kernel algorithmic rate {ach:.0f} GB/s exceeds the HBM peak"
     assert whole_gbs <= HBM_PEAK_GBS, f"whole-forward algorithmic rate {whole_gbs:.0f} GB/s exceeds the HBM peak"
     kname = ("conv_x3_kernel<3,2,8,0,0,false>" if prec == "f16x3" else "conv_mfma_kernel<3,1,1,2,8,1,1,2,0,false>")
-    return {"bound": "hbm", "kernel": kname + " (RDB conv3x3 Cin->32 +ReLU, convs 0-2 of each dense block)",
-            "precision": prec, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 4),
-            "traffic": pmc_traffic(prec), "avg_kernel_us": round(avg_s * 1e6, 2), "launches": kern_n,
+    # Which roof?  Arithmetic intensity at the mode's storage width against the ridge of its product count: f16x3 executes 3
+    # MFMA products per algorithmic multiply-add, so its ridge is 2500 / 3 TFLOP/s / 8 TB/s = 104 FLOP/B and the kernel's
+    # 115 FLOP/B sits ON / above it -> the matrix pipe is the roof, and that pipe runs at the clock the package power cap
+    # leaves (`power`, `power_bound`).  f16: 230 FLOP/B against a ridge of 312 -> HBM.
+    ai = rdb_conv_flops(1, hp // 2, wp // 2) / ab
+    ridge = MFMA_PEAK_TF * 1e12 / PRODUCTS[prec] / (HBM_PEAK_GBS * 1e9)
+    traffic, traffic_src = pmc_traffic(prec)
+    hbm = {"achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}
+    mfma = {"achieved": round(mf, 1), "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(mf / MFMA_PEAK_TF, 4),
+            "note": f"executed MFMA FLOPs = {PRODUCTS[prec]} x the conv's algorithmic FLOPs; peak = nominal dense fp16 "
+                    "at 2.4 GHz — scale by power.clock_mhz / 2400 for the peak at the clock this run held",
+            "reference_sustained_at_power_cap": {
+                "random_fp16": 1663.0, "zeros": 2473.0, "unit": "TFLOP/s",
+                "source": "profiles/r02_power_cap.md (register-resident v_mfma_f32_32x32x16_f16 alone, "
+                          "tools/probe_mfma_power.hip); a round-2 measurement, NOT taken in this run — this run's "
+                          "own clock, package power and zero-operand control are in `power` / `power_bound`"}}
+    mfma_bound = ai >= ridge
+    top = mfma if mfma_bound else hbm
+    return {"bound": "mfma" if mfma_bound else "hbm",
+            "regime": ("mfma@power-cap: arithmetic intensity at or above the ridge of the 3-product scheme; the matrix pipe runs at "
+                       "the clock the package power cap leaves (see power / power_bound)") if mfma_bound
+                      else "hbm: arithmetic intensity below the ridge",
+            "arithmetic_intensity_flop_per_byte": round(ai, 1), "ridge_flop_per_byte": round(ridge, 1),
+            "kernel": kname + " (RDB conv3x3 Cin->32 +ReLU, convs 0-2 of each dense block)",
+            "precision": prec, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
+            "traffic": traffic, "traffic_source": traffic_src, "traffic_note": TRAFFIC_NOTE,
+            "avg_kernel_us": round(avg_s * 1e6, 2), "launches": kern_n,
             "algorithmic_bytes_per_launch": int(ab), "bytes_per_element": BYTES_PER_ELEM[prec],
-            "mfma": {"achieved": round(mf, 1), "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(mf / MFMA_PEAK_TF, 4),
-                     "note": f"executed MFMA FLOPs = {PRODUCTS[prec]} x the conv's algorithmic FLOPs; peak = nominal dense fp16 "
-                             "at 2.4 GHz — scale by power.clock_mhz / 2400 for the peak at the clock this run held",
-                     "reference_sustained_at_power_cap": {
-                         "random_fp16": 1663.0, "zeros": 2473.0, "unit": "TFLOP/s",
-                         "source": "profiles/r02_power_cap.md (register-resident v_mfma_f32_32x32x16_f16 alone, "
-                                   "tools/probe_mfma_power.hip); a round-2 measurement, NOT taken in this run — this run's "
-                                   "own clock and package power are in `power`"}},
+            "algorithmic_flop_per_launch": int(rdb_conv_flops(1, hp // 2, wp // 2)),
+            "hbm": hbm, "mfma": mfma,
             "whole_forward": {"algorithmic_GB": round(abytes / 1e9, 1), "achieved_GBs": round(whole_gbs, 1),
                               "frac_hbm": round(whole_gbs / HBM_PEAK_GBS, 4),
                               "algorithmic_TFLOP": round(flops / 1e12, 3),
@@ -401,14 +543,23 @@ def train_roofline(batch, size, step_s, prec, bwd_prec, kern, kern_overlapped=No
         avg_s, n = kern
         kf, kb = wgrad3x3_launch_model(batch, h2, w2)
         kb *= BYTES_PER_ELEM[prec] / 4.0
+        wg_traffic, wg_src = pmc_wgrad_traffic()
+        wg_ai, wg_ridge = kf / kb, MFMA_PEAK_TF * 1e12 / prod_b / (HBM_PEAK_GBS * 1e9)
         out["dominant_kernel"] = {
             "kernel": "wgrad3x3_xrow_kernel (3x3 weight gradient of the dense-block convs, Cin = 96..192 -> 32)",
             "avg_kernel_us": round(avg_s * 1e6, 2), "launches": n, "launches_per_step": 4 * 48,
             "share_of_step": round(avg_s * 4 * 48 / step_s, 4),
             "avg_kernel_us_beside_backward_data": None if kern_overlapped is None else round(kern_overlapped * 1e6, 2),
-            "algorithmic_bytes_per_launch": int(kb), "bound": "hbm", "achieved": round(kb / avg_s / 1e9, 1),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(kb / avg_s / 1e9 / HBM_PEAK_GBS, 4),
-            "traffic": pmc_wgrad_traffic(),
+            "algorithmic_bytes_per_launch": int(kb),
+            "bound": "mfma" if wg_ai >= wg_ridge else "hbm",
+            "regime": "mfma@power-cap" if wg_ai >= wg_ridge else "hbm",
+            "arithmetic_intensity_flop_per_byte": round(wg_ai, 1), "ridge_flop_per_byte": round(wg_ridge, 1),
+            "achieved": round((kf * prod_b / avg_s / 1e12) if wg_ai >= wg_ridge else (kb / avg_s / 1e9), 1),
+            "peak": MFMA_PEAK_TF if wg_ai >= wg_ridge else HBM_PEAK_GBS, "unit": "TFLOP/s" if wg_ai >= wg_ridge else "GB/s",
+            "frac": round((kf * prod_b / avg_s / 1e12 / MFMA_PEAK_TF) if wg_ai >= wg_ridge else (kb / avg_s / 1e9 / HBM_PEAK_GBS), 4),
+            "hbm": {"achieved": round(kb / avg_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(kb / avg_s / 1e9 / HBM_PEAK_GBS, 4)},
+            "traffic": wg_traffic, "traffic_source": wg_src,
             "mfma": {"achieved": round(kf * prod_b / avg_s / 1e12, 1), "peak": MFMA_PEAK_TF, "unit": "TFLOP/s",
                      "frac": round(kf * prod_b / avg_s / 1e12 / MFMA_PEAK_TF, 4)},
             "timing": "HIP event pairs around each launch, 2 steps right after the timed region with the weight gradients on the "
@@ -420,15 +571,15 @@ def train_roofline(batch, size, step_s, prec, bwd_prec, kern, kern_overlapped=No
 
 def pmc_wgrad_traffic():
     """HBM-side bytes per launch of the 3x3 weight-gradient kernel from the committed PMC passes (profiles/), or null."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in PMC_FILES:
         try:
             with open(os.path.join(REPO, "profiles", name)) as f:
                 v = json.load(f).get("wgrad3x3")
             if v:
-                return int(v["traffic_bytes_per_launch"])
+                return int(v["traffic_bytes_per_launch"]), "profiles/" + name
         except Exception:
             pass
-    return None
+    return None, None
 
 
 def main():
@@ -446,6 +597,10 @@ def main():
                     help="A/B: force the four-call schedule (stage s of both windows batched along N; the default only for "
                          "small frames and training) for the 720p inference window")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-power", action="store_true",
+                    help="skip the power passes after the timed regions (clock / watts sampling, the zero-operand control)")
+    ap.add_argument("--no-harness", action="store_true", help="skip the PNG-in -> PNG-out folder leg")
+    ap.add_argument("--harness-frames", type=int, default=21, help="synthetic 720p PNG frames of the folder leg")
     ap.add_argument("--calib", action="store_true",
                     help="also run one 256 MiB device copy (known HBM bytes) to calibrate rocprofv3 FETCH/WRITE_SIZE")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
@@ -545,15 +700,15 @@ def main():
         # still runs.  Measured +0.4 % (31.43 vs 31.30 frames/s): every kernel already fills both workgroup slots of
         # every CU, so another stream's kernels only slip into the ramp/drain.  Off by default.
         kw_in = {"input_events": []} if (net.resolved_streams() > 1 and not args.four_calls and args.pipeline) else {}
-        from bin_amd.utils.smi import Sampler
-        smi = Sampler(dev.index)                # shader clock / package power DURING the timed region (host thread)
-        smi.start()
+        from bin_amd.utils.smi import power_pass
         t0 = time.perf_counter()
         for _ in range(args.steps):
             out = net(*frames, **kw_in)
         sync_all()
         dt = time.perf_counter() - t0
-        power = smi.stop()
+        # shader clock / package power of the same forwards, in a pass of its own right after the timed region
+        do_power = rank == 0 and not args.no_power
+        power = power_pass(lambda: net(*frames, **kw_in), dev, min_seconds=1.0, sync=torch.cuda.synchronize) if do_power else None
         # ---- roofline leg: the dominant kernel's mean duration, HIP events on the launch stream.  With several
         # streams kernels of different RDN calls overlap and a per-kernel duration is not meaningful, so this pass
         # re-runs the same forward serially (n_streams = 1) right after the timed region; `value` is unaffected.
@@ -613,14 +768,13 @@ def main():
             for _ in range(2):
                 net(*frames)
             torch.cuda.synchronize()
-            smi.start()
             ta = time.perf_counter()
             n_alt = max(3, args.steps // 2)
             for _ in range(n_alt):
                 net(*frames)
             torch.cuda.synchronize()
             t_alt = (time.perf_counter() - ta) / n_alt
-            alt_power = smi.stop()
+            alt_power = power_pass(lambda: net(*frames), dev, min_seconds=0.6, sync=torch.cuda.synchronize) if do_power else None
             alt_ms, alt_n = dominant_kernel_pass() if prof else (0.0, 0)
             alt = {"precision": other, "dtype": DTYPE[other], "value": round(1.0 / t_alt, 4),
                    "unit": "interpolated frames/s", "n_gpus": 1, "ms_per_step": round(t_alt * 1e3, 3),
@@ -629,6 +783,22 @@ def main():
                    "parity": "f16: max-abs <= 1e-3 / |dPSNR| <= 0.01 dB, f16x3: max-abs <= 2e-5 vs the fp32 reference "
                              "(tests/test_gpu_net.py incl. the full-size 720p fixture tests/golden/g8_720p.npz)"}
             net.set_precision(args.precision)
+            ops.check_status()
+        # ---- zero-operand control of the headline mode: same forwards, all-zero frames and weights
+        power_bound = None
+        if do_power and not args.zero_data:
+            saved = [prm.detach().clone() for prm in net.parameters()]
+            zframes = [torch.zeros_like(f) for f in frames]
+            for prm in net.parameters():
+                prm.zero_()
+            for _ in range(2):
+                net(*zframes, **kw_in)
+            torch.cuda.synchronize()
+            zero = power_pass(lambda: net(*zframes, **kw_in), dev, min_seconds=0.6, sync=torch.cuda.synchronize)
+            for prm, sv in zip(net.parameters(), saved):
+                prm.copy_(sv)
+            del saved, zframes
+            power_bound = power_bound_object(dt / args.steps * 1e3, power, zero, "720p window, " + args.precision)
             ops.check_status()
         if world > 1:
             dist.barrier()
@@ -644,6 +814,14 @@ def main():
             train = train_bench(args, rank, world, dev, steps=4, warmup=2, standalone=False)
         except Exception as e:          # the headline must still print
             train = {"error": f"{type(e).__name__}: {e}"[:300]}
+
+    # ---- N1 end to end: PNG folder in -> PNG folder out through bin_amd.test, headline precision
+    harness = None
+    if rank == 0 and world == 1 and not args.no_extras and not args.no_harness and not args.zero_data:
+        try:
+            harness = harness_bench(args.precision, args.harness_frames, stream_fps)
+        except Exception as e:          # the headline must still print
+            harness = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0:
         value = world * args.steps / dt
@@ -667,6 +845,8 @@ def main():
                                  else "max-abs <= 1e-3 (f16) vs the fp32 reference (tests/)"},
             "roofline": roof,
             "power": power,
+            "power_bound": power_bound,
+            "harness": harness,
             "nccl_ranks": (dist.get_world_size() if world > 1 else 1),
             "backend": (dist.get_backend() if world > 1 else None),
             "tolerance_mode" if other == "f16" else "fp32_class": alt,

@@ -103,7 +103,9 @@ def _score(sums, clip, kind, img_bgr, gt_path, want_ssim):
         sums.add(clip, kind + "_ssim", util.calculate_ssim(img_bgr, gt))
 
 
-def main(argv=None):
+def main(argv=None, stats=None):
+    """`stats` (optional dict, filled on rank 0): windows run, wall seconds incl. all IO, net + glue seconds per window —
+    what bench.py's `harness` leg reports."""
     args = parse_args(argv)
     opt = option.parse(args.opt, is_train=False)
     if args.launcher == "pytorch":
@@ -283,6 +285,8 @@ def main(argv=None):
         log.info("Avg. testset " + " ".join(f"{k} {tot[k]:.4f}" for k in METRICS))
         log.info("windows: %d  wall: %.2f s  -> %.2f interpolated frames/s (IO included); net+glue per window %.4f s",
                  n_win, wall, n_win / max(wall, 1e-9), timer.avg)
+        if stats is not None:
+            stats.update(windows=n_win, wall=wall, net_s_per_window=timer.avg)
     return 0
 
 

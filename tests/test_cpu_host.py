@@ -59,6 +59,19 @@ def test_product_library_contains_only_dispatched_weight_gradient_kernels():
     assert os.path.exists(os.path.join(REPO, "tools", "experiments", "wgrad_experiments.inc"))
 
 
+def test_bare_rdn_subnetwork_offers_the_direct_gradient_context():
+    """A bare RDN sub-network can be a wrapper's netG (VideoBaseModel's netG= injection): `direct_param_grads` is a METHOD on
+    it as on the whole network (round 3 shadowed it with a bool attribute there), and the wrapper's helper flips its flag."""
+    from bin_amd.models.archs.RDN import RDN_residual_interp_2_input, bin_stage4_lstm
+    from bin_amd.models.base_model import _direct_param_grads
+    for net in (RDN_residual_interp_2_input(96, 2, 4, 32), bin_stage4_lstm()):
+        mods = [net] if not hasattr(net, "rdn_modules") else net.rdn_modules()
+        assert not any(m._direct_grads for m in mods)
+        with _direct_param_grads(net):
+            assert all(m._direct_grads for m in mods)
+        assert not any(m._direct_grads for m in mods)
+
+
 def test_header_version_and_export_count_match_the_library():
     """include/binhip.h carries BINHIP_VERSION (what binhip_version() returns) and BINHIP_ABI_EXPORTS (the number of
     BINHIP_API declarations): a binder can check both at compile / load time."""

@@ -42,7 +42,7 @@ for step in "$@"; do
   echo "=== [$TAG] $verb $*"
   case $verb in
     tag) TAG=$1 ;;
-    env) export "$1" ;;
+    env) case "$1" in *=) unset "${1%=}" ;; *) export "$1" ;; esac ;;
     test)
       args="$*"; [ -z "$args" ] && args=tests
       ( timeout 2400 python -m pytest -m gpu -q $args 2>&1 | grep -E "passed|failed|rror|^E |^FAILED|^tests/.*(FAIL|ERR)" | tail -25 ) 2>&1 | tee -a gpurun_out/${TAG}_pytest.log ;;
