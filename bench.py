@@ -600,7 +600,7 @@ def main():
     ap.add_argument("--no-power", action="store_true",
                     help="skip the power passes after the timed regions (clock / watts sampling, the zero-operand control)")
     ap.add_argument("--no-harness", action="store_true", help="skip the PNG-in -> PNG-out folder leg")
-    ap.add_argument("--harness-frames", type=int, default=21, help="synthetic 720p PNG frames of the folder leg")
+    ap.add_argument("--harness-frames", type=int, default=41, help="synthetic 720p PNG frames of the folder leg")
     ap.add_argument("--calib", action="store_true",
                     help="also run one 256 MiB device copy (known HBM bytes) to calibrate rocprofv3 FETCH/WRITE_SIZE")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
