@@ -32,6 +32,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes); exported on the GPU boxes anyway
+
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
@@ -353,6 +355,9 @@ def train_bench(args, rank, world, dev, steps=None, warmup=None, standalone=True
                      "restarts": None, "restart_weights": None, "lr_gamma": 0.5, "clear_state": False}}
     m = create_model(opt)
     m.netG.module.load_state_dict(reference_state_dict(0), strict=True)
+    if prec == "f16":                        # timing diagnostic only: single-product training is gated (bin_amd/autograd.py)
+        for mod in m.netG.module.rdn_modules():
+            mod.allow_f16_training = True
     g = torch.Generator().manual_seed(7 + rank)
     B, S = args.batch, 256
     batch = {"LQs": torch.rand(B, 6, 3, S, S, generator=g), "GTenh": torch.rand(B, 6, 3, S, S, generator=g),

@@ -8,10 +8,12 @@
                transpose reads, fused ReLU masks / skip adds / PixelShuffle inverse).
 * `_ConvLstmFn` — ConvLSTMCell (RDN.py:50-95) forward/backward kernels.
 Training precision defaults to "f16x3" (fp32-class gradients, ~5e-6 relative vs torch autograd of the oracle).
-BIN_AMD_TRAIN_PRECISION=f16 (single fp16 product in forward AND backward) is NOT a training mode to rely on: its forward's
-~1e-3 activation error flips ReLU masks, and individual parameter gradients come out 1-25 % off
-(tests/test_gpu_backward.py, tolerance 2.5e-1).  The supported speed/accuracy trade is `backward_precision = "f16"` (a per-network attribute) behind the
-f16x3 forward (exact loss and masks, ~2e-3 relative gradient error).
+Training in "f16" (single fp16 product in forward AND backward) is NOT a supported mode: its forward's ~1e-3 activation error
+flips ReLU masks, and individual parameter gradients come out 1-25 % off (tests/test_gpu_backward.py only checks it to
+2.5e-1).  Since round 4 it is GATED: a differentiable call of an RDN whose precision resolves to "f16" raises unless the
+module carries `allow_f16_training = True` (diagnostics / that test).  The supported speed/accuracy trade is
+`backward_precision = "f16"` (a per-network attribute, bench.py's "mixed") behind the f16x3 forward: exact loss and masks,
+~2e-3 relative gradient error.
 """
 import ctypes as C
 import os
@@ -60,6 +62,12 @@ def default_backward_precision():
 def train_precision(module):
     from .models.archs.RDN import PRECISIONS
     p = module.precision or os.environ.get("BIN_AMD_TRAIN_PRECISION", "f16x3")
+    if PRECISIONS[p] == 1 and not getattr(module, "allow_f16_training", False):
+        raise RuntimeError(
+            "bin_amd: training with precision 'f16' (one fp16 product in forward and backward) is not a supported mode — its "
+            "parameter gradients are only verified to 25 %.  Train in 'f16x3' (the default; set network_G.precision: f16x3 or "
+            "leave it unset), optionally with network_G.backward_precision: f16 for the faster mixed mode; 'f16' is the "
+            "inference mode (wrap inference in torch.no_grad()).  Diagnostics may set module.allow_f16_training = True.")
     return PRECISIONS[p]
 
 

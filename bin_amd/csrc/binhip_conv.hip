@@ -319,7 +319,8 @@ static int launch_cfg_x(const ConvKArgs& ka, int cout_pad, hipStream_t s) {
 template <int KS, int MT, int WM, int R, int WN, int KC, int NT, int NBUF, int EPI>
 static int launch_cfg(const ConvKArgs& ka, int cout_pad, hipStream_t s) {
     if constexpr (EPI == BINHIP_EPI_PLANES) {
-        if (ka.has_res || ka.r2_hi || ka.m_hi) return launch_cfg_x<KS, MT, WM, R, WN, KC, NT, NBUF, EPI, true>(ka, cout_pad, s);
+        if (ka.has_res || ka.r2_hi || ka.m_hi || ka.y_unshuf)
+            return launch_cfg_x<KS, MT, WM, R, WN, KC, NT, NBUF, EPI, true>(ka, cout_pad, s);
     }
     return launch_cfg_x<KS, MT, WM, R, WN, KC, NT, NBUF, EPI, false>(ka, cout_pad, s);
 }
@@ -378,6 +379,9 @@ int bh_prepare_conv(const BhConvCall& c, ConvKArgs* out) {
     a.res_chunks = c.res_chunks > 0 ? c.res_chunks : (1 << 30);
     a.mask_from = c.mask_from;
     a.y_cpg = c.y_cpg; a.y_group_stride = c.y_group_stride;
+    a.y_unshuf = c.y_unshuf;
+    if (c.y_unshuf && (d.epilogue != BINHIP_EPI_PLANES || c.y_cpg > 0 || (d.H & 1) || (d.W & 1) || c.y_unshuf * 16 < d.cout))
+        return BINHIP_E_SHAPE;
     if (c.r2_hi && d.nterms == 3 && !c.r2_lo) return BINHIP_E_ARG;
     a.out_f32 = c.y_f32;
     for (int i = 0; i < 5; ++i) a.img[i] = c.images[i];

@@ -41,6 +41,9 @@ struct ConvKArgs {
     int mask_from;            // mask applies to output chunks >= mask_from (when m_hi != null)
     int y_cpg;                // output chunk grouping (<=0: one group)
     long long y_group_stride;
+    int y_unshuf;             // XTRA kernels only: > 0 = the output goes out through an inverse PixelShuffle(2) — full-resolution
+                              // pixel (Y, X), chunk c -> plane (2 (Y & 1) + (X & 1)) * y_unshuf + c at (Y / 2, X / 2) of the half-
+                              // resolution tensor (the channel order UPNet.0's permuted rows use); y_unshuf = chunks per sub-position
 };
 
 template <int N>
@@ -169,6 +172,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const float* _
                             o = (a.y_cpg > 0)
                                 ? (long long)(och / a.y_cpg) * a.y_group_stride + (long long)(och % a.y_cpg) * plane_elems + pix16
                                 : (long long)och * plane_elems + pix16;
+                            if constexpr (X) {
+                                if (a.y_unshuf > 0) {     // PixelShuffle backward fused into this store (UPNet.2's backward-data)
+                                    const int sub = ((gyc & 1) << 1) | (gxc & 1);
+                                    o = (long long)(sub * a.y_unshuf + och) * (plane_elems >> 2) +
+                                        ((((long long)img * (H >> 1) + (gyc >> 1)) * (W >> 1) + (gxc >> 1)) << 4) + (co & 15);
+                                }
+                            }
                             if constexpr (X) {
                                 const bool live = och < a.och_limit;
                                 if (use_res && och < a.res_chunks && live) {

@@ -333,7 +333,7 @@ static int launch_x3_x(const ConvKArgs& ka, int cout_pad, hipStream_t s) {
 template <int KS, int R, int WN, int EPI, int WIDE>
 static int launch_x3(const ConvKArgs& ka, int cout_pad, hipStream_t s) {
     if constexpr (EPI == BINHIP_EPI_PLANES) {
-        if (ka.has_res || ka.r2_hi || ka.m_hi) return launch_x3_x<KS, R, WN, EPI, WIDE, true>(ka, cout_pad, s);
+        if (ka.has_res || ka.r2_hi || ka.m_hi || ka.y_unshuf) return launch_x3_x<KS, R, WN, EPI, WIDE, true>(ka, cout_pad, s);
     }
     return launch_x3_x<KS, R, WN, EPI, WIDE, false>(ka, cout_pad, s);
 }

@@ -55,6 +55,7 @@ struct BhConvCall {
     int mask_from = 0;
     int y_cpg = 0;
     int64_t y_group_stride = 0;
+    int y_unshuf = 0;                                // > 0: store through an inverse PixelShuffle(2), chunks per sub-position
     void *y_hi, *y_lo;
     float* y_f32;
     const float* images[5];

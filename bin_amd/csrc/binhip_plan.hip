@@ -393,7 +393,7 @@ int binhip_rdn_backward(const BinRdnBwdPlan* p, const void* saved, size_t saved_
     // data gradient through forward layer `layer`: conv with the transposed/flipped weights
     auto dgrad = [&](int layer, int ks, int Hc, int Wc, int gin_chunks, int gout_ch, int64_t g_off, int64_t g_size,
                      int64_t y_off, int64_t y_size, int64_t r_off, int64_t r_size, int res_chunks, bool acc_inplace,
-                     int64_t m_off, int mask_from, int y_cpg, int64_t y_gstride) -> int {
+                     int64_t m_off, int mask_from, int y_cpg, int64_t y_gstride, int y_unshuf = 0) -> int {
         BhConvCall c;
         c.d.N = N; c.d.H = Hc; c.d.W = Wc; c.d.ksize = ks; c.d.cin_chunks = gin_chunks; c.d.cout = gout_ch;
         c.d.cout_pad = binhip_dgrad_rows_pad(ks, gout_ch); c.d.nterms = nt; c.d.epilogue = BINHIP_EPI_PLANES; c.d.relu = 0;
@@ -406,6 +406,7 @@ int binhip_rdn_backward(const BinRdnBwdPlan* p, const void* saved, size_t saved_
         c.r2_hi = acc_inplace ? c.y_hi : nullptr; c.r2_lo = acc_inplace ? c.y_lo : nullptr;
         c.m_hi = (m_off >= 0) ? SH(m_off) : nullptr; c.mask_from = mask_from;
         c.y_cpg = y_cpg; c.y_group_stride = y_gstride;
+        c.y_unshuf = y_unshuf;
         c.y_f32 = nullptr;
         c.status = p->status;
         for (int i = 0; i < 5; ++i) c.images[i] = nullptr;
@@ -419,9 +420,11 @@ int binhip_rdn_backward(const BinRdnBwdPlan* p, const void* saved, size_t saved_
     auto chain = [&]() -> int {
         // ---- UPNet.2 (64 -> 3 at full res): X = U
         if ((rc = wgrad(LG + 3, 3, H, W, 4, 64, 3, w.u, w.s_u, 0, 0, b.gout, b.s_gout, 0))) return rc;
-        if ((rc = dgrad(LG + 3, 3, H, W, 1, 64, b.gout, b.s_gout, b.gu, b.s_gu, -1, 0, 0, false, -1, 0, 0, 0))) return rc;
-        // ---- PixelShuffle backward, then UPNet.0 (G0 -> 256): X = G1
-        if ((rc = binhip_unshuffle_planes(GH(b.gu), GL(b.gu, b.s_gu), N, h, ww, 4, GH(b.guu), GL(b.guu, b.s_guu), stream))) return rc;
+        // its backward-data writes straight through the inverse PixelShuffle (round 4: y_unshuf; before, a 64-channel
+        // full-resolution gradient went to b.gu and a separate layout pass — 856 MB per launch at N = 40 — turned it
+        // into the 256 half-resolution channels UPNet.0's backward reads)
+        if ((rc = dgrad(LG + 3, 3, H, W, 1, 64, b.gout, b.s_gout, b.guu, b.s_guu, -1, 0, 0, false, -1, 0, 0, 0, 4))) return rc;
+        // ---- UPNet.0 (G0 -> 256): X = G1
         if ((rc = wgrad(LG + 2, 3, h, ww, c0, G0, 256, w.g1, w.s_g, 0, 0, b.guu, b.s_guu, 1))) return rc;
         if ((rc = dgrad(LG + 2, 3, h, ww, 16, G0, b.guu, b.s_guu, b.gg1, b.s_g, -1, 0, 0, false, -1, 0, 0, 0))) return rc;
         // ---- GFF.1 (+ f__1 skip): X = G0

@@ -146,6 +146,7 @@ class _RDNBase(nn.Module):
         from ...rdn_plan import default_plan_flags
         self.backward_precision = default_backward_precision()   # "f16" = single-product backward behind an f16x3 forward
         self._direct_grads = False                               # kernels accumulate weight gradients straight into .grad
+        self.allow_f16_training = False                          # "f16" is the inference mode; training in it is gated (autograd.py)
         self.wgrad_side_stream = default_wgrad_side_stream()     # weight-gradient kernels beside the backward-data chain
         self.plan_flags = default_plan_flags()                   # BINHIP_PLAN_* bits of every call of this sub-network
         self.profiler = None                                     # BinhipProfiler handle (bench.py's roofline leg)

@@ -157,6 +157,10 @@ def test_rdn_backward_vs_oracle_autograd(set_name, k, prec, tol, canon_cpu, monk
     mod = mod.cuda()
     mod.precision = prec
     mod.backward_precision = bwd           # a per-module attribute (not a process-wide switch)
+    if prec == "f16":
+        with pytest.raises(RuntimeError, match="not a supported mode"):      # gated since round 4 ...
+            mod(*[torch.rand(1, 3, 32, 48).cuda().requires_grad_() for _ in range(k)])
+        mod.allow_f16_training = True                                        # ... diagnostics opt in explicitly
     gen = torch.Generator().manual_seed(11)
     ins = [torch.rand(1, 3, 32, 48, generator=gen) for _ in range(k)]
     gout = torch.randn(1, 3, 32, 48, generator=gen) * 1e-3
