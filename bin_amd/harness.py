@@ -27,8 +27,9 @@ def interpolate_clip(netG, clip, rank=0, world=1, reuse_stage1=True, batch=1):
     u8_to_frame / frame_to_u8 kernels, each padded frame cached because 5 of a window's 6 frames recur in the
     next window) or [T,3,H,W] fp32 RGB in [0,1].  Returns {window index: (interp, deblur_first, deblur_second)}
     as cropped HWC BGR uint8 images — what test.py writes with cv2.imwrite (test.py:380-402).
-    reuse_stage1 (N3): consecutive windows share 4 of their 5 stage-1 frame pairs; their RDN results are reused
-    (exact: same inputs, same kernels), 17 -> 13 RDN calls per window.
+    reuse_stage1 (N3): consecutive windows share 4 of their 5 stage-1 frame pairs, 2 stage-2 calls and 1 stage-3 call
+    (every call of the first sub-window that the next forward repeats; none sees ConvLSTM state); their RDN results are
+    reused (exact: same inputs, same kernels), 17 -> 10 RDN calls per window (rounds 1-3 reused stage 1 only: 13).
     batch > 1: that many consecutive windows go through the net as ONE forward along N.  A small frame does not fill
     the chip (a 320x320 window is 50 tiles per launch on 256 CUs): 8 windows per forward give 2.5x the windows/s at
     256x256 and 1.75x at 448x256 (tools/bench_small.py); per-image arithmetic is unchanged, so the images are

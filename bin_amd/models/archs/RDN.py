@@ -344,9 +344,10 @@ class RDN_residual_interp_5_input_ConvLSTM_L(nn.Module):
         window's stage-1 calls start on idle streams while the previous window's lone stage-4 call is still running.
         The outputs are joined onto the caller's stream as always.
         `stage1_cache` (bin_amd extension, inference only): a dict owned by a streaming caller.  Consecutive
-        windows of a clip share 4 of their 5 stage-1 frame pairs, so model1(Bi, Bj) results are
-        memoised on the identity of the two (cached, hence long-lived) frame tensors: 17 -> 13 RDN calls per
-        window, outputs unchanged bit for bit."""
+        windows of a clip share 4 of their 5 stage-1 frame pairs, and — round 4 — the first window of
+        the next forward also repeats two stage-2 calls and one stage-3 call of this one (it sees no ConvLSTM state), so
+        every LSTM-free call is memoised on the identity of its (cached, hence long-lived) input tensors: 17 -> 10 RDN
+        calls per window (rounds 1-3: 13), outputs unchanged bit for bit.  (The name is kept from round 1.)"""
         for t in (B1, B3, B5, B7, B9, B11):
             if not t.is_cuda:
                 raise RuntimeError("bin_amd: bin_stage4 runs on a HIP device only (no CPU fallback; "
@@ -507,36 +508,44 @@ def _forward_streams(self, B, stage1_cache=None, input_events=None):
 
     B1, B3, B5, B7, B9, B11 = B
 
-    def stage1(si, Ba, Bb):
+    touched = set()
+
+    def memo(si, k, *ins):
+        """An LSTM-free RDN call, memoised across forwards on the IDENTITY of its input tensors when the caller streams
+        consecutive windows (`stage1_cache`).  Window k + 1's first window is window k's shifted by one frame and sees no
+        ConvLSTM state, so besides four of the five stage-1 pairs (round 1) it repeats two stage-2 calls and one stage-3 call
+        of window k exactly — and because a hit returns the very tensor object the earlier forward produced, the deeper
+        calls' keys match on their own (I3' = model2(I2', I2', I4') = model2(I4, I4, I6) = I5 of the window before).  17
+        independent -> 10 RDN calls per window, same kernels on the same inputs => the same bits."""
         if stage1_cache is None:
-            return rdn(si, 1, Ba, Bb)
-        key = (id(Ba), id(Bb))
+            return rdn(si, k, *ins)
+        key = (k,) + tuple(id(t) for t in ins)
+        touched.add(key)
         hit = stage1_cache.get(key)
-        if hit is not None and hit[1] is Ba and hit[2] is Bb:
-            if hit[3] is not None:
-                ready[id(hit[0])] = hit[3]        # computed by an earlier forward: consumers still wait on ITS event
+        if hit is not None and all(a is b for a, b in zip(hit[1], ins)):
+            if hit[2] is not None:
+                ready[id(hit[0])] = hit[2]        # computed by an earlier forward: consumers still wait on ITS event
             return hit[0]
-        out = rdn(si, 1, Ba, Bb)
-        stage1_cache[key] = (out, Ba, Bb, ready.get(id(out)))
+        out = rdn(si, k, *ins)
+        stage1_cache[key] = (out, ins, ready.get(id(out)))     # (holding `ins` keeps their ids from being recycled)
         return out
 
-    if stage1_cache is not None:         # keep only pairs that can still recur (those of this window)
-        live = {(id(a), id(b)) for a, b in ((B1, B3), (B3, B5), (B5, B7), (B7, B9), (B9, B11))}
-        for k in [k for k in stage1_cache if k not in live]:
-            del stage1_cache[k]
-    # ---- window 1
-    I2 = stage1(0, B1, B3); I4 = stage1(1, B3, B5); I6 = stage1(2, B5, B7); I8 = stage1(3, B7, B9)
-    I3 = rdn(0, 2, I2, I2, I4); I5 = rdn(1, 2, I4, I4, I6); I7 = rdn(2, 2, I6, I6, I8)
+    # ---- window 1 (no ConvLSTM input: every call is a pure function of frames / earlier window-1 results)
+    I2 = memo(0, 1, B1, B3); I4 = memo(1, 1, B3, B5); I6 = memo(2, 1, B5, B7); I8 = memo(3, 1, B7, B9)
+    I3 = memo(0, 2, I2, I2, I4); I5 = memo(1, 2, I4, I4, I6); I7 = memo(2, 2, I6, I6, I8)
     h4 = cell(3, cells[0], I4); h6 = cell(3, cells[1], I6); h8 = cell(3, cells[2], I8)
-    I4pp = rdn(0, 3, I3, B3, I3, I5, B5); I6pp = rdn(1, 3, I5, B5, I5, I7, B7)
+    I4pp = memo(0, 3, I3, B3, I3, I5, B5); I6pp = memo(1, 3, I5, B5, I5, I7, B7)
     h5 = cell(2, cells[3], I5); h7 = cell(2, cells[4], I7)
-    I8b = stage1(2, B9, B11)                                            # window 2's only new stage-1 call
-    I5ppp = rdn(0, 4, I4, I4, I4pp, I6pp, I6)
+    I8b = memo(2, 1, B9, B11)                                           # window 2's only new stage-1 call
+    I5ppp = memo(0, 4, I4, I4, I4pp, I6pp, I6)
     h6pp = cell(1, cells[5], I6pp)
-    # ---- window 2 (stage-1 outputs I4, I6, I8 of window 1 are its I2', I4', I6')
+    # ---- window 2 (stage-1 outputs I4, I6, I8 of window 1 are its I2', I4', I6'; its deeper calls see the cells' states)
     J3 = rdn(0, 2, h4, I4, I6); J5 = rdn(1, 2, h6, I6, I8); J7 = rdn(2, 2, h8, I8, I8b)
     J4pp = rdn(0, 3, h5, B5, J3, J5, B7); J6pp = rdn(1, 3, h7, B7, J5, J7, B9)
     J5ppp = rdn(0, 4, h6pp, I6, J4pp, J6pp, I8)
+    if stage1_cache is not None:         # keep only what this forward touched: whatever can recur in a neighbouring window
+        for key in [key for key in stage1_cache if key not in touched]:
+            del stage1_cache[key]
     for s in streams:
         if s is not main:
             main.wait_stream(s)

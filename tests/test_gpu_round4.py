@@ -97,3 +97,39 @@ def test_general_convlstm_conv_refuses_a_weight_changed_before_backward():
         w.mul_(0.5)                                                # what an optimizer step does
     with pytest.raises(RuntimeError, match="modified in place"):
         y.sum().backward()
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "f16"])
+def test_streaming_windows_reuse_every_lstm_free_call(prec, monkeypatch):
+    """N3, widened in round 4: the next window's first sub-window repeats 4 stage-1, 2 stage-2 and 1 stage-3 call of this one
+    (none sees ConvLSTM state), so a streaming caller's cache brings a window from 17 to 10 RDN calls — sliding forward AND
+    backward — and every one of the 14 outputs stays bit-identical to an independent forward of the same six frames."""
+    from bin_amd import rdn_plan
+    from bin_amd.models.archs.RDN import bin_stage4_lstm
+    from bin_amd.weights import reference_state_dict, synthetic_frames
+    net = bin_stage4_lstm()
+    net.load_state_dict(reference_state_dict(0), strict=True)
+    net = net.cuda().eval().set_precision(prec)
+    net.four_calls_infer = "0"                       # (small test frames would otherwise take the batched four-call schedule)
+    clip = [f.cuda() for f in synthetic_frames(91, 1, 64, 96, 11)]
+    calls = []
+    real = rdn_plan.rdn_forward
+
+    def counting(*a, **k):
+        calls.append(1)
+        return real(*a, **k)
+    with torch.no_grad():
+        want = {i: [o.clone() for o in net(*clip[i:i + 6])] for i in range(6)}
+        torch.cuda.synchronize()
+        monkeypatch.setattr(rdn_plan, "rdn_forward", counting)
+        cache, per_window = {}, []
+        order = [0, 1, 2, 3, 4, 5, 4, 3, 2]
+        for i in order:
+            calls.clear()
+            got = net(*clip[i:i + 6], stage1_cache=cache)
+            per_window.append(len(calls))
+            torch.cuda.synchronize()
+            for x, y in zip(got, want[i]):
+                assert torch.equal(x, y), (i, prec)
+    assert per_window == [17] + [10] * (len(order) - 1), per_window
+    assert len(cache) <= 11                          # only what the last forward touched is kept
