@@ -323,7 +323,13 @@ def harness_bench(precision, n_frames, gpu_only_fps, io_threads=12):
                            "--opt", yml, "--precision", precision, "--io_threads", str(io_threads)], stats=stats)
         n_png = sum(1 for _, _, fs in os.walk(os.path.join(tmp, "out1")) for x in fs if x.endswith(".png"))
         fps = stats["windows"] / stats["wall"]
+        st = stats.get("stamps") or []
+        steady = None
+        if len(st) >= 24:               # the middle half of the clip: the host is throttled by the bounded writer queue, so the
+            a, b = len(st) // 4, (3 * len(st)) // 4          # rate at which it QUEUES windows there is the pipeline's own rate
+            steady = (b - a) / max(st[b] - st[a], 1e-9)
         return {"frames_per_s": round(fps, 3), "unit": "interpolated frames/s, PNG files in -> PNG files out",
+                "steady_state_frames_per_s": None if steady is None else round(steady, 3),
                 "gpu_only_frames_per_s": None if gpu_only_fps is None else round(gpu_only_fps, 3),
                 "io_overlap_frac": None if not gpu_only_fps else round(fps / gpu_only_fps, 4),
                 "windows": stats["windows"], "input_frames": n_frames, "wall_s": round(stats["wall"], 3),

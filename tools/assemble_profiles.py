@@ -135,6 +135,13 @@ file) and for `train.roofline.dominant_kernel.traffic` (`wgrad3x3`).  Written by
 
     # ---- SQ counters: the raw table + the derived launch-level figures
     sq = read("pmc_sq.log")
+    # (tools/gpu.sh appends: keep the LAST section of each kernel when a tag was used for more than one run)
+    secs = {}
+    for sec in re.split(r"(?m)^(?==== pmc_one.py )", sq):
+        m = re.match(r"=== pmc_one.py (\w+)", sec)
+        if m and len(sec.splitlines()) > 2:
+            secs[m.group(1)] = sec.strip()
+    sq = "\n".join(secs.values())
     vals = {}
     cur = None
     for ln in sq.splitlines():
