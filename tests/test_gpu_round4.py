@@ -133,3 +133,38 @@ def test_streaming_windows_reuse_every_lstm_free_call(prec, monkeypatch):
                 assert torch.equal(x, y), (i, prec)
     assert per_window == [17] + [10] * (len(order) - 1), per_window
     assert len(cache) <= 11                          # only what the last forward touched is kept
+
+
+def test_4k_window_runs_whole_in_both_precisions():
+    """The reference tiles 4K frames because they do not fit its GPU (Video_base_model.py:189-194); with 288 GB a 6-frame
+    2160x3840 window (padded by the test.py rule to 2176x3904, 8.5 M pixels per frame, ~30 GB of workspace in f16x3) goes
+    through the network WHOLE.  No CPU oracle finishes at this size in a test's time, so the check is the agreement of the two
+    independent kernel families (f16x3: plane-split three-product kernels; f16: the generic single-product kernels + VALU
+    UPNet.2) to the f16 mode's own bar, plus finiteness, the status word and the largest 32-bit buffer offsets in use."""
+    from bin_amd import ops
+    from bin_amd.models.archs.RDN import bin_stage4_lstm
+    from bin_amd.utils import util
+    from bin_amd.weights import reference_state_dict, synthetic_frames
+    H, W = 2160, 3840
+    pads = util.pad_sizes(H, W)
+    frames = [util.replicate_pad(f, pads).cuda() for f in synthetic_frames(4242, 1, H, W, 6)]
+    assert frames[0].shape[2] % 32 == 0 and frames[0].shape[3] % 32 == 0
+    net = bin_stage4_lstm()
+    net.load_state_dict(reference_state_dict(0), strict=True)
+    net = net.cuda().eval()
+    outs = {}
+    with torch.no_grad():
+        for prec in ("f16x3", "f16"):
+            net.set_precision(prec)
+            out = net(*frames)
+            torch.cuda.synchronize()
+            ops.check_status()
+            assert all(torch.isfinite(o).all() for o in out)
+            outs[prec] = [o[..., pads[2]:pads[2] + H, pads[0]:pads[0] + W].cpu() for o in (out[13], out[8], out[12])]
+            del out
+    for a, b in zip(outs["f16x3"], outs["f16"]):
+        assert tuple(a.shape) == (1, 3, H, W)
+        assert float((a - b).abs().max()) <= 1e-3
+    from bin_amd.rdn_plan import release_workspaces
+    release_workspaces()
+    torch.cuda.empty_cache()
