@@ -357,6 +357,10 @@ int bh_conv_cout_block(int ksize, int cout_pad, int nterms) {
 static int bh_dispatch_conv(const ConvKArgs& a, int k, int cp, int nt, int e, hipStream_t s);
 int bh_launch_conv_x3(const ConvKArgs& a, int cout_pad, int epilogue, hipStream_t s);   // binhip_conv_x3.hip
 int bh_launch_final_dot2(const ConvKArgs& a, int nterms, hipStream_t s);                 // binhip_conv_x3.hip
+int bh_launch_conv_x3_k5(const ConvKArgs& a, int cout_pad, hipStream_t s);               // binhip_conv_x3.hip
+#ifndef BINHIP_K5_X3
+#define BINHIP_K5_X3 1        // 0 (side builds): the 5x5 layers of the fp32-class mode on the generic single-buffered kernel (rounds 1-3)
+#endif
 
 // validate a call and fill the kernel argument block (everything but the tile counts, which the launcher of the chosen
 // tile shape sets)
@@ -522,6 +526,7 @@ static int bh_dispatch_conv(const ConvKArgs& a0, int k, int cp, int nt, int e, h
             if (a.nchunks >= 32) return launch_cfg<1, 3, 1, 2, 4, 1, 3, 2, P>(a, cp, s);
             return launch_cfg<1, 3, 1, 1, 8, 1, 3, 2, P>(a, cp, s);    // LFF 90 vs 108 us
         }
+        if (e == P && k == 5 && cb == 32 && BINHIP_K5_X3) return bh_launch_conv_x3_k5(a, cp, s);   // plane-split stages, double-buffered
         if (e == P && k == 5 && cb == 32)  return launch_cfg<5, 1, 1, 2, 8, 1, 3, 1, P>(a, cp, s);
     }
     return BINHIP_E_SHAPE;

@@ -53,7 +53,9 @@ struct X3Cfg {
     static constexpr int LDS_BYTES = 2 * PATCH_BYTES + 2 * WBUF_BYTES;
     static constexpr int NPJ = (PP + NW - 1) / NW;
     static constexpr int NWJ = (2 * WP + NW - 1) / NW;
-    static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+    // 3x3: two workgroups per CU.  5x5 (SFENet1, round 4): the 25-tap weight slab alone is 50 KB per chunk, so ONE workgroup per CU
+    // — still with both rings double-buffered (the generic kernel had to single-buffer its 96 KB stage: NBUF = 1, nothing overlapped)
+    static_assert((KS == 3 ? 2 : 1) * LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
 template <class C>
@@ -504,6 +506,11 @@ int bh_launch_final_dot2(const ConvKArgs& ka, int nterms, hipStream_t s) {
 // entry for the dispatcher in binhip_conv.hip: every 3x3 convolution of the nterms = 3 path, in 32-row output blocks
 // (wider layers — 96 -> 96, UPNet.0's 96 -> 256, the 96-row backward-data convs — run as cout_pad / 32 workgroup
 // columns over the same tiles: the input patch is re-read per column, from L2)
+// SFENet1 (5x5, 12 n_inputs -> 96 as three 32-row columns) and its backward-data on the plane-split pipeline
+int bh_launch_conv_x3_k5(const ConvKArgs& a, int cout_pad, hipStream_t s) {
+    return launch_x3<5, BINHIP_X3_R, BINHIP_X3_WN, BINHIP_EPI_PLANES, 1>(a, cout_pad, s);
+}
+
 int bh_launch_conv_x3(const ConvKArgs& a, int cout_pad, int epilogue, hipStream_t s) {
     if (epilogue == BINHIP_EPI_PLANES)
         return cout_pad == 32 ? launch_x3<3, BINHIP_X3_R, BINHIP_X3_WN, BINHIP_EPI_PLANES, 0>(a, cout_pad, s)
