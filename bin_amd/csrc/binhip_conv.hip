@@ -358,6 +358,10 @@ static int bh_dispatch_conv(const ConvKArgs& a, int k, int cp, int nt, int e, hi
 int bh_launch_conv_x3(const ConvKArgs& a, int cout_pad, int epilogue, hipStream_t s);   // binhip_conv_x3.hip
 int bh_launch_final_dot2(const ConvKArgs& a, int nterms, hipStream_t s);                 // binhip_conv_x3.hip
 int bh_launch_conv_x3_k5(const ConvKArgs& a, int cout_pad, hipStream_t s);               // binhip_conv_x3.hip
+int bh_launch_final_m16(const ConvKArgs& a, hipStream_t s);                              // binhip_conv_x3.hip
+#ifndef BINHIP_FINAL_M16
+#define BINHIP_FINAL_M16 1    // 0 (side builds): UPNet.2 of the fp32-class mode on the 32-row tile of conv_x3_kernel (rounds 2-3)
+#endif
 #ifndef BINHIP_K5_X3
 #define BINHIP_K5_X3 1        // 0 (side builds): the 5x5 layers of the fp32-class mode on the generic single-buffered kernel (rounds 1-3)
 #endif
@@ -485,6 +489,9 @@ static int bh_dispatch_conv(const ConvKArgs& a0, int k, int cp, int nt, int e, h
     if (e == F && k == 3 && cp == 32 && a.cout <= 3 && (nt == 1 || BINHIP_DOT2_X3) && BH_VARIANT(CLS_FINAL) < 0)
         return bh_launch_final_dot2(a, nt, s);
 #endif
+    // UPNet.2 in the fp32-class mode: 16-row matrix tile over tap pairs (binhip_conv_x3.hip, round 4)
+    if (e == F && k == 3 && cp == 32 && a.cout <= 3 && nt == 3 && BINHIP_FINAL_M16 && BH_VARIANT(CLS_FINAL) < 0)
+        return bh_launch_final_m16(a, s);
     //                                   KS MT WM R WN KC NT NBUF EPI
     if (nt == 1) {
         if (e == F && k == 3 && cp == 32) return launch_cfg<3, 1, 1, 2, 8, 1, 1, 2, F>(a, cp, s);     // 8 waves, 16x32 tile

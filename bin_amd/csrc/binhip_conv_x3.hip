@@ -487,6 +487,206 @@ final_dot2_kernel(const ConvKArgs a, const unsigned* __restrict__ w_hi32, const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// UPNet.2 in the fp32-class mode on a 16-ROW matrix tile with a THREE-stage patch ring (round 4).
+// Three output channels on the 32x32x16 tile of conv_x3_kernel are 91 % padding — but the layer was never bound by its matrix
+// work: 110 us per launch at 720p = 2.5 TB/s of a 277 MB layer.  A sub-stage of x3_tile has ONE LDS-DMA batch in flight per workgroup
+// (prefetch distance: one sub-stage); with a sub-stage's matrix work at ~0.3-0.6 us the loop runs at the DMA round trip, ~3.5 us per
+// sub-stage.  (First form of this kernel, same ring as x3_tile, 1.8x fewer matrix cycles: 120 us.  profiles/r04_experiments.md)
+// What changes here:
+//   * the weights of the WHOLE layer stay in LDS for the tile's life: only rows 0-3 of every tap's 32-row slab matter (rows 0-2 are
+//     the layer, row 3 is zero padding), 128 B per tap and plane = 10 KB instead of a 2 x 18 KB per-chunk ring;
+//   * that frees a third 20 KB patch slot: prefetch distance TWO sub-stages with counted vmcnt (a wave issues 2 or 3 pieces per
+//     stage: wave-uniform choice of the immediate), still 70 KB = two workgroups per CU;
+//   * v_mfma_f32_16x16x32_f16: M = 16 rows, N = 16 pixels, K = 32 spent on TAP PAIRS: k = 8 kb + e (kb = lane >> 4) = channel
+//     8 (kb & 1) + e of the chunk at tap 2p + (kb >> 1) of pair p — 5 instructions per 16 pixels, chunk and product.  An A fragment
+//     is row min(lane & 15, 3) of its tap (D rows 3-15 are never read, so what multiplies into them is irrelevant; the odd tap of
+//     pair 4 does not exist: its lanes read row 3 = zeros).  B fragment of lane (n = lane & 15, kb): channel half kb & 1 of the
+//     patch pixel under the lane's tap, one ds_read_b128 with a per-lane address.  C/D: col = lane & 15 = pixel, row = 4 (lane >> 4)
+//     + reg: the three channels of 16 pixels sit in lanes 0-15, registers 0-2.
+struct M16 {
+    using C = X3Cfg<3, 2, 8>;
+    static constexpr int NSTAGE = 3;
+    static constexpr int WPIECES = 5;                              // 36 taps x 128 B per plane, in 1-KiB DMA pieces
+    static constexpr int W_OFF = NSTAGE * C::PATCH_BYTES;
+    static constexpr int LDS_BYTES = W_OFF + 2 * WPIECES * 1024;    // 70 KB
+    static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+};
+
+template <bool HI>
+__device__ __forceinline__ void m16_compute(const char* pb, const char* wb, int a_lane_off, int b_lane_off, int slot, int a_zero,
+                                            floatx4 (&acc)[2][2]) {
+    using C = X3Cfg<3, 2, 8>;
+    half8 Ah[2], Al[2], B[2][2][2];
+    auto tap_off = [](int t) { return ((t / 3) * C::PW + (t % 3)) * 16; };
+    auto load = [&](int p, half8& ah, half8& al, half8 (&b)[2][2]) {
+        // tap slab = 128 B (rows 0-3 x 32 B); pair 4's second tap: row 3 of tap 8 (zeros) for every lane
+        const int aoff = (p < 4) ? (2 * p + slot) * 128 + a_lane_off : (slot ? 8 * 128 + a_zero : 8 * 128 + a_lane_off);
+        ah = x3_ld8(wb + aoff);
+        if constexpr (HI) al = x3_ld8(wb + M16::WPIECES * 1024 + aoff);
+        const int boff = b_lane_off + tap_off(2 * p) + slot * (p < 4 ? tap_off(2 * p + 1) - tap_off(2 * p) : 0);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) b[r][g] = x3_ld8(pb + boff + (r * C::PW + g * 16) * 16);
+    };
+    load(0, Ah[0], Al[0], B[0]);
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+        if (p + 1 < 5) load(p + 1, Ah[(p + 1) & 1], Al[(p + 1) & 1], B[(p + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                if constexpr (HI) acc[r][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[p & 1], B[p & 1][r][g], acc[r][g], 0, 0, 0);
+                acc[r][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[p & 1], B[p & 1][r][g], acc[r][g], 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
+final_m16_kernel(const ConvKArgs a, const float* __restrict__ bias) {
+    using C = X3Cfg<3, 2, 8>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = blockIdx.x;
+    if (a.xcd_remap) bid = xcd_band(bid, gridDim.x);
+    const int tx = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y;
+    const int img = bid / a.tiles_y;
+    const int tx0 = tx * 32, ty0 = ty * C::TH;
+    const int H = a.H, W = a.W;
+    const long long plane_elems = (long long)a.N * H * W * 16;
+    const unsigned plane_bytes = (unsigned)(plane_elems * 2);
+
+    unsigned voff[C::NPJ];
+#pragma unroll
+    for (int j = 0; j < C::NPJ; ++j) {
+        const int i = wave + C::NW * j;
+        const int q = i * 64 + lane;
+        const int cg = q >= C::PH * C::PW ? 1 : 0;
+        const int p = q - cg * (C::PH * C::PW);
+        const int py = p / C::PW;
+        const int px = p - py * C::PW;
+        const int gy = ty0 + py - 1;
+        const int gx = tx0 + px - 1;
+        const bool ok = (p < C::PH * C::PW) && (gy >= 0) && (gy < H) && (gx >= 0) && (gx < W);
+        voff[j] = ok ? (unsigned)((((long long)img * H + gy) * W + gx) * 32 + cg * 16) : 0x80000000u;
+    }
+    const int n16 = lane & 15, kb = lane >> 4;
+    const int slot = kb >> 1;
+    const int a_lane_off = ((n16 < 3 ? n16 : 3) * 2 + (kb & 1)) * 16;  // row min(n16, 3) of a tap's 4-row slab, channel half kb & 1
+    const int a_zero = (3 * 2 + (kb & 1)) * 16;                        // row 3: zero padding
+    const int b_lane_off = ((kb & 1) * (C::PH * C::PW) + wave * 2 * C::PW + n16) * 16;
+    floatx4 acc[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) acc[r][g] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = a.nchunks;
+    const int nstage = 2 * nchunks;                       // stage s = (chunk s / 2, plane s & 1), ring slot s % 3
+    // ---- the layer's weights, rows 0-3 of every (chunk, tap) slab: lane l of piece i fetches 16 B no. l % 8 of tap 8 i + l / 8
+    {
+        const int ntaps = nchunks * 9;
+        for (int i = wave; i < 2 * M16::WPIECES; i += C::NW) {
+            const int pl = i >= M16::WPIECES ? 1 : 0;
+            const int t = (i - pl * M16::WPIECES) * 8 + (lane >> 3);
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(pl ? a.w_lo : a.w_hi), 0, (unsigned)(ntaps * 1024), 0x00020000);
+            const unsigned off = t < ntaps ? (unsigned)(t * 1024 + (lane & 7) * 16) : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(smem + M16::W_OFF + i * 1024), 16, off, 0, 0, 0);
+        }
+    }
+    x3_issue_patch<C>(a, smem, 0, 0, 0, wave, voff, plane_elems, plane_bytes);
+    if (nstage > 1) x3_issue_patch<C>(a, smem, 0, 1, 1, wave, voff, plane_elems, plane_bytes);
+    const bool three = wave < (C::PP - 2 * C::NW);        // this wave issues 3 patch pieces per stage (else 2)
+    for (int s = 0; s < nstage; ++s) {
+        // stage s landed: at most the pieces of stage s + 1 (issued one sub-stage ago) may still be in flight
+        if (s + 1 < nstage) {
+            if (three) wait_vmcnt<3>(); else wait_vmcnt<2>();
+        } else {
+            wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();                      // every wave's pieces of stage s landed; stage s - 1's slot is free
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 < nstage) x3_issue_patch<C>(a, smem, (s + 2) >> 1, (s + 2) & 1, (s + 2) % 3, wave, voff, plane_elems, plane_bytes);
+        const char* pb = smem + (s % 3) * C::PATCH_BYTES;
+        const char* wb = smem + M16::W_OFF + (s >> 1) * (9 * 128);
+        if (s & 1) m16_compute<false>(pb, wb, a_lane_off, b_lane_off, slot, a_zero, acc);
+        else m16_compute<true>(pb, wb, a_lane_off, b_lane_off, slot, a_zero, acc);
+    }
+    // ---- epilogue (BINHIP_EPI_FINAL, the arithmetic of conv_epilogue): + bias + mean of the input frames -> fp32 NCHW.
+    // EVERY frame load of the wave first, the twelve means pinned in registers, then the stores: loads and stores share vmcnt on
+    // gfx9, so a value loaded before a store can only be used after that store has drained.  Left alone, hipcc sinks each 16-pixel
+    // group's adds behind the previous group's stores: four serial round trips per tile, and the kernel's time followed the number of
+    // input frames (94 / 122 / 157 us for 2 / 3 / 5; now 84 / 89 / 109).  Fetching the frames BEFORE the K loop instead was measured
+    // and is slower (93.7 vs 88.9 us: the values live across the loop's control flow and the compiler drains the whole prefetch
+    // ring once per tile to be sure of them).
+    if (kb == 0) {
+        float sum[2][2][3];
+        const int nimg = a.nimg;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int gy = ty0 + wave * 2 + r, gx = tx0 + g * 16 + n16;
+                const bool ok = gy < H && gx < W;
+                const int gyc = gy < H ? gy : H - 1, gxc = gx < W ? gx : W - 1;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const long long idx = (((long long)img * a.cout + (j < a.cout ? j : 0)) * H + gyc) * W + gxc;
+                    float v[5];
+#pragma unroll
+                    for (int t = 0; t < 5; ++t) v[t] = (t < nimg) ? a.img[t][idx] : 0.f;
+                    float sj = v[0];
+#pragma unroll
+                    for (int t = 1; t < 5; ++t)
+                        if (t < nimg) sj += v[t];
+                    sum[r][g][j] = (ok && nimg > 0) ? sj / (float)nimg : 0.f;
+                }
+            }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(sum[r][g][j]));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int gy = ty0 + wave * 2 + r, gx = tx0 + g * 16 + n16;
+                if (gy >= H || gx >= W) continue;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    if (j >= a.cout) break;
+                    const long long idx = (((long long)img * a.cout + j) * H + gy) * W + gx;
+                    a.out_f32[idx] = (acc[r][g][j] + bias[j]) + sum[r][g][j];
+                }
+            }
+    }
+}
+
+int bh_launch_final_m16(const ConvKArgs& ka, hipStream_t s) {
+    using C = X3Cfg<3, 2, 8>;
+    static std::atomic<unsigned long long> lds_set{0};
+    if (ka.nchunks > 5) return BINHIP_E_SHAPE;                   // (5 weight pieces per plane = 40 taps)
+    if (int rc = bh_set_max_lds(&final_m16_kernel, M16::LDS_BYTES, lds_set)) return rc;
+    ConvKArgs a = ka;
+    a.tiles_x = (a.W + 31) / 32;
+    a.tiles_y = (a.H + C::TH - 1) / C::TH;
+    a.ncol = 1;
+    final_m16_kernel<<<dim3((unsigned)(a.tiles_x * a.tiles_y * a.N)), dim3(512), M16::LDS_BYTES, s>>>(a, a.bias);
+    BH_CHECK_LAUNCH();
+    return 0;
+}
+
 // FINAL epilogue with <= 3 output channels (UPNet.2), both precisions
 int bh_launch_final_dot2(const ConvKArgs& ka, int nterms, hipStream_t s) {
     using C = X3Cfg<3, 2, 4>;
