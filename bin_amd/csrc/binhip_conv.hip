@@ -359,6 +359,9 @@ int bh_launch_conv_x3(const ConvKArgs& a, int cout_pad, int epilogue, hipStream_
 int bh_launch_final_dot2(const ConvKArgs& a, int nterms, hipStream_t s);                 // binhip_conv_x3.hip
 int bh_launch_conv_x3_k5(const ConvKArgs& a, int cout_pad, hipStream_t s);               // binhip_conv_x3.hip
 int bh_launch_final_m16(const ConvKArgs& a, hipStream_t s);                              // binhip_conv_x3.hip
+#ifndef BINHIP_LFFD_EPI
+#define BINHIP_LFFD_EPI 1     // 0 (side builds): the LFF backward-data tile on the generic extras grouping (rounds 2-3)
+#endif
 #ifndef BINHIP_FINAL_M16
 #define BINHIP_FINAL_M16 1    // 0 (side builds): UPNet.2 of the fp32-class mode on the 32-row tile of conv_x3_kernel (rounds 2-3)
 #endif
@@ -526,7 +529,14 @@ static int bh_dispatch_conv(const ConvKArgs& a0, int k, int cp, int nt, int e, h
         if (e == S && k == 3 && cp == 256) return launch_cfg<3, 1, 2, 4, 2, 1, 3, 2, S>(a, cp, s);
         if (e == P && k == 3 && cb == 64)  return launch_cfg<3, 2, 1, 2, 4, 1, 3, 2, P>(a, cp, s);
         if (e == P && k == 3 && cb == 96)  return launch_cfg<3, 3, 1, 1, 8, 1, 3, 2, P>(a, cp, s);   // 8 waves x 1 row: 168 vs 184 us
-        if (e == P && k == 1 && cb == 224) return launch_cfg<1, 7, 1, 1, BINHIP_K1_DGRAD_WN, 1, 3, 2, P>(a, cp, s);   // LFF dgrad
+        if (e == P && k == 1 && cb == 224) {   // LFF backward-data
+            // bin_stage4's own pattern (residual gy on output chunks 0-5, ReLU mask from chunk 12, one output group): the
+            // instantiation whose epilogue fetches its extras in two groups instead of four (binhip_conv_common.h)
+            if (a.has_res && a.m_hi && !a.r2_hi && a.res_chunks == 6 && a.mask_from == 12 && a.y_cpg <= 0 && !a.y_unshuf &&
+                a.och_limit >= 14 && cp == 224 && BINHIP_LFFD_EPI)
+                return launch_cfg_x<1, 7, 1, 1, BINHIP_K1_DGRAD_WN, 1, 3, 2, BINHIP_EPI_PLANES_LFFD, true>(a, cp, s);
+            return launch_cfg<1, 7, 1, 1, BINHIP_K1_DGRAD_WN, 1, 3, 2, P>(a, cp, s);
+        }
         if (e == P && k == 1 && cb == 192) return launch_cfg<1, 6, 1, 1, BINHIP_K1_DGRAD_WN, 1, 3, 2, P>(a, cp, s);   // GFF.0 dgrad
         if (e == P && k == 1 && cb == 32)  return launch_cfg<1, 1, 1, 4, 4, 2, 3, 2, P>(a, cp, s);
         if (e == P && k == 1 && cb == 96) {

@@ -47,6 +47,9 @@ struct ConvKArgs {
                               // resolution tensor (the channel order UPNet.0's permuted rows use); y_unshuf = chunks per sub-position
 };
 
+// internal epilogue code (never crosses the ABI): chunk planes with the extras pattern of the LFF backward-data tile
+#define BINHIP_EPI_PLANES_LFFD 3
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -138,11 +141,120 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const float* _
         union H4 { half4 h; unsigned u[2]; };
         unsigned sat = 0;
         const int gxc = gx < W ? gx : W - 1;     // clamped coordinates: loads need no branch, stores are predicated
-        constexpr bool X = XTRA && (EPI == BINHIP_EPI_PLANES);
+        constexpr bool X = XTRA && (EPI == BINHIP_EPI_PLANES || EPI == BINHIP_EPI_PLANES_LFFD);
         constexpr int MTG = (X && MT >= 6) ? 2 : 1;      // weight tiles per load group (<= 10 registers per slot)
         const bool use_res = X && a.has_res;
         const bool use_r2 = X && (a.r2_hi != nullptr);
         const bool use_m = X && (a.m_hi != nullptr);
+        // The LFF backward-data tile (224 rows = 7 weight tiles; residual gy on output chunks 0-5, ReLU mask on chunks 12-13,
+        // nothing on 6-11): the generic grouping below fetches extras per PAIR of weight tiles, four load groups per pixel row, and
+        // every group after the first waits for the previous group's stores to drain before it may use what it loaded (loads and
+        // stores share vmcnt).  With the pattern known, ALL extras of the row — 24 residual slots + 4 mask slots = 56 registers,
+        // fewer than the generic group's 80 — are fetched before the first store: one round trip per row instead of four.
+        // (Its own instantiation — EPI = BINHIP_EPI_PLANES_LFFD, chosen by the launcher when the call has exactly this pattern:
+        // compiled into the generic kernel beside the generic path the two together spill; alone it needs 174 registers, the
+        // generic tile 233.)
+        constexpr bool LFFD = EPI == BINHIP_EPI_PLANES_LFFD;
+        static_assert(!LFFD || (XTRA && MT == 7 && NT == 3), "the LFF backward-data epilogue");
+        if constexpr (LFFD) {
+            {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int gy = row0 + r;
+                    const bool ok = (gy < H) && (gx < W);
+                    const int gyc = gy < H ? gy : H - 1;
+                    const long long pix = (((long long)img * H + gyc) * W + gxc) << 4;
+                    // every extra of the row before its first store: tiles 0-2 (residual), 6 (mask); tiles 3-5 carry nothing
+                    auto emit = [&](const int mt, const half4 (&xr)[4], const half4 (&xrl)[4], const half4 (&xm)[4], const int kind)
+                        __attribute__((always_inline)) {                 // kind: 0 nothing, 1 residual, 2 mask
+#pragma unroll
+                        for (int gp = 0; gp < 2; ++gp) {
+                            H4 hv[2], lv[2];
+                            long long o_slot = 0;
+#pragma unroll
+                            for (int ge = 0; ge < 2; ++ge) {
+                                const int g = 2 * gp + ge;
+                                float bv[4];
+                                bias4(mt * 32 + 8 * g, bv);
+                                float v[4] = {acc[mt][r][4 * g + 0] + bv[0], acc[mt][r][4 * g + 1] + bv[1],
+                                              acc[mt][r][4 * g + 2] + bv[2], acc[mt][r][4 * g + 3] + bv[3]};
+                                const int co = mt * 32 + 8 * g + 4 * kg;
+                                const long long o = (long long)(co >> 4) * plane_elems + pix + (co & 15);
+                                if (kind == 1) {
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) v[j] += (float)xr[g][j];
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) v[j] += (float)xrl[g][j];
+                                }
+                                if (a.relu) {
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                                }
+                                if (kind == 2) {
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) v[j] = ((float)xm[g][j] > 0.f) ? v[j] : 0.f;
+                                }
+                                if (ge == kg) o_slot = o - 4 * kg;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    const _Float16 hj = split_hi(v[j], sat);
+                                    hv[ge].h[j] = hj;
+                                    lv[ge].h[j] = split_lo(v[j], hj);
+                                }
+                            }
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) {
+                                auto sw = __builtin_amdgcn_permlane32_swap(hv[0].u[k], hv[1].u[k], false, false);
+                                hv[0].u[k] = sw[0]; hv[1].u[k] = sw[1];
+                                auto sl = __builtin_amdgcn_permlane32_swap(lv[0].u[k], lv[1].u[k], false, false);
+                                lv[0].u[k] = sl[0]; lv[1].u[k] = sl[1];
+                            }
+                            if (ok) {
+                                store16(a.y_hi, o_slot, make_uint4(hv[0].u[0], hv[0].u[1], hv[1].u[0], hv[1].u[1]), a.wt);
+                                store16(a.y_lo, o_slot, make_uint4(lv[0].u[0], lv[0].u[1], lv[1].u[0], lv[1].u[1]), a.wt);
+                            }
+                        }
+                    };
+                    auto fetch = [&](const int mt, const _Float16* hi, const _Float16* lo, half4 (&xh)[4], half4 (&xl)[4])
+                        __attribute__((always_inline)) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int co = mt * 32 + 8 * g + 4 * kg;
+                            const long long o = (long long)(co >> 4) * plane_elems + pix + (co & 15);
+                            xh[g] = *reinterpret_cast<const half4*>(hi + o);
+                            if (lo) xl[g] = *reinterpret_cast<const half4*>(lo + o);
+                        }
+                    };
+                    half4 ra[4], ral[4], rb[4], rbl[4], rc[4], rcl[4], rm[4], none[4];
+                    fetch(0, a.r_hi, a.r_lo, ra, ral);
+                    fetch(1, a.r_hi, a.r_lo, rb, rbl);
+                    fetch(2, a.r_hi, a.r_lo, rc, rcl);
+                    fetch(6, a.m_hi, nullptr, rm, none);
+                    // pin them: left alone, hipcc waits for each tile's values right before THAT tile's stores, i.e. behind the
+                    // stores of the tiles before it — and vmcnt counts those stores too
+                    auto pin = [](half4 (&x)[4]) __attribute__((always_inline)) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            H4 t;
+                            t.h = x[g];
+                            asm volatile("" : "+v"(t.u[0]), "+v"(t.u[1]));
+                            x[g] = t.h;
+                        }
+                    };
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    pin(ra); pin(ral); pin(rb); pin(rbl); pin(rc); pin(rcl); pin(rm);
+                    __builtin_amdgcn_sched_barrier(0);
+                    emit(0, ra, ral, none, 1);
+                    emit(1, rb, rbl, none, 1);
+                    emit(2, rc, rcl, none, 1);
+                    emit(6, none, none, rm, 2);
+                    emit(3, none, none, none, 0);
+                    emit(4, none, none, none, 0);
+                    emit(5, none, none, none, 0);
+                }
+            }
+        }
+        if constexpr (!LFFD) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int gy = row0 + r;
@@ -195,6 +307,26 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const float* _
                         }
                         off[mi][g] = o;
                     }
+                }
+                if constexpr (X) {
+                    // Every extra of the group is in its register BEFORE the group's first store (round 4): left alone, hipcc waits
+                    // for a slot's values right before THAT slot's stores — behind the stores of the slots before it, which vmcnt
+                    // counts too (the UPNet.2 epilogue went 122 -> 89 us on exactly this, profiles/r04_experiments.md section 9).
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int mi = 0; mi < MTG; ++mi)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            auto pin = [](half4& x) __attribute__((always_inline)) {
+                                H4 t;
+                                t.h = x;
+                                asm volatile("" : "+v"(t.u[0]), "+v"(t.u[1]));
+                                x = t.h;
+                            };
+                            pin(xr[mi][g]); pin(x2[mi][g]); pin(xm[mi][g]);
+                            if constexpr (NT == 3) { pin(xrl[mi][g]); pin(x2l[mi][g]); }
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 // ---- phase 2: bias, extras, ReLU / mask, hi / lo split, lane swap, stores
 #pragma unroll
@@ -274,6 +406,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const float* _
                 }
             }
         }
+        }   // !LFFD
         if (a.flags && __builtin_amdgcn_ballot_w64(sat != 0) != 0 && (threadIdx.x & 63) == 0)
             atomicOr(a.flags, BINHIP_FLAG_SATURATED);
     }
