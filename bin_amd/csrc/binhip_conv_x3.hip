@@ -466,23 +466,32 @@ final_dot2_kernel(const ConvKArgs a, const unsigned* __restrict__ w_hi32, const 
     }
     const int gy = ty0 + py, gx = tx0 + px;
     if (gy < H && gx < W) {
-        float sum[3];                                 // the frame loads of all three channels first, then the stores
+        // every load of the epilogue — the input frames AND the three biases (a.bias sits inside the by-value argument struct: per-lane
+        // vector loads) — before the first store, pinned: a load behind a store can only be used once the store has drained (shared
+        // vmcnt); the round-3 form fetched bias[j] between the stores: three serial round trips per pixel row (round 4)
+        float sum[3], bj[3];
+        const int nimg = a.nimg;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            float sj = 0.f;
-            if (j < a.cout && a.nimg > 0) {
-                const long long idx = (((long long)img * a.cout + j) * H + gy) * W + gx;
-                sj = a.img[0][idx];
-                for (int t = 1; t < a.nimg; ++t) sj += a.img[t][idx];
-                sj = sj / (float)a.nimg;
-            }
-            sum[j] = sj;
+            const long long idx = (((long long)img * a.cout + (j < a.cout ? j : 0)) * H + gy) * W + gx;
+            float v[5];
+#pragma unroll
+            for (int t = 0; t < 5; ++t) v[t] = (t < nimg) ? a.img[t][idx] : 0.f;
+            bj[j] = a.bias[j < a.cout ? j : 0];
+            float sj = v[0];
+#pragma unroll
+            for (int t = 1; t < 5; ++t)
+                if (t < nimg) sj += v[t];
+            sum[j] = nimg > 0 ? sj / (float)nimg : 0.f;
         }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(sum[j]), "+v"(bj[j]));
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             if (j >= a.cout) break;
             const long long idx = (((long long)img * a.cout + j) * H + gy) * W + gx;
-            a.out_f32[idx] = (acc[j] + a.bias[j]) + sum[j];
+            a.out_f32[idx] = (acc[j] + bj[j]) + sum[j];
         }
     }
 }
