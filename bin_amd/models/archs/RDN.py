@@ -585,7 +585,12 @@ def _forward_four_calls(self, B):
              self.clstm_7_prime_prime, self.clstm_6_prime_prime_prime)
 
     def parts(t, k):
-        return [t[i * n:(i + 1) * n] for i in range(k)]
+        # ONE split node, not k slices: the backward of a slice allocates and zero-fills a full-size tensor per slice and adds
+        # them up (k x (fill + add) over the whole batched output: ~6 GB of pure autograd traffic per 8 x 256x256 step); the
+        # backward of split is a single concatenation of the k slice gradients (same box: 129.5 -> 129.0 ms per step)
+        out = torch.split(t, n, 0)
+        assert len(out) == k
+        return list(out)
 
     I2, I4, I6, I8, I8b = parts(m.model1_1(cat((B1, B3, B5, B7, B9), 0), cat((B3, B5, B7, B9, B11), 0)), 5)
     h4, h6, h8 = (cells[k](x, None)[0] for k, x in enumerate((I4, I6, I8)))

@@ -40,8 +40,12 @@ for e in rows[:45]:
     if dt is None:
         dt = getattr(e, "cuda_time_total", 0)
     print(f"{e.count:6d} {dt:12.1f}  {e.key[:60]:60s} {str(e.input_shapes)[:90]}")
+print("---- fills / zeros / copies / adds by input shape")
+for e in rows:
+    if any(k in e.key for k in ("fill_", "zero_", "copy_", "aten::add", "aten::zeros", "aten::cat", "aten::clone")):
+        print(f"{e.count:6d}  {e.key[:40]:40s} {str(e.input_shapes)[:110]}")
 print("---- stacks of the most frequent small ops")
 ks = prof.key_averages(group_by_stack_n=6)
-for e in sorted(ks, key=lambda e: -e.count)[:25]:
+for e in sorted(ks, key=lambda e: -e.count)[:80]:
     if any(k in e.key for k in ("fill_", "zero_", "copy_", "aten::add", "aten::mul", "aten::cat", "aten::slice", "aten::neg", "aten::empty")):
-        print(e.count, e.key, [s for s in e.stack if "bin_amd" in s or "torch/optim" in s or "autograd" in s][:4])
+        print(e.count, e.key, [s.split("/")[-1] for s in e.stack if "bin_amd" in s or "torch/optim" in s or "autograd" in s][:5])
