@@ -41,6 +41,7 @@ struct ConvKArgs {
     int res_chunks;           // residual r applies to output chunks < res_chunks
     int mask_from;            // mask applies to output chunks >= mask_from (when m_hi != null)
     int y_cpg;                // output chunk grouping (<=0: one group)
+    unsigned y_cpg_inv;       // ceil(2^20 / y_cpg): och / y_cpg == (och * y_cpg_inv) >> 20 for och < 4096, y_cpg <= 128 (no SALU division per slot)
     long long y_group_stride;
     int y_unshuf;             // XTRA kernels only: > 0 = the output goes out through an inverse PixelShuffle(2) — full-resolution
                               // pixel (Y, X), chunk c -> plane (2 (Y & 1) + (X & 1)) * y_unshuf + c at (Y / 2, X / 2) of the half-
@@ -282,9 +283,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const float* _
                         } else {
                             const int och = co >> 4;
                             const long long pix16 = ((((long long)img * H + gyc) * W + gxc) << 4) + (co & 15);
-                            o = (a.y_cpg > 0)
-                                ? (long long)(och / a.y_cpg) * a.y_group_stride + (long long)(och % a.y_cpg) * plane_elems + pix16
-                                : (long long)och * plane_elems + pix16;
+                            if (a.y_cpg > 0) {
+                                const int q = (int)(((unsigned)och * a.y_cpg_inv) >> 20);     // och / y_cpg
+                                o = (long long)q * a.y_group_stride + (long long)(och - q * a.y_cpg) * plane_elems + pix16;
+                            } else {
+                                o = (long long)och * plane_elems + pix16;
+                            }
                             if constexpr (X) {
                                 if (a.y_unshuf > 0) {     // PixelShuffle backward fused into this store (UPNet.2's backward-data)
                                     const int sub = ((gyc & 1) << 1) | (gxc & 1);

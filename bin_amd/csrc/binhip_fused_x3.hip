@@ -391,7 +391,7 @@ rdb_tail_x3_kernel(const TailKArgs a, const float* __restrict__ bias_c, const fl
     e.flags = a.flags;
     e.N = a.N; e.H = H; e.W = W;
     e.relu = 0; e.has_res = 0; e.cout = 96; e.wt = a.wt;
-    e.och_limit = 6; e.res_chunks = 0; e.mask_from = 0; e.y_cpg = 0; e.y_group_stride = 0; e.y_unshuf = 0;
+    e.och_limit = 6; e.res_chunks = 0; e.mask_from = 0; e.y_cpg = 0; e.y_cpg_inv = 0; e.y_group_stride = 0; e.y_unshuf = 0;
     conv_epilogue<3, TX::R, 3, BINHIP_EPI_PLANES, false>(e, bias_l, accl, img, ty0 + wave * TX::R, tx0, 0, true, n, kg, plane_elems);
 }
 

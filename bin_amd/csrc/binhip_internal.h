@@ -35,12 +35,16 @@ __device__ static inline int bh_chunks_dev(int C) { return (C + 15) / 16; }
 // value of the epilogue live (+86 VGPRs on the multi-tile kernels, one wave per SIMD less: GFF.0 253 -> 352 us)
 __device__ __forceinline__ _Float16 split_hi(float v, unsigned& sat) {
     sat |= ((__float_as_uint(v) & 0x7fffffffu) > 0x477fe000u) ? 1u : 0u;
-    return (_Float16)fminf(fmaxf(v, -BINHIP_F16_MAX), BINHIP_F16_MAX);
+    // v_med3_f32 directly (round 4): fminf(fmaxf()) costs a canonicalising v_max per call on top of the med3 — two of the ~12 VALU
+    // instructions per stored value, in epilogues that are instruction-issue-bound (GFF.0 backward-data: 3 583 instructions per pixel
+    // row and wave for 48 stores).  Same results: in range the median is v; a NaN operand makes v_med3 return min3 = -65504, which is
+    // what the fminf / fmaxf chain produced.
+    return (_Float16)__builtin_amdgcn_fmed3f(v, -BINHIP_F16_MAX, BINHIP_F16_MAX);
 }
 // lo = v - hi, itself kept inside the fp16 range: in range it is |lo| <= ulp(hi)/2 and the clamp is the identity; after
 // a saturated hi the excess can be anything (or NaN), and an unclamped conversion would store inf / NaN after all
 __device__ __forceinline__ _Float16 split_lo(float v, _Float16 hi) {
-    return (_Float16)fminf(fmaxf(v - (float)hi, -BINHIP_F16_MAX), BINHIP_F16_MAX);
+    return (_Float16)__builtin_amdgcn_fmed3f(v - (float)hi, -BINHIP_F16_MAX, BINHIP_F16_MAX);
 }
 
 // internal launcher used by both the per-op ABI and the RDN plan
