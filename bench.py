@@ -227,6 +227,90 @@ def cpu_baseline(timeout_s=420):
             "sample": "cpu baseline failed: " + (err_txt.strip().splitlines() or ["?"])[-1][:200]}
 
 
+CLOCK_EXPLAINED_TOL = 0.03        # |cycles_data / cycles_zero - 1| up to which the time ratio counts as explained by the clock
+AT_CAP_PPT_FRAC = 0.5             # share of the firmware's samples with the PPT (package power) limiter active = "at the cap"
+AT_CAP_POWER_FRAC = 0.9           # fallback without limiter data: mean watts against the nominal cap
+
+
+def power_bound_reading(ms, ms_zero, power, zero):
+    """COMPUTE what the zero-operand control says (this used to be a constant string).  Inputs: the timed
+    ms of the real-data run, the ms of the all-zero run, and the two sampler summaries.  Returns the fields that go on the line:
+      cycles_data / cycles_zero (M cycles = ms x the mean shader clock of each pass), cycle_ratio,
+      limiter (what the device says throttled the real-data pass), at_cap + how that was decided,
+      reading = one of
+        "not at the cap: ..."        the device did not report the power limiter (or, without limiter data, mean watts < 0.9 cap)
+        "clock-explained: ..."       at the cap, and the real-data run needs the same cycles as the zero run (within 3 %):
+                                     time ratio = clock ratio, the instruction schedule is not what limits
+        "not clock-explained: ..."   at the cap, but real data costs more (or fewer) CYCLES than zeros at the sampled clocks;
+                                     the other sampled domains (memory / fabric clock, slowest XCD) are listed as candidates
+        "undetermined: ..."          a clock or a time is missing
+    """
+    def mean(d, k):
+        v = (d or {}).get(k)
+        return v.get("mean") if isinstance(v, dict) else None
+    out = {}
+    ck_d, ck_z = mean(power, "clock_mhz"), mean(zero, "clock_mhz")
+    pw_d = mean(power, "power_w")
+    lim = (power or {}).get("limiter") or {}
+    fr = lim.get("active_frac") or {}
+    out["limiter"] = {"source": lim.get("source", "unavailable"), "active_frac": fr or None, "dominant": lim.get("dominant"),
+                      "xcd_below_host_limit_ppt_frac": (lim.get("xcd_below_host_limit_ppt_frac") or {}).get("mean"),
+                      "zero_pass_active_frac": ((zero or {}).get("limiter") or {}).get("active_frac")}
+    cap = (power or {}).get("power_cap_w")
+    pmax = ((power or {}).get("power_w") or {}).get("max") if isinstance((power or {}).get("power_w"), dict) else None
+    out["power_cap_w"] = cap
+    out["power_cap_observed_w"] = pmax               # the highest socket power any sample of the real-data pass saw
+    out["power_from_energy_w"] = {"data": (power or {}).get("power_from_energy_w"), "zero": (zero or {}).get("power_from_energy_w")}
+    if "ppt_power" in fr:
+        at_cap = fr["ppt_power"] >= AT_CAP_PPT_FRAC
+        how = f"device: PPT limiter active in {fr['ppt_power']:.0%} of the firmware's samples (threshold {AT_CAP_PPT_FRAC:.0%})"
+    elif pw_d is not None and cap:
+        at_cap = pw_d >= AT_CAP_POWER_FRAC * cap
+        how = f"no limiter data: mean {pw_d:.0f} W against {AT_CAP_POWER_FRAC} x the nominal cap {cap:.0f} W"
+    else:
+        at_cap, how = None, "no limiter data and no power samples"
+    out["at_cap"], out["at_cap_rule"] = at_cap, how
+    if not (ck_d and ck_z and ms and ms_zero):
+        out.update(cycles_data_M=None, cycles_zero_M=None, cycle_ratio=None,
+                   reading="undetermined: a clock or a time is missing (no smi source on this box?)")
+        return out
+    cyc_d, cyc_z = ms * ck_d * 1e-3, ms_zero * ck_z * 1e-3          # ms x MHz = 1e3 cycles
+    cr = cyc_d / cyc_z
+    out.update(cycles_data_M=round(cyc_d, 2), cycles_zero_M=round(cyc_z, 2), cycle_ratio=round(cr, 4))
+    other = {}
+    for k in ("mem_clock_mhz", "fabric_clock_mhz", "soc_clock_mhz"):
+        a, b = mean(power, k), mean(zero, k)
+        if a and b:
+            other[k] = {"data": a, "zero": b, "zero_over_data": round(b / a, 4)}
+    xd, xz = (power or {}).get("xcd_clock_mhz"), (zero or {}).get("xcd_clock_mhz")
+    if xd and xz:
+        other["xcd_clock_mhz"] = {"data": xd, "zero": xz,
+                                  "cycle_ratio_at_xcd_mean_clock": round(ms * xd["mean"] / (ms_zero * xz["mean"]), 4),
+                                  "cycle_ratio_at_slowest_xcd": round(ms * xd["slowest_xcd_mean"] / (ms_zero * xz["slowest_xcd_mean"]), 4)}
+    out["other_domains"] = other or None
+    tr, clr = ms / ms_zero, ck_z / ck_d
+    if at_cap is False:
+        out["reading"] = (f"not at the cap: {how}; time ratio {tr:.3f}, clock ratio {clr:.3f}, cycle ratio {cr:.3f} - the zero-operand "
+                          "speed-up cannot be attributed to the package power limit on this box")
+    elif abs(cr - 1.0) <= CLOCK_EXPLAINED_TOL:
+        out["reading"] = (f"clock-explained: {how}; real data and zeros need the same cycles ({cyc_d:.1f} M vs {cyc_z:.1f} M, ratio "
+                          f"{cr:.3f}), so the time ratio {tr:.3f} is the clock ratio {clr:.3f}: the run is limited by the clock the "
+                          "limiter leaves, not by its instruction schedule")
+    else:
+        cand = []
+        for k, v in other.items():
+            if k != "xcd_clock_mhz" and abs(v["zero_over_data"] - 1.0) > 0.01:
+                cand.append(f"{k} {v['data']:.0f} vs {v['zero']:.0f}")
+        if "xcd_clock_mhz" in other:
+            x = other["xcd_clock_mhz"]
+            cand.append(f"cycle ratio at the per-XCD mean clock {x['cycle_ratio_at_xcd_mean_clock']:.3f}, at the slowest XCD "
+                        f"{x['cycle_ratio_at_slowest_xcd']:.3f}")
+        out["reading"] = (f"not clock-explained: {how}; real data takes {(cr - 1) * 100:+.1f} % cycles against zeros at the sampled "
+                          f"shader clocks ({cyc_d:.1f} M vs {cyc_z:.1f} M; time ratio {tr:.3f}, clock ratio {clr:.3f})"
+                          + ("; other domains: " + "; ".join(cand) if cand else "; no other sampled domain differs"))
+    return out
+
+
 def power_bound_object(ms, power, zero, what):
     """`power`: sampler summary of the real-data power pass, `zero`: of the all-zero-operand pass (both carry ms_per_repetition)."""
     def mean(d, k):
@@ -234,18 +318,18 @@ def power_bound_object(ms, power, zero, what):
         return v.get("mean") if isinstance(v, dict) else None
     ms_zero = zero.get("ms_per_repetition")
     ms_data = power.get("ms_per_repetition")
-    return {"what": f"{what}: the same launches on all-zero operands (same instruction streams, idle datapaths), right after the "
-                    "timed region",
-            "ms": round(ms, 3), "ms_data_pass": ms_data, "ms_zero": ms_zero,
-            "ratio": None if not ms_zero else round(ms / ms_zero, 4),
-            "clock_mhz": {"data": mean(power, "clock_mhz"), "zero": mean(zero, "clock_mhz")},
-            "clock_ratio": (None if not (mean(power, "clock_mhz") and mean(zero, "clock_mhz"))
-                            else round(mean(zero, "clock_mhz") / mean(power, "clock_mhz"), 4)),
-            "power_w": {"data": mean(power, "power_w"), "zero": mean(zero, "power_w")},
-            "power_cap_w": power.get("power_cap_w"),
-            "reading": "ratio ~ clock_ratio > 1 with power_w.data at the cap and power_w.zero below it: the real-data run is "
-                       "limited by the clock the package power cap leaves, not by its instruction schedule",
-            "zero_pass_repetitions": zero.get("repetitions")}
+    out = {"what": f"{what}: the same launches on all-zero operands (same instruction streams, idle datapaths), right after the "
+                   "timed region",
+           "ms": round(ms, 3), "ms_data_pass": ms_data, "ms_zero": ms_zero,
+           "ratio": None if not ms_zero else round(ms / ms_zero, 4),
+           "clock_mhz": {"data": mean(power, "clock_mhz"), "zero": mean(zero, "clock_mhz")},
+           "clock_ratio": (None if not (mean(power, "clock_mhz") and mean(zero, "clock_mhz"))
+                           else round(mean(zero, "clock_mhz") / mean(power, "clock_mhz"), 4)),
+           "power_w": {"data": mean(power, "power_w"), "zero": mean(zero, "power_w")},
+           "energy_j_per_repetition": {"data": power.get("energy_j_per_repetition"), "zero": zero.get("energy_j_per_repetition")}}
+    out.update(power_bound_reading(ms, ms_zero, power, zero))
+    out["zero_pass_repetitions"] = zero.get("repetitions")
+    return out
 
 
 def max_over_ranks(dt, dev, world):

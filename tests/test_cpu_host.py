@@ -525,3 +525,39 @@ def test_harness_rules_properties():
         sizes = [e - s for s, e in spans]
         assert max(sizes) - min(sizes) <= 1
     shards()
+
+
+def test_power_bound_reading_is_derived_from_its_numbers():
+    """bench.power_bound_reading: three outcomes from the numbers, decided by the device's limiter residency when it is there."""
+    import bench
+
+    def summ(clock, power, ppt=None, cap=1400.0, mem=None):
+        d = {"clock_mhz": {"mean": clock}, "power_w": {"mean": power, "max": power + 30}, "power_cap_w": cap,
+             "limiter": {"source": "unavailable"} if ppt is None else
+             {"source": "x", "active_frac": {"ppt_power": ppt, "hbm_thermal": 0.0}, "dominant": "ppt_power" if ppt > 0.05 else None}}
+        if mem:
+            d["mem_clock_mhz"] = {"mean": mem}
+        return d
+    zero = summ(2366.0, 1050.0, 0.0)
+    r = bench.power_bound_reading(69.2, 53.4, summ(1810.0, 1296.0, 0.98), zero)        # r04 builder box: same cycles
+    assert r["reading"].startswith("clock-explained") and r["at_cap"] is True and abs(r["cycle_ratio"] - 1.0) <= 0.03
+    r = bench.power_bound_reading(73.9, 53.4, summ(1812.7, 1296.0, 0.98, mem=1800.0), dict(zero, mem_clock_mhz={"mean": 2000.0}))
+    assert r["reading"].startswith("not clock-explained") and r["cycle_ratio"] == pytest.approx(1.0603, abs=2e-3)   # r04 driver box
+    assert "mem_clock_mhz 1800 vs 2000" in r["reading"]
+    r = bench.power_bound_reading(60.0, 53.4, summ(2300.0, 1100.0, 0.02), zero)
+    assert r["reading"].startswith("not at the cap") and r["at_cap"] is False
+    # without limiter data the watts decide: 1296 W of a 1400 W cap is "at the cap" (>= 0.9), 1100 W is not
+    assert bench.power_bound_reading(69.2, 53.4, summ(1810.0, 1296.0), zero)["at_cap"] is True
+    assert bench.power_bound_reading(69.2, 53.4, summ(1810.0, 1100.0), zero)["at_cap"] is False
+    assert bench.power_bound_reading(69.2, 53.4, {"clock_mhz": None}, zero)["reading"].startswith("undetermined")
+
+
+def test_smi_device_index_accepts_every_device_spelling():
+    """advisor r04: a str device used to resolve to the bound method `str.index` and the sampler silently reported nothing."""
+    from bin_amd.utils import smi
+    assert [smi.device_index(d) for d in (None, 0, 3, "cuda", "cuda:0", "cuda:2", "1", torch.device("cuda", 1), torch.device("cuda"))] \
+        == [0, 0, 3, 0, 0, 2, 1, 1, 0]
+    with pytest.raises(ValueError):
+        smi.device_index("cpu")
+    s = smi.Sampler("cuda:0")                    # no GPU in the build container: reports the error, never raises
+    assert "samples" in s.summary()
