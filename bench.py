@@ -270,25 +270,40 @@ def power_bound_reading(ms, ms_zero, power, zero):
     else:
         at_cap, how = None, "no limiter data and no power samples"
     out["at_cap"], out["at_cap_rule"] = at_cap, how
-    if not (ck_d and ck_z and ms and ms_zero):
+    # Which clock?  amdsmi's GFX `clk` is the FASTEST XCD's clock (measured round 5: it equals fastest_xcd_mean to the digit); under
+    # the package limit the eight XCDs settle 5-8 % apart, and every XCD runs its own band of tiles, so the device-wide mean
+    # (and, for the tail of a launch, the slowest XCD) is what the work sees.  Cycles are counted at the per-XCD MEAN when
+    # the gpu_metrics table has it, at `clk` otherwise; both figures are on the line.
+    xd, xz = (power or {}).get("xcd_clock_mhz"), (zero or {}).get("xcd_clock_mhz")
+    use_xcd = bool(xd and xz and xd.get("mean") and xz.get("mean"))
+    fd, fz = (xd["mean"], xz["mean"]) if use_xcd else (ck_d, ck_z)
+    out["cycles_clock"] = ("per-XCD mean shader clock (gpu_metrics current_gfxclks)" if use_xcd
+                           else "amdsmi GFX clk (= the fastest XCD; no per-XCD table on this box)")
+    if not (fd and fz and ms and ms_zero):
         out.update(cycles_data_M=None, cycles_zero_M=None, cycle_ratio=None,
                    reading="undetermined: a clock or a time is missing (no smi source on this box?)")
         return out
-    cyc_d, cyc_z = ms * ck_d * 1e-3, ms_zero * ck_z * 1e-3          # ms x MHz = 1e3 cycles
+    cyc_d, cyc_z = ms * fd * 1e-3, ms_zero * fz * 1e-3              # ms x MHz = 1e3 cycles
     cr = cyc_d / cyc_z
     out.update(cycles_data_M=round(cyc_d, 2), cycles_zero_M=round(cyc_z, 2), cycle_ratio=round(cr, 4))
     other = {}
-    for k in ("mem_clock_mhz", "fabric_clock_mhz", "soc_clock_mhz"):
+    for k in ("mem_clock_mhz", "fabric_clock_mhz"):
         a, b = mean(power, k), mean(zero, k)
         if a and b:
             other[k] = {"data": a, "zero": b, "zero_over_data": round(b / a, 4)}
-    xd, xz = (power or {}).get("xcd_clock_mhz"), (zero or {}).get("xcd_clock_mhz")
-    if xd and xz:
+    if use_xcd:
         other["xcd_clock_mhz"] = {"data": xd, "zero": xz,
-                                  "cycle_ratio_at_xcd_mean_clock": round(ms * xd["mean"] / (ms_zero * xz["mean"]), 4),
+                                  "cycle_ratio_at_gfx_clk": None if not (ck_d and ck_z) else round(ms * ck_d / (ms_zero * ck_z), 4),
                                   "cycle_ratio_at_slowest_xcd": round(ms * xd["slowest_xcd_mean"] / (ms_zero * xz["slowest_xcd_mean"]), 4)}
     out["other_domains"] = other or None
-    tr, clr = ms / ms_zero, ck_z / ck_d
+    tr, clr = ms / ms_zero, fz / fd
+    out["clock_ratio_used"] = round(clr, 4)
+    # if the real-data run needs FEWER cycles than the zero run, part of it does not scale with the shader clock (HBM-bound
+    # kernels, host gaps): the share s of the zero run's time that must be clock-independent for tr = s + (1 - s) * clr
+    share = None
+    if clr > 1.0 and tr < clr:
+        share = round((clr - tr) / (clr - 1.0), 4)
+    out["clock_independent_share_implied"] = share
     if at_cap is False:
         out["reading"] = (f"not at the cap: {how}; time ratio {tr:.3f}, clock ratio {clr:.3f}, cycle ratio {cr:.3f} - the zero-operand "
                           "speed-up cannot be attributed to the package power limit on this box")
@@ -303,11 +318,14 @@ def power_bound_reading(ms, ms_zero, power, zero):
                 cand.append(f"{k} {v['data']:.0f} vs {v['zero']:.0f}")
         if "xcd_clock_mhz" in other:
             x = other["xcd_clock_mhz"]
-            cand.append(f"cycle ratio at the per-XCD mean clock {x['cycle_ratio_at_xcd_mean_clock']:.3f}, at the slowest XCD "
+            cand.append(f"cycle ratio at the GFX clk (fastest XCD) {x['cycle_ratio_at_gfx_clk']}, at the slowest XCD "
                         f"{x['cycle_ratio_at_slowest_xcd']:.3f}")
-        out["reading"] = (f"not clock-explained: {how}; real data takes {(cr - 1) * 100:+.1f} % cycles against zeros at the sampled "
-                          f"shader clocks ({cyc_d:.1f} M vs {cyc_z:.1f} M; time ratio {tr:.3f}, clock ratio {clr:.3f})"
-                          + ("; other domains: " + "; ".join(cand) if cand else "; no other sampled domain differs"))
+        if cr < 1.0 and share is not None:
+            cand.append(f"fewer cycles on real data = a clock-independent share of the run (HBM-bound kernels, gaps): implied "
+                        f"{share:.0%} of the zero run's time")
+        out["reading"] = (f"not clock-explained: {how}; real data takes {(cr - 1) * 100:+.1f} % cycles against zeros ({cyc_d:.1f} M vs "
+                          f"{cyc_z:.1f} M; time ratio {tr:.3f}, clock ratio {clr:.3f})"
+                          + ("; " + "; ".join(cand) if cand else "; no other sampled domain differs"))
     return out
 
 
@@ -322,7 +340,8 @@ def power_bound_object(ms, power, zero, what):
                    "timed region",
            "ms": round(ms, 3), "ms_data_pass": ms_data, "ms_zero": ms_zero,
            "ratio": None if not ms_zero else round(ms / ms_zero, 4),
-           "clock_mhz": {"data": mean(power, "clock_mhz"), "zero": mean(zero, "clock_mhz")},
+           "clock_mhz": {"data": mean(power, "clock_mhz"), "zero": mean(zero, "clock_mhz"),
+                         "note": "amdsmi GFX clk = the fastest XCD; the per-XCD mean / slowest are in other_domains.xcd_clock_mhz"},
            "clock_ratio": (None if not (mean(power, "clock_mhz") and mean(zero, "clock_mhz"))
                            else round(mean(zero, "clock_mhz") / mean(power, "clock_mhz"), 4)),
            "power_w": {"data": mean(power, "power_w"), "zero": mean(zero, "power_w")},

@@ -550,6 +550,17 @@ def test_power_bound_reading_is_derived_from_its_numbers():
     assert bench.power_bound_reading(69.2, 53.4, summ(1810.0, 1296.0), zero)["at_cap"] is True
     assert bench.power_bound_reading(69.2, 53.4, summ(1810.0, 1100.0), zero)["at_cap"] is False
     assert bench.power_bound_reading(69.2, 53.4, {"clock_mhz": None}, zero)["reading"].startswith("undetermined")
+    # with the per-XCD table the cycles are counted at the device-wide MEAN clock (amdsmi's GFX clk is the fastest XCD):
+    # the r05 box — 71.67 ms at clk 1791 / XCD mean 1733 vs 53.32 ms at 2364 / 2352
+    xd = {"xcds": 8, "mean": 1732.9, "slowest_xcd_mean": 1675.0, "fastest_xcd_mean": 1791.2}
+    xz = {"xcds": 8, "mean": 2351.9, "slowest_xcd_mean": 2338.2, "fastest_xcd_mean": 2364.1}
+    r = bench.power_bound_reading(71.669, 53.322, dict(summ(1791.2, 1308.7, 0.956), xcd_clock_mhz=xd), dict(summ(2363.8, 1210.7, 0.28), xcd_clock_mhz=xz))
+    assert r["cycles_clock"].startswith("per-XCD") and r["cycle_ratio"] == pytest.approx(0.9903, abs=1e-3)
+    assert r["reading"].startswith("clock-explained") and r["other_domains"]["xcd_clock_mhz"]["cycle_ratio_at_gfx_clk"] == pytest.approx(1.0185, abs=1e-3)
+    # fewer cycles on real data (training: a quarter of the step is HBM-bound): the implied clock-independent share is reported
+    r = bench.power_bound_reading(132.72, 114.29, dict(summ(1797.5, 1335.0, 0.92), xcd_clock_mhz=dict(xd, mean=1754.6)),
+                                  dict(summ(2193.9, 1231.0, 0.48), xcd_clock_mhz=dict(xz, mean=2178.9)))
+    assert r["reading"].startswith("not clock-explained") and 0.25 < r["clock_independent_share_implied"] < 0.40
 
 
 def test_smi_device_index_accepts_every_device_spelling():

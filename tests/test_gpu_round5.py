@@ -117,9 +117,15 @@ def test_bench_power_bound_reading_is_computed_from_the_numbers_beside_it():
     kind = pb["reading"].split(":")[0]
     assert kind in ("clock-explained", "not clock-explained", "not at the cap", "undetermined")
     assert kind != "undetermined", pb                                  # a GPU box has an smi source
-    assert pb["cycles_data_M"] == pytest.approx(pb["ms"] * pb["clock_mhz"]["data"] * 1e-3, rel=1e-3)
-    assert pb["cycles_zero_M"] == pytest.approx(pb["ms_zero"] * pb["clock_mhz"]["zero"] * 1e-3, rel=1e-3)
+    x = (pb["other_domains"] or {}).get("xcd_clock_mhz")
+    fd, fz = (x["data"]["mean"], x["zero"]["mean"]) if x else (pb["clock_mhz"]["data"], pb["clock_mhz"]["zero"])
+    assert ("per-XCD" in pb["cycles_clock"]) == bool(x)
+    assert pb["cycles_data_M"] == pytest.approx(pb["ms"] * fd * 1e-3, rel=1e-3)
+    assert pb["cycles_zero_M"] == pytest.approx(pb["ms_zero"] * fz * 1e-3, rel=1e-3)
     assert pb["cycle_ratio"] == pytest.approx(pb["cycles_data_M"] / pb["cycles_zero_M"], rel=1e-3)
+    assert pb["cycle_ratio"] == pytest.approx(pb["ratio"] / pb["clock_ratio_used"], rel=2e-3)
+    if x:                          # amdsmi's GFX clk is the fastest XCD: never below the per-XCD mean
+        assert pb["clock_mhz"]["data"] >= x["data"]["mean"] - 1.0 and x["data"]["slowest_xcd_mean"] <= x["data"]["mean"]
     if kind == "not at the cap":
         assert pb["at_cap"] is False
     else:

@@ -18,7 +18,7 @@
 #   env NAME=VALUE              export for the steps that follow (env NAME= unsets)
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.." || exit 1
 mkdir -p gpurun_out; export TMPDIR=/tmp
-TAG=run; NB=0
+TAG=run; NB=0; NP=0
 keyfig() { python - "$1" <<'PY'
 import json, sys
 try:
@@ -81,8 +81,8 @@ for step in "$@"; do
       case "$1" in wgrad*) F=wgrad3x3;; rdb*) F=conv_x3;; *) F=_x3_;; esac
       ( echo "=== pmc_one.py $*"; python tools/pmc_sum.py /tmp/pmc_a $F; python tools/pmc_sum.py /tmp/pmc_b $F ) 2>&1 | tee -a gpurun_out/${TAG}_pmc_sq.log ;;
     py)
-      script=$1; shift; b=$(basename $script .py)
-      ( timeout 1200 python $script "$@" 2>&1 | tail -60 ) > gpurun_out/${TAG}_$b.log 2>&1; tail -30 gpurun_out/${TAG}_$b.log ;;
+      script=$1; shift; b=$(basename $script .py); NP=$((NP+1))
+      ( timeout 1200 python $script "$@" 2>&1 | tail -150 ) > gpurun_out/${TAG}_${b}_$NP.log 2>&1; tail -30 gpurun_out/${TAG}_${b}_$NP.log ;;
     *) echo "unknown step: $verb" ;;
   esac
 done
