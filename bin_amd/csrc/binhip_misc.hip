@@ -179,6 +179,160 @@ convlstm_kernel(const float* __restrict__ x, const float* __restrict__ cp, const
     }
 }
 
+// ---- the same cell, FOUR pixels per thread (round 5; W % 4 == 0 and 16-byte aligned planes, else the kernels above/below) ----
+// The one-pixel kernel issues 27 (54 with state) 4-byte loads and 324 (648) broadcast LDS reads per pixel and, with state, fetches
+// c_prev between its stores: loads and stores share vmcnt on gfx9, so each of those loads waits for the stores before it
+// (36.9 us per 768x1344 cell = 1.0 TB/s of a 37 MB pass).  Here a thread owns 4 consecutive pixels of a row: one 16-byte load + two
+// edge loads per (channel, row) serve 3 taps x 4 pixels, the 12 gate weights of a tap are three ds_read_b128 (layout
+// [channel][tap][gate]) reused by 4 pixels, and EVERY load of the epilogue (c_prev; in the backward also g_h, g_c) is issued
+// and pinned before the first store.  Each pixel's fmaf chain runs in the order of the one-pixel kernel (bias, then channel,
+// dy, dx; an out-of-image tap contributes fma(w, 0, g) = g), so the two kernels agree bit for bit.
+__device__ __forceinline__ void convlstm_load_weights4(float* ws, const float* __restrict__ w, const float* __restrict__ b) {
+    for (int i = threadIdx.x; i < 12 * 54 + 12; i += blockDim.x) {
+        if (i < 648) {
+            const int o = i / 54, r = i % 54;              // w[(o * 6 + ci) * 9 + tap]  ->  ws[(ci * 9 + tap) * 12 + o]
+            ws[r * 12 + o] = w[i];
+        } else {
+            ws[i] = b[i - 648];
+        }
+    }
+}
+__device__ __forceinline__ void convlstm_gates4(const float* __restrict__ x, const float* __restrict__ hp, const float* ws,
+                                                int n, int y, int x0, int H, int W, long long HW, float (&g)[12][4]) {
+#pragma unroll
+    for (int o = 0; o < 12; ++o)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) g[o][p] = ws[648 + o];
+    const int nin = hp ? 6 : 3;
+    for (int ci = 0; ci < nin; ++ci) {
+        const float* src = (ci < 3) ? (x + ((long long)n * 3 + ci) * HW) : (hp + ((long long)n * 3 + (ci - 3)) * HW);
+        float v[3][6];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {                   // the three rows' loads first, then their 9 x 12 x 4 fmas
+            const int yy = y + dy - 1;
+            const bool ok = yy >= 0 && yy < H;
+            const float* r = src + (long long)(ok ? yy : y) * W + x0;
+            const float4 c = *reinterpret_cast<const float4*>(r);
+            const float l = (x0 > 0) ? r[-1] : 0.f, rt = (x0 + 4 < W) ? r[4] : 0.f;
+            v[dy][0] = ok ? l : 0.f; v[dy][1] = ok ? c.x : 0.f; v[dy][2] = ok ? c.y : 0.f;
+            v[dy][3] = ok ? c.z : 0.f; v[dy][4] = ok ? c.w : 0.f; v[dy][5] = ok ? rt : 0.f;
+        }
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const float4* wq = reinterpret_cast<const float4*>(ws + ((ci * 9) + dy * 3 + dx) * 12);
+                const float4 w0 = wq[0], w1 = wq[1], w2 = wq[2];
+                const float wv[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+#pragma unroll
+                for (int o = 0; o < 12; ++o)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) g[o][p] = fmaf(wv[o], v[dy][p + dx], g[o][p]);
+            }
+    }
+}
+__device__ __forceinline__ float4 ld4_or_zero(const float* p, long long o) {
+    return p ? *reinterpret_cast<const float4*>(p + o) : float4{0.f, 0.f, 0.f, 0.f};
+}
+__device__ __forceinline__ void pin4(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+
+__global__ void __launch_bounds__(256)
+convlstm4_kernel(const float* __restrict__ x, const float* __restrict__ cp, const float* __restrict__ hp,
+                 const float* __restrict__ w, const float* __restrict__ b, float fb, int N, int H, int W,
+                 float* __restrict__ cn, float* __restrict__ hn) {
+    __shared__ __attribute__((aligned(16))) float ws[12 * 6 * 9 + 12];
+    convlstm_load_weights4(ws, w, b);
+    __syncthreads();
+    const long long HW = (long long)H * W;
+    const int W4 = W >> 2;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)N * H * W4) return;
+    const int xq = (int)(t % W4), y = (int)((t / W4) % H), n = (int)(t / ((long long)W4 * H));
+    const int x0 = xq * 4;
+    float g[12][4];
+    convlstm_gates4(x, hp, ws, n, y, x0, H, W, HW, g);
+    const long long o0 = ((long long)n * 3) * HW + (long long)y * W + x0;
+    float4 cprev[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cprev[k] = ld4_or_zero(cp, o0 + k * HW);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pin4(cprev[k]);
+    __builtin_amdgcn_sched_barrier(0);
+    float4 c1v[3], h1v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {           // i = g[0:3], j = g[3:6], f = g[6:9], o = g[9:12]  (RDN.py:79)
+        float c1[4], h1[4];
+        const float cpv[4] = {cprev[k].x, cprev[k].y, cprev[k].z, cprev[k].w};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            c1[p] = cpv[p] * sigmoidf_(g[6 + k][p] + fb) + sigmoidf_(g[k][p]) * tanhf(g[3 + k][p]);
+            h1[p] = tanhf(c1[p]) * sigmoidf_(g[9 + k][p]);
+        }
+        c1v[k] = float4{c1[0], c1[1], c1[2], c1[3]};
+        h1v[k] = float4{h1[0], h1[1], h1[2], h1[3]};
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (cn) *reinterpret_cast<float4*>(cn + o0 + k * HW) = c1v[k];
+        *reinterpret_cast<float4*>(hn + o0 + k * HW) = h1v[k];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+convlstm4_bwd_gates_kernel(const float* __restrict__ x, const float* __restrict__ cp, const float* __restrict__ hp,
+                           const float* __restrict__ w, const float* __restrict__ b, float fb, int N, int H, int W,
+                           const float* __restrict__ gh, const float* __restrict__ gc, float* __restrict__ dgates,
+                           float* __restrict__ gcp) {
+    __shared__ __attribute__((aligned(16))) float ws[12 * 6 * 9 + 12];
+    convlstm_load_weights4(ws, w, b);
+    __syncthreads();
+    const long long HW = (long long)H * W;
+    const int W4 = W >> 2;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)N * H * W4) return;
+    const int xq = (int)(t % W4), y = (int)((t / W4) % H), n = (int)(t / ((long long)W4 * H));
+    const int x0 = xq * 4;
+    float g[12][4];
+    convlstm_gates4(x, hp, ws, n, y, x0, H, W, HW, g);
+    const long long pix = (long long)y * W + x0;
+    const long long o0 = ((long long)n * 3) * HW + pix;
+    float4 cprev[3], ghv[3], gcv[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        cprev[k] = ld4_or_zero(cp, o0 + k * HW);
+        ghv[k] = ld4_or_zero(gh, o0 + k * HW);
+        gcv[k] = ld4_or_zero(gc, o0 + k * HW);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { pin4(cprev[k]); pin4(ghv[k]); pin4(gcv[k]); }
+    __builtin_amdgcn_sched_barrier(0);
+    const long long d0 = ((long long)n * 12) * HW + pix;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float cpv[4] = {cprev[k].x, cprev[k].y, cprev[k].z, cprev[k].w};
+        const float gh4[4] = {ghv[k].x, ghv[k].y, ghv[k].z, ghv[k].w};
+        const float gc4[4] = {gcv[k].x, gcv[k].y, gcv[k].z, gcv[k].w};
+        float di[4], dj[4], df[4], dob[4], dcp[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const float si = sigmoidf_(g[k][p]), tj = tanhf(g[3 + k][p]), sf = sigmoidf_(g[6 + k][p] + fb), so = sigmoidf_(g[9 + k][p]);
+            const float c1 = cpv[p] * sf + si * tj;
+            const float tc = tanhf(c1);
+            const float gct = gc4[p] + gh4[p] * so * (1.f - tc * tc);
+            di[p] = gct * tj * si * (1.f - si);
+            dj[p] = gct * si * (1.f - tj * tj);
+            df[p] = gct * cpv[p] * sf * (1.f - sf);
+            dob[p] = gh4[p] * tc * so * (1.f - so);
+            dcp[p] = gct * sf;
+        }
+        *reinterpret_cast<float4*>(dgates + d0 + (long long)(k) * HW) = float4{di[0], di[1], di[2], di[3]};
+        *reinterpret_cast<float4*>(dgates + d0 + (long long)(3 + k) * HW) = float4{dj[0], dj[1], dj[2], dj[3]};
+        *reinterpret_cast<float4*>(dgates + d0 + (long long)(6 + k) * HW) = float4{df[0], df[1], df[2], df[3]};
+        *reinterpret_cast<float4*>(dgates + d0 + (long long)(9 + k) * HW) = float4{dob[0], dob[1], dob[2], dob[3]};
+        if (gcp) *reinterpret_cast<float4*>(gcp + o0 + k * HW) = float4{dcp[0], dcp[1], dcp[2], dcp[3]};
+    }
+}
+
 // ---- ConvLSTM gate arithmetic for cells OTHER than the (3, 3) cell of the live path (reference RDN.py:74-82, any
 // input_size / hidden_size: RDN.py:14-24).  The gates conv of such a cell runs on the general convolution kernels; these two
 // elementwise kernels are the rest: gates [N, 4h, H, W] (i, j, f, o) -> c', h' and its backward.
@@ -581,14 +735,26 @@ int binhip_pack_inputs(const float* const* images, int n_images, int N, int H, i
     return 0;
 }
 
+// the four-pixel ConvLSTM kernels: rows of whole float4s, every plane pointer 16-byte aligned (null = absent = fine)
+static inline bool convlstm_vec4_ok(int W, const void* a, const void* b, const void* c, const void* d, const void* e, const void* f,
+                                    const void* g) {
+    uintptr_t m = 0;
+    for (const void* p : {a, b, c, d, e, f, g}) m |= (uintptr_t)p;
+    return (W & 3) == 0 && (m & 15) == 0;
+}
+
 int binhip_convlstm_fwd(const float* x, const float* c_prev, const float* h_prev, const float* w, const float* b,
                         float forget_bias, int N, int H, int W, float* c_new, float* h_new, void* stream) {
     if (!x || !w || !b || !h_new) return BINHIP_E_ARG;
     if ((c_prev == nullptr) != (h_prev == nullptr)) return BINHIP_E_ARG;
     if (N <= 0 || H <= 0 || W <= 0) return BINHIP_E_SHAPE;
     const long long total = (long long)N * H * W;
-    hipLaunchKernelGGL(convlstm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       x, c_prev, h_prev, w, b, forget_bias, N, H, W, c_new, h_new);
+    if (convlstm_vec4_ok(W, x, c_prev, h_prev, c_new, h_new, nullptr, nullptr))
+        hipLaunchKernelGGL(convlstm4_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           x, c_prev, h_prev, w, b, forget_bias, N, H, W, c_new, h_new);
+    else
+        hipLaunchKernelGGL(convlstm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           x, c_prev, h_prev, w, b, forget_bias, N, H, W, c_new, h_new);
     BH_CHECK_LAUNCH();
     return 0;
 }
@@ -750,8 +916,12 @@ int binhip_convlstm_bwd(const float* x, const float* c_prev, const float* h_prev
     float* part = dg + (size_t)N * 12 * H * W;
     const long long total = (long long)N * H * W;
     const unsigned nb = (unsigned)((total + 255) / 256);
-    hipLaunchKernelGGL(convlstm_bwd_gates_kernel, dim3(nb), dim3(256), 0, s, x, c_prev, h_prev, w, b, forget_bias, N, H, W,
-                       g_h, g_c, dg, g_cprev);
+    if (convlstm_vec4_ok(W, x, c_prev, h_prev, g_h, g_c, dg, g_cprev))
+        hipLaunchKernelGGL(convlstm4_bwd_gates_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, x, c_prev, h_prev,
+                           w, b, forget_bias, N, H, W, g_h, g_c, dg, g_cprev);
+    else
+        hipLaunchKernelGGL(convlstm_bwd_gates_kernel, dim3(nb), dim3(256), 0, s, x, c_prev, h_prev, w, b, forget_bias, N, H, W,
+                           g_h, g_c, dg, g_cprev);
     if (gx || g_hprev)
         hipLaunchKernelGGL(convlstm_bwd_input_kernel, dim3(nb), dim3(256), 0, s, dg, w, N, H, W, gx, g_hprev);
     if (dw && db) {

@@ -136,3 +136,59 @@ def test_bench_power_bound_reading_is_computed_from_the_numbers_beside_it():
         assert pb["at_cap"] == (fr["ppt_power"] >= 0.5) and pb["at_cap_rule"].startswith("device:")
         assert all(0.0 <= v <= 1.0001 for v in fr.values())
     assert pb["power_cap_observed_w"] >= pb["power_w"]["data"] - 1e-6
+
+
+def _off1(t):
+    """A copy of `t` whose data pointer is 4 bytes past a 16-byte boundary (forces the one-pixel ConvLSTM kernels)."""
+    buf = torch.empty(t.numel() + 4, dtype=t.dtype, device=t.device)
+    assert buf.data_ptr() % 16 == 0
+    v = buf[1:1 + t.numel()].view(t.shape)
+    v.copy_(t)
+    assert v.data_ptr() % 16 == 4
+    return v
+
+
+@pytest.mark.parametrize("with_state", [False, True])
+@pytest.mark.parametrize("shape", [(1, 16, 24), (2, 9, 20), (1, 33, 4), (1, 5, 64)])
+def test_convlstm_four_pixel_kernels_equal_the_one_pixel_kernels(shape, with_state):
+    """Round 5: `binhip_convlstm_fwd` / `_bwd` run four pixels per thread (float4 rows, weights as ds_read_b128, every epilogue
+    load before the first store) when W % 4 == 0 and the planes are 16-byte aligned, and the round-1 one-pixel kernels otherwise.
+    Same fmaf chains per pixel -> the two must agree BIT FOR BIT: the same data is run through both by mis-aligning the planes
+    by one float.  (Both are pinned to the reference by tests/test_gpu_ops.py::test_convlstm_golden.)"""
+    import ctypes as C
+    from bin_amd import _lib as L
+    lib = L.lib()
+    n, h, w = shape
+    g = torch.Generator().manual_seed(n * 1000 + h * 10 + w)
+    dev = torch.device("cuda")
+    mk = lambda *s: (torch.rand(*s, generator=g) - 0.5).to(dev)
+    x, cp, hp, gh, gc = (mk(n, 3, h, w) for _ in range(5))
+    wt, b = mk(12, 6, 3, 3), mk(12)
+    p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    nbytes = lib.binhip_convlstm_bwd_workspace_bytes(n, h, w)
+
+    def run(conv):
+        X, CP, HP, GH, GC = (conv(t) for t in (x, cp, hp, gh, gc))
+        if not with_state:
+            CP = HP = None
+        cn, hn, gx, ghp, gcp = (conv(torch.zeros_like(x)) for _ in range(5))
+        L.check(lib.binhip_convlstm_fwd(p(X), p(CP), p(HP), p(wt), p(b), 1.0, n, h, w, p(cn), p(hn), stream), "fwd")
+        ws = torch.empty(nbytes + 512, dtype=torch.uint8, device=dev)
+        dw, db = torch.zeros_like(wt), torch.zeros_like(b)
+        L.check(lib.binhip_convlstm_bwd(p(X), p(CP), p(HP), p(wt), p(b), 1.0, n, h, w, p(GH), p(GC), p(ws), nbytes, p(gx),
+                                        p(ghp) if with_state else None, p(gcp) if with_state else None, p(dw), p(db), stream), "bwd")
+        torch.cuda.synchronize()
+        return [t.clone() for t in (cn, hn, gx, dw, db)] + ([ghp.clone(), gcp.clone()] if with_state else [])
+
+    fast = run(lambda t: t.clone())
+    slow = run(_off1)
+    for i, (a, c) in enumerate(zip(fast, slow)):
+        assert torch.equal(a, c), (i, float((a - c).abs().max()))
+    # and against plain torch (the formula of RDN.py:74-92), forward only: 1e-6
+    xin = torch.cat((x, hp if with_state else torch.zeros_like(x)), 1)
+    gates = torch.nn.functional.conv2d(xin, wt, b, padding=1)
+    i_, j_, f_, o_ = gates.chunk(4, 1)
+    c_ref = (cp if with_state else 0) * torch.sigmoid(f_ + 1.0) + torch.sigmoid(i_) * torch.tanh(j_)
+    h_ref = torch.tanh(c_ref) * torch.sigmoid(o_)
+    assert float((fast[0] - c_ref).abs().max()) <= 2e-6 and float((fast[1] - h_ref).abs().max()) <= 2e-6
