@@ -817,6 +817,8 @@ int binhip_conv2d_bwd_data(const BinConvDesc* d, const void* gy_hi, const void* 
     c.r2_hi = acc_hi; c.r2_lo = acc_lo;
     c.m_hi = mask_hi; c.mask_from = mask_from;
     c.y_cpg = y_cpg; c.y_group_stride = y_group_stride;
+    c.y_unshuf = d->reserved > 0 ? d->reserved : 0;      // (BinConvDesc.reserved: the fused inverse PixelShuffle of the store)
+    c.d.reserved = 0;
     c.y_hi = gx_hi; c.y_lo = gx_lo; c.y_f32 = nullptr;
     c.status = d->status;
     for (int i = 0; i < 5; ++i) c.images[i] = nullptr;

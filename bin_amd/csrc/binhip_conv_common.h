@@ -226,7 +226,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const float* _
                             if (lo) xl[g] = *reinterpret_cast<const half4*>(lo + o);
                         }
                     };
-                    half4 ra[4], ral[4], rb[4], rbl[4], rc[4], rcl[4], rm[4], none[4];
+                    half4 ra[4], ral[4], rb[4], rbl[4], rc[4], rcl[4], rm[4], none[4] = {};
                     fetch(0, a.r_hi, a.r_lo, ra, ral);
                     fetch(1, a.r_hi, a.r_lo, rb, rbl);
                     fetch(2, a.r_hi, a.r_lo, rc, rcl);
@@ -265,7 +265,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const float* _
             for (int mt0 = 0; mt0 < MT; mt0 += MTG) {
                 // ---- phase 1: addresses and (XTRA) every load of the group
                 long long off[MTG][4];
-                half4 xr[MTG][4], xrl[MTG][4], x2[MTG][4], x2l[MTG][4], xm[MTG][4];
+                // (zero-initialised: the pins below touch every slot, also those no load filled — a slot beyond res_chunks, a
+                //  call without mask — and must not read indeterminate registers; advisor r04)
+                half4 xr[MTG][4] = {}, xrl[MTG][4] = {}, x2[MTG][4] = {}, x2l[MTG][4] = {}, xm[MTG][4] = {};
 #pragma unroll
                 for (int mi = 0; mi < MTG; ++mi) {
                     const int mt = mt0 + mi;

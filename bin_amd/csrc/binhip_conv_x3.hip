@@ -659,12 +659,19 @@ final_m16_kernel(const ConvKArgs a, const float* __restrict__ bias) {
                     sum[r][g][j] = (ok && nimg > 0) ? sj / (float)nimg : 0.f;
                 }
             }
+        // (the three biases too: `bias` is a scalar-load parameter, but a load of it BETWEEN the stores would still sit behind
+        //  their drain — advisor r04; final_dot2_kernel hoists them the same way)
+        float bj[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) bj[j] = bias[j < a.cout ? j : 0];
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int g = 0; g < 2; ++g)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(sum[r][g][j]));
+#pragma unroll
+        for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(bj[j]));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 2; ++r)
@@ -676,7 +683,7 @@ final_m16_kernel(const ConvKArgs a, const float* __restrict__ bias) {
                 for (int j = 0; j < 3; ++j) {
                     if (j >= a.cout) break;
                     const long long idx = (((long long)img * a.cout + j) * H + gy) * W + gx;
-                    a.out_f32[idx] = (acc[r][g][j] + bias[j]) + sum[r][g][j];
+                    a.out_f32[idx] = (acc[r][g][j] + bj[j]) + sum[r][g][j];
                 }
             }
     }

@@ -347,7 +347,10 @@ class RDN_residual_interp_5_input_ConvLSTM_L(nn.Module):
         windows of a clip share 4 of their 5 stage-1 frame pairs, and — round 4 — the first window of
         the next forward also repeats two stage-2 calls and one stage-3 call of this one (it sees no ConvLSTM state), so
         every LSTM-free call is memoised on the identity of its (cached, hence long-lived) input tensors: 17 -> 10 RDN
-        calls per window (rounds 1-3: 13), outputs unchanged bit for bit.  (The name is kept from round 1.)"""
+        calls per window (rounds 1-3: 13), outputs unchanged bit for bit.  (The name is kept from round 1.)  The key also
+        carries the weight set's state (precision, parameter versions, relayout generation), so a dict that outlives a
+        weight change misses instead of serving stale results.  While a cache is live the OUTPUTS are shared with it (this
+        window's I5 comes back as the next window's I3): do not modify them in place."""
         for t in (B1, B3, B5, B7, B9, B11):
             if not t.is_cuda:
                 raise RuntimeError("bin_amd: bin_stage4 runs on a HIP device only (no CPU fallback; "
@@ -426,7 +429,9 @@ def _forward_streams(self, B, stage1_cache=None, input_events=None):
     m = self.model
     mods = {1: m.model1_1, 2: m.model2_1, 3: m.model3_1, 4: m.model4_1}
     nterms = {k: PRECISIONS[v.precision or default_precision()] for k, v in mods.items()}
-    stale = [v._wcache is None or v._wcache[0] != v._weights_key(nterms[k]) for k, v in mods.items()]
+    wkeys = {k: v._weights_key(nterms[k]) for k, v in mods.items()}     # (precision, device, generation, every parameter's version)
+    stale = [v._wcache is None or v._wcache[0] != wkeys[k] for k, v in mods.items()]
+    wstamp = {k: hash(wkeys[k]) for k in mods}
     relayout_pending = any(stale)
     kw = {k: v.kernel_weights(nterms[k]) for k, v in mods.items()}       # relayouts (if any) on the main stream
     lib = L.lib()
@@ -519,7 +524,9 @@ def _forward_streams(self, B, stage1_cache=None, input_events=None):
         independent -> 10 RDN calls per window, same kernels on the same inputs => the same bits."""
         if stage1_cache is None:
             return rdn(si, k, *ins)
-        key = (k,) + tuple(id(t) for t in ins)
+        # the weight set's state is part of the key (advisor r04): a cache dict that survives an optimizer step,
+        # load_state_dict, set_precision or invalidate_kernel_weights() must miss, not serve the old weights' outputs
+        key = (k, wstamp[k]) + tuple(id(t) for t in ins)
         touched.add(key)
         hit = stage1_cache.get(key)
         if hit is not None and all(a is b for a, b in zip(hit[1], ins)):

@@ -346,16 +346,19 @@ def rdb_tail(blk, cw3, cwl, out=None, store_o3=False):
     return out
 
 
-def conv2d_bwd_data(gy, dw, res=None, res_chunks=0, acc=None, mask=None, mask_from=0, out=None):
-    """gx = [mask](conv_{W'}(gy) [+ res] [+ acc]) on chunk planes (binhip_conv2d_bwd_data)."""
+def conv2d_bwd_data(gy, dw, res=None, res_chunks=0, acc=None, mask=None, mask_from=0, out=None, y_unshuf=0):
+    """gx = [mask](conv_{W'}(gy) [+ res] [+ acc]) on chunk planes (binhip_conv2d_bwd_data).  `y_unshuf` > 0: the result leaves
+    through an inverse PixelShuffle(2) — 4 * y_unshuf planes at half resolution (BinConvDesc.reserved)."""
     _, n, h, w, _ = gy.hi.shape
     d = L.BinConvDesc()
     d.N, d.H, d.W, d.ksize = n, h, w, dw.ks
     d.cin_chunks, d.cout, d.cout_pad, d.nterms = dw.cin_chunks, dw.cout, dw.cout_pad, dw.nterms
     d.epilogue, d.relu, d.x_cpg, d.x_group_stride, d.n_images = L.EPI_PLANES, 0, 0, 0, 0
     d.status = status_word(gy.hi.device).data_ptr()
+    d.reserved = int(y_unshuf)
     if out is None:
-        out = CP.empty(chunks(dw.cout), n, h, w, dw.nterms, gy.hi.device, dw.cout)
+        out = (CP.empty(4 * y_unshuf, n, h // 2, w // 2, dw.nterms, gy.hi.device) if y_unshuf
+               else CP.empty(chunks(dw.cout), n, h, w, dw.nterms, gy.hi.device, dw.cout))
     z = C.c_void_p(0)
     rc = L.lib().binhip_conv2d_bwd_data(
         C.byref(d), _ptr(gy.hi), _ptr(gy.lo), _ptr(dw.w_hi), _ptr(dw.w_lo), _ptr(dw.bias),

@@ -134,6 +134,21 @@ def main(argv=None, stats=None):
         util.setup_logger("base", result_root, "test", screen=True, tofile=True)
     log = logging.getLogger("base")
 
+    # Ramp (round 5): the window list is known before the network exists, so the decoder pool starts on the FIRST windows'
+    # frames now and works while the model is constructed and its weights are laid out (into plain host arrays: the
+    # page-locked staging buffers need the device context, which the main thread is about to create).
+    windows = list_windows(args.input_path)
+    begin, end = harness.shard_windows(len(windows), rank, world)
+    pool = ThreadPoolExecutor(max_workers=max(2, args.io_threads))
+    early = {}
+    if begin < end:
+        clip0, frames0, index0 = windows[begin]
+        for ahead in range(0, 3):
+            if begin + ahead < end and windows[begin + ahead][0] == clip0:
+                for fid in harness.window_frame_ids(index0 + ahead, len(frames0)):
+                    if (clip0, fid) not in early:
+                        early[(clip0, fid)] = pool.submit(data_util.imread_u8, os.path.join(args.input_path, clip0, frames0[fid]))
+
     model = create_model(opt)
     netG = model.netG
     netG.eval()
@@ -143,10 +158,7 @@ def main(argv=None, stats=None):
     log.info("In Data: %s | model: %s | parameters: %d | ranks: %d | stage-1 reuse: %s", args.input_path,
              opt["path"]["pretrain_model_G"], sum(p.numel() for p in netG.parameters() if p.requires_grad), world, reuse)
 
-    windows = list_windows(args.input_path)
-    begin, end = harness.shard_windows(len(windows), rank, world)
     sums = _Sums()
-    pool = ThreadPoolExecutor(max_workers=max(2, args.io_threads))
     copy_stream = torch.cuda.Stream(device=dev)
     decoded, frames_dev, stage1_cache, pending = {}, {}, {}, []
     geom = None                                        # (h, w, pads) of the current clip
@@ -161,8 +173,8 @@ def main(argv=None, stats=None):
     upload_stream = torch.cuda.Stream(device=dev)
     stage_pool, stage_lock, in_flight = [], threading.Lock(), []
 
-    def decode(path):                                  # (worker thread)
-        img = data_util.imread_u8(path)
+    def decode(path, ready=None):                      # (worker thread)
+        img = data_util.imread_u8(path) if ready is None else ready.result()
         src = torch.from_numpy(img)
         with stage_lock:
             buf = next((b for b in stage_pool if b.shape == src.shape), None)
@@ -190,25 +202,25 @@ def main(argv=None, stats=None):
     def want(clip, frames, fid):                       # async decode, at most once per frame
         key = (clip, fid)
         if key not in decoded:
-            decoded[key] = pool.submit(decode, os.path.join(args.input_path, clip, frames[fid]))
+            decoded[key] = pool.submit(decode, os.path.join(args.input_path, clip, frames[fid]), early.pop(key, None))
         return decoded[key]
 
     def finish(job):
-        clip, names, owned, host, done, blurry_path = job
+        """(worker thread) ONE output image of a window: wait for its D2H copy, encode + write it, score it.  One task per
+        image (round 5; before: the window's three images in one task) — in steady state the pool is busy either way, but
+        the LAST window's three encodes now run side by side instead of one after the other (the drain at the end of a clip)."""
+        clip, name, mine, kind, img, done, blurry_path = job
         done.synchronize()
-        clip_dir = os.path.join(result_root, clip)
-        for img, name, mine, kind in zip(host.numpy(), names, owned, ("interp", "deblur", "deblur")):
-            if name is None:
-                continue
-            if mine:
-                util.save_img(img, os.path.join(clip_dir, name))
-                with written_lock:
-                    written.append(os.path.join(clip, name))
-            if mine or kind == "interp":           # the reference scores a deblurred frame when it writes it
-                _score(sums, clip, kind, img, args.gt_path and os.path.join(args.gt_path, clip, name), args.ssim)
-        if args.gt_path:
+        img = img.numpy()
+        if mine:
+            util.save_img(img, os.path.join(result_root, clip, name))
+            with written_lock:
+                written.append(os.path.join(clip, name))
+        if mine or kind == "interp":               # the reference scores a deblurred frame when it writes it
+            _score(sums, clip, kind, img, args.gt_path and os.path.join(args.gt_path, clip, name), args.ssim)
+        if blurry_path is not None and args.gt_path:
             _score(sums, clip, "blurry", data_util.imread_u8(blurry_path)[:, :, :3],
-                   os.path.join(args.gt_path, clip, names[0]), args.ssim)
+                   os.path.join(args.gt_path, clip, name), args.ssim)
 
     written, written_lock = [], threading.Lock()       # files THIS rank saved (--manifest)
     stamps = []                                        # host time at which each window's work had been queued
@@ -238,10 +250,13 @@ def main(argv=None, stats=None):
                 outs.record_stream(copy_stream)
                 done = torch.cuda.Event()
                 done.record()
-            pending.append((pool.submit(finish, (clip, names, owned, host, done, blurry_path)), host))
+            jobs = [pool.submit(finish, (clip, name, mine, kind, host[k], done, blurry_path if k == 0 else None))
+                    for k, (name, mine, kind) in enumerate(zip(names, owned, ("interp", "deblur", "deblur"))) if name is not None]
+            pending.append((jobs, host))
         while len(pending) > 8 + len(group):             # bound host memory; surfaces worker exceptions
-            job, buf = pending.pop(0)
-            job.result()
+            jobs, buf = pending.pop(0)
+            for job in jobs:
+                job.result()
             pinned.append(buf)
         timer.update((time.time() - t0) / len(group), len(group))
         stamps.extend([time.time()] * len(group))
@@ -290,8 +305,9 @@ def main(argv=None, stats=None):
             if len(group) >= args.batch:
                 flush()
         flush()
-        for job, _ in pending:
-            job.result()
+        for jobs, _ in pending:
+            for job in jobs:
+                job.result()
     torch.cuda.synchronize()
     ops.check_status(dev)                 # a frame that left the fp16 storage range is an error, not a result
     wall = time.time() - t_all

@@ -93,7 +93,12 @@ typedef struct BinConvDesc {
     int64_t x_group_stride;   /*   x + (i / x_cpg) * x_group_stride + (i % x_cpg) * N*H*W*16     */
                               /*   (elements). x_cpg <= 0: one group.                             */
     int32_t n_images;         /* FINAL: number of fp32 NCHW images averaged into the output      */
-    int32_t reserved;
+    int32_t reserved;         /* binhip_conv2d_bwd_data only: y_unshuf > 0 = store the result through an  */
+                              /*   inverse PixelShuffle(2): full-resolution pixel (Y, X), chunk c goes to    */
+                              /*   plane (2 (Y & 1) + (X & 1)) * y_unshuf + c at (Y / 2, X / 2) of a tensor  */
+                              /*   of 4 * y_unshuf planes at H/2 x W/2 — what binhip_unshuffle_planes makes  */
+                              /*   of the plain result (H, W even, y_cpg = 0, 16 * y_unshuf >= cout).        */
+                              /*   0 everywhere else.                                                        */
     void*   status;           /* device uint32 status word (BINHIP_STATUS_*), OR-ed into; or NULL */
 } BinConvDesc;
 

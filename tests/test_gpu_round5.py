@@ -192,3 +192,112 @@ def test_convlstm_four_pixel_kernels_equal_the_one_pixel_kernels(shape, with_sta
     c_ref = (cp if with_state else 0) * torch.sigmoid(f_ + 1.0) + torch.sigmoid(i_) * torch.tanh(j_)
     h_ref = torch.tanh(c_ref) * torch.sigmoid(o_)
     assert float((fast[0] - c_ref).abs().max()) <= 2e-6 and float((fast[1] - h_ref).abs().max()) <= 2e-6
+
+
+# ------------------------------------------------------------------------------------------------ per-op tests of the round-4 device paths
+# (advisor r04: the LFF backward-data epilogue instantiation, the fused inverse-PixelShuffle store and final_m16_kernel were only
+#  exercised through whole-RDN tests at 32x48 and the 720p golden).  Shapes: N = 2, 18 x 44 — partial 16 x 32 tiles in both dimensions.
+def _planes(t, nt=3):
+    from bin_amd import ops
+    return ops.nchw_to_planes(t, nt)
+
+
+def test_bwd_data_fused_inverse_pixelshuffle_equals_the_two_pass_form():
+    """UPNet.2's backward-data (64 <- 3 channels, 3x3, at full resolution) storing straight through the inverse PixelShuffle
+    (`BinConvDesc.reserved` = y_unshuf = 4 chunks per sub-position) == the plain backward-data followed by
+    binhip_unshuffle_planes, bit for bit — both precisions, N > 1, ragged tiles."""
+    import ctypes as C
+    from bin_amd import _lib as L, ops
+    g = torch.Generator().manual_seed(91)
+    n, h, w = 2, 18, 44
+    wt = ((torch.rand(3, 64, 3, 3, generator=g) - 0.5) / 8).cuda()
+    gy = (torch.rand(n, 3, h, w, generator=g) - 0.5).cuda()
+    for nt in (3, 1):
+        dgw = ops.DgradWeights(wt, nterms=nt)
+        gp = _planes(gy, nt)
+        plain = ops.conv2d_bwd_data(gp, dgw)                                  # 4 chunks at h x w
+        two = ops.CP.empty(16, n, h // 2, w // 2, nt, gy.device)
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        L.check(L.lib().binhip_unshuffle_planes(p(plain.hi), p(plain.lo), n, h // 2, w // 2, 4, p(two.hi), p(two.lo),
+                                                C.c_void_p(torch.cuda.current_stream().cuda_stream)), "unshuffle_planes")
+        fused = ops.conv2d_bwd_data(gp, dgw, y_unshuf=4)
+        assert tuple(fused.hi.shape) == (16, n, h // 2, w // 2, 16)
+        assert torch.equal(fused.hi, two.hi), nt
+        if nt == 3:
+            assert torch.equal(fused.lo, two.lo)
+        # and the values: conv_transpose of gy, un-shuffled (channel order of UPNet.0's permuted rows = pixel_unshuffle's)
+        ref = torch.nn.functional.conv_transpose2d(gy.double(), wt.double(), padding=1)
+        got = ops.planes_to_nchw(plain, 64).double()
+        assert float((got - ref).abs().max()) <= (2e-6 if nt == 3 else 2e-3) * float(ref.abs().max())
+
+
+def test_lff_backward_data_epilogue_instantiation_vs_float64():
+    """The LFF 1x1 backward-data tile with its own epilogue (EPI_PLANES_LFFD: residual on the first 6 chunks, ReLU mask from
+    chunk 12, 14 output chunks) — the call pattern binhip_plan.hip issues per dense block — against the same arithmetic in fp64:
+        gcat = W^T gy ;  gcat[:, :96] += gy ;  gcat[:, 192:] *= (act[:, 192:] > 0)."""
+    from bin_amd import ops
+    g = torch.Generator().manual_seed(92)
+    n, h, w = 2, 18, 44
+    wt = ((torch.rand(96, 224, 1, 1, generator=g) - 0.5) / 6).cuda()
+    gy = (torch.rand(n, 96, h, w, generator=g) - 0.5).cuda()
+    act = (torch.rand(n, 224, h, w, generator=g) - 0.4).cuda()                 # ~40 % of the masked channels are <= 0
+    gp, ap = _planes(gy), _planes(act)
+    dgw = ops.DgradWeights(wt, nterms=3)
+    out = ops.conv2d_bwd_data(gp, dgw, res=gp, res_chunks=6, mask=ap, mask_from=12)
+    got = ops.planes_to_nchw(out, 224).double()
+    gyq = ops.planes_to_nchw(gp, 96).double()                                  # what the kernel really read (hi + lo)
+    ref = torch.nn.functional.conv_transpose2d(gyq, wt.double())
+    ref[:, :96] += gyq
+    ref[:, 192:] *= (ops.planes_to_nchw(ops.CP(ap.hi, None, 224), 224)[:, 192:] > 0)      # the mask reads the hi plane
+    assert float((got - ref).abs().max()) <= 3e-6 * float(ref.abs().max())
+    assert float(got[:, 192:][ref[:, 192:] == 0].abs().max()) == 0.0          # masked means exactly zero
+    # the generic extras path (same call without the mask: a different instantiation) agrees on the unmasked chunks
+    nomask = ops.planes_to_nchw(ops.conv2d_bwd_data(gp, dgw, res=gp, res_chunks=6), 224).double()
+    assert torch.equal(nomask[:, :192], got[:, :192])
+
+
+@pytest.mark.parametrize("cin,nimg", [(64, 2), (64, 5), (80, 3)])
+def test_final_m16_kernel_vs_float64(cin, nimg):
+    """UPNet.2 of the fp32-class mode (`final_m16_kernel`: 16x16x32 MFMA with tap pairs, 3 output channels + the mean of the
+    input frames) at N = 2 on ragged tiles, with 4 and 5 input chunks (5 = its weight-slab limit) and 2 / 3 / 5 frames."""
+    from bin_amd import _lib as L, ops
+    g = torch.Generator().manual_seed(93 + cin + nimg)
+    n, h, w = 2, 18, 44
+    wt = ((torch.rand(3, cin, 3, 3, generator=g) - 0.5) / 10).cuda()
+    b = (torch.rand(3, generator=g) - 0.5).cuda()
+    x = (torch.rand(n, cin, h, w, generator=g) - 0.3).cuda()
+    imgs = [torch.rand(n, 3, h, w, generator=g).cuda() for _ in range(nimg)]
+    xp = _planes(x)
+    cw = ops.ConvWeights(wt, b, nterms=3)
+    got = ops.conv2d(xp, cw, epilogue=L.EPI_FINAL, images=imgs).double()
+    xq = ops.planes_to_nchw(xp, cin).double()
+    ref = torch.nn.functional.conv2d(xq, wt.double(), b.double(), padding=1) + sum(i.double() for i in imgs) / nimg
+    assert float((got - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
+    f16 = ops.conv2d(_planes(x, 1), ops.ConvWeights(wt, b, nterms=1), epilogue=L.EPI_FINAL, images=imgs).double()
+    assert float((f16 - ref).abs().max()) <= 3e-3                             # the single-product mode's kernel (v_dot2 lanes)
+
+
+def test_streaming_cache_misses_after_a_weight_or_precision_change():
+    """advisor r04: the cross-window memo was keyed on (stage, input identities) only — a cache dict that outlived an optimizer
+    step / load_state_dict / set_precision served the OLD weights' results.  The key now carries the weight set's state."""
+    from bin_amd.models.archs.RDN import bin_stage4_lstm
+    from bin_amd.weights import reference_state_dict, synthetic_frames
+    net = bin_stage4_lstm()
+    net.load_state_dict(reference_state_dict(0), strict=True)
+    net = net.cuda().eval().set_precision("f16x3")
+    frames = [f.cuda() for f in synthetic_frames(77, 1, 64, 96, 6)]
+    cache = {}
+    with torch.no_grad():
+        a = net(*frames, stage1_cache=cache)
+        again = net(*frames, stage1_cache=cache)
+        assert all(x is y for x, y in zip(a[:10], again[:10]))                  # same weights: every LSTM-free call is a hit
+        for p in net.model.model1_1.SFENet1.parameters():
+            p.mul_(1.25)                                                        # in-place: bumps the version counters
+        b = net(*frames, stage1_cache=cache)
+        fresh = net(*frames)
+        assert all(torch.equal(x, y) for x, y in zip(b, fresh))
+        assert not torch.equal(a[0], b[0])
+        net.set_precision("f16")
+        c = net(*frames, stage1_cache=cache)
+        fresh16 = net(*frames)
+        assert all(torch.equal(x, y) for x, y in zip(c, fresh16)) and not torch.equal(b[0], c[0])
