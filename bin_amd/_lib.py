@@ -24,6 +24,19 @@ class BinConvDesc(C.Structure):
                 ("reserved", C.c_int32), ("status", C.c_void_p)]
 
 
+LOSS_MAX_TERMS = 24          # BINHIP_LOSS_MAX_TERMS
+
+
+class BinLossTerms(C.Structure):
+    _fields_ = [("x", C.c_void_p * LOSS_MAX_TERMS), ("y", C.c_void_p * LOSS_MAX_TERMS), ("n_terms", C.c_int32)]
+
+
+class BinLossGrads(C.Structure):
+    _fields_ = [("out", C.c_void_p * LOSS_MAX_TERMS), ("term_a", C.c_int32 * LOSS_MAX_TERMS),
+                ("term_b", C.c_int32 * LOSS_MAX_TERMS), ("sign_a", C.c_float * LOSS_MAX_TERMS),
+                ("sign_b", C.c_float * LOSS_MAX_TERMS), ("n_out", C.c_int32)]
+
+
 class BinRdnShape(C.Structure):
     """(G0, D, C, G) of an RDN sub-network (include/binhip.h); all zero = bin_stage4's (96, 12, 4, 32)."""
     _fields_ = [("G0", C.c_int32), ("D", C.c_int32), ("C", C.c_int32), ("G", C.c_int32)]
@@ -91,6 +104,10 @@ _SIGNATURES = {
                                         C.c_void_p]),
     "binhip_pixel_loss_bwd": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p]),
+    "binhip_multi_loss_fwd": (C.c_int, [C.c_int, C.POINTER(BinLossTerms), C.c_int64, C.c_float, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]),
+    "binhip_multi_loss_bwd": (C.c_int, [C.c_int, C.POINTER(BinLossTerms), C.c_int64, C.c_float, C.c_void_p,
+                                        C.POINTER(BinLossGrads), C.c_void_p]),
     "binhip_dgrad_rows_pad": (C.c_int, [C.c_int, C.c_int]),
     "binhip_weights_relayout_dgrad": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                 C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -426,6 +426,71 @@ charb_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, long 
     }
 }
 
+// ---- all terms of bin_model.get_loss at once (binhip_multi_loss_fwd / _bwd, include/binhip.h) -------------------------
+// blockIdx.y = term; per term the SAME partial sums as charb_partial_kernel with the same grid -> the same bits
+template <int KIND>
+__global__ void __launch_bounds__(256)
+multi_loss_partial_kernel(const BinLossTerms t, long long n, float eps, float* __restrict__ partials) {
+    const float* __restrict__ x = t.x[blockIdx.y];
+    const float* __restrict__ y = t.y[blockIdx.y];
+    float acc = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        acc += crit_term<KIND>(x[i] - y[i], eps);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    __shared__ float sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[(long long)blockIdx.y * gridDim.x + blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+// one block: every term's final reduction (as charb_final_kernel), then the left-to-right fp32 sum of the terms / T
+__global__ void __launch_bounds__(256)
+multi_loss_final_kernel(const float* __restrict__ partials, int nb, int nterms, double denom, float* __restrict__ terms,
+                        float* __restrict__ loss) {
+    __shared__ double sm[256];
+    for (int t = 0; t < nterms; ++t) {
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < nb; i += 256) acc += (double)partials[(long long)t * nb + i];
+        sm[threadIdx.x] = acc;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) terms[t] = (float)(sm[0] / denom);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float s = terms[0];
+        for (int t = 1; t < nterms; ++t) s = s + terms[t];
+        // (ATen divides a device tensor by a host scalar as a product with the fp32 reciprocal; the same here, so that the fused
+        //  loss and the per-term path — torch ops over binhip_pixel_loss_fwd results — agree bit for bit)
+        loss[0] = s * (1.0f / (float)nterms);
+    }
+}
+// blockIdx.y = output tensor k: out[k] = s * (sign_a * crit'(x_a - y_a) [+ sign_b * crit'(x_b - y_b)])
+template <int KIND>
+__global__ void __launch_bounds__(256)
+multi_loss_bwd_kernel(const BinLossTerms t, const BinLossGrads g, long long n, float eps, float scale, float inv_terms,
+                      const float* __restrict__ gl) {
+    const int k = blockIdx.y;
+    const int ta = g.term_a[k], tb = g.term_b[k];
+    const float s = (gl[0] * inv_terms) * scale;       // d loss / d term = gloss * (1 / T) (as autograd's division node), then / numel
+    const float sa = g.sign_a[k], sb = g.sign_b[k];
+    const float* __restrict__ xa = t.x[ta];
+    const float* __restrict__ ya = t.y[ta];
+    const float* __restrict__ xb = tb >= 0 ? t.x[tb] : nullptr;
+    const float* __restrict__ yb = tb >= 0 ? t.y[tb] : nullptr;
+    float* __restrict__ out = g.out[k];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        // each term's gradient is rounded on its own (s * crit') and the two are then added: what autograd's accumulation of
+        // the per-term gradients computes
+        float v = sa * (s * crit_grad<KIND>(xa[i] - ya[i], eps));
+        if (xb) v += sb * (s * crit_grad<KIND>(xb[i] - yb[i], eps));
+        out[i] = v;
+    }
+}
+
 // ---- gradient scaling: scale = 2^floor(log2(target / amax)) so fp16 gradient planes neither overflow nor
 // underflow; sc[0] = scale, sc[1] = 1/scale.  Two-pass amax (deterministic).
 __global__ void __launch_bounds__(256)
@@ -820,6 +885,55 @@ int binhip_pixel_loss_bwd(int kind, const float* x, const float* y, int64_t nume
         hipLaunchKernelGGL(charb_bwd_kernel<BINHIP_LOSS_L1_SUM>, grid, block, 0, s, x, y, (long long)numel, eps, inv, gloss, gx, gy);
     else
         hipLaunchKernelGGL(charb_bwd_kernel<BINHIP_LOSS_L2_SUM>, grid, block, 0, s, x, y, (long long)numel, eps, inv, gloss, gx, gy);
+    BH_CHECK_LAUNCH();
+    return 0;
+}
+
+int binhip_multi_loss_fwd(int kind, const BinLossTerms* t, int64_t numel, float eps, float* partials, float* terms, float* loss,
+                          void* stream) {
+    if (!t || !partials || !terms || !loss) return BINHIP_E_ARG;
+    if (kind < BINHIP_LOSS_CHARBONNIER || kind > BINHIP_LOSS_L2_SUM) return BINHIP_E_ARG;
+    if (t->n_terms <= 0 || t->n_terms > BINHIP_LOSS_MAX_TERMS) return BINHIP_E_ARG;
+    for (int i = 0; i < t->n_terms; ++i)
+        if (!t->x[i] || !t->y[i]) return BINHIP_E_ARG;
+    if (numel <= 0) return BINHIP_E_SHAPE;
+    long long nb = (numel + 255) / 256;
+    if (nb > CHARB_BLOCKS) nb = CHARB_BLOCKS;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)nb, (unsigned)t->n_terms), block(256);
+    if (kind == BINHIP_LOSS_CHARBONNIER)
+        hipLaunchKernelGGL(multi_loss_partial_kernel<BINHIP_LOSS_CHARBONNIER>, grid, block, 0, s, *t, (long long)numel, eps, partials);
+    else if (kind == BINHIP_LOSS_L1_SUM)
+        hipLaunchKernelGGL(multi_loss_partial_kernel<BINHIP_LOSS_L1_SUM>, grid, block, 0, s, *t, (long long)numel, eps, partials);
+    else
+        hipLaunchKernelGGL(multi_loss_partial_kernel<BINHIP_LOSS_L2_SUM>, grid, block, 0, s, *t, (long long)numel, eps, partials);
+    hipLaunchKernelGGL(multi_loss_final_kernel, dim3(1), dim3(256), 0, s, partials, (int)nb, (int)t->n_terms,
+                       kind == BINHIP_LOSS_CHARBONNIER ? (double)numel : 1.0, terms, loss);
+    BH_CHECK_LAUNCH();
+    return 0;
+}
+
+int binhip_multi_loss_bwd(int kind, const BinLossTerms* t, int64_t numel, float eps, const float* gloss, const BinLossGrads* g,
+                          void* stream) {
+    if (!t || !g || !gloss) return BINHIP_E_ARG;
+    if (kind < BINHIP_LOSS_CHARBONNIER || kind > BINHIP_LOSS_L2_SUM) return BINHIP_E_ARG;
+    if (t->n_terms <= 0 || t->n_terms > BINHIP_LOSS_MAX_TERMS || g->n_out <= 0 || g->n_out > BINHIP_LOSS_MAX_TERMS) return BINHIP_E_ARG;
+    for (int k = 0; k < g->n_out; ++k)
+        if (!g->out[k] || g->term_a[k] < 0 || g->term_a[k] >= t->n_terms || g->term_b[k] >= t->n_terms) return BINHIP_E_ARG;
+    if (numel <= 0) return BINHIP_E_SHAPE;
+    long long nb = (numel + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)nb, (unsigned)g->n_out), block(256);
+    // gloss / T, and for the mean criterion / numel: the per-term rounding order of the per-term path (g / T first, then / numel)
+    const float scale = (kind == BINHIP_LOSS_CHARBONNIER ? 1.f / (float)numel : 1.f);
+    const float inv_t = 1.0f / (float)t->n_terms;
+    if (kind == BINHIP_LOSS_CHARBONNIER)
+        hipLaunchKernelGGL(multi_loss_bwd_kernel<BINHIP_LOSS_CHARBONNIER>, grid, block, 0, s, *t, *g, (long long)numel, eps, scale, inv_t, gloss);
+    else if (kind == BINHIP_LOSS_L1_SUM)
+        hipLaunchKernelGGL(multi_loss_bwd_kernel<BINHIP_LOSS_L1_SUM>, grid, block, 0, s, *t, *g, (long long)numel, eps, scale, inv_t, gloss);
+    else
+        hipLaunchKernelGGL(multi_loss_bwd_kernel<BINHIP_LOSS_L2_SUM>, grid, block, 0, s, *t, *g, (long long)numel, eps, scale, inv_t, gloss);
     BH_CHECK_LAUNCH();
     return 0;
 }

@@ -379,17 +379,16 @@ class bin_model(BaseModel):
 
     # ------------------------------------------------------------------ loss (bin_model.py:395-425)
     def get_loss(self, ret=0):
-        loss_list = []
+        # reference bin_model.py:395-425: 14 terms against the sharp frames, for nframes 6 / version 2 three cycle terms between
+        # outputs, loss = sum(terms) / len(terms); the returned list is trimmed to the 14.  All terms and the mean are ONE
+        # autograd node on the device (models/loss.py::multi_term_loss) when the criterion is one of the product's.
+        from .loss import multi_term_loss
         num, gt_list = self.get_info(mode=1)
         assert num == len(gt_list)
-        for idx, gt in enumerate(gt_list):
-            loss_list.append(self.cri_pix(self.Ft_p[idx], gt))
-        loss = sum(loss_list) / len(loss_list)
+        pairs = [(self.Ft_p[idx], gt) for idx, gt in enumerate(gt_list)]
         if self.nframes == 6 and self.version == 2:
-            loss_list.append(self.cri_pix(self.Ft_p[1], self.Ft_p[7]))
-            loss_list.append(self.cri_pix(self.Ft_p[5], self.Ft_p[9]))
-            loss_list.append(self.cri_pix(self.Ft_p[2], self.Ft_p[8]))
-            loss = sum(loss_list) / len(loss_list)
+            pairs += [(self.Ft_p[1], self.Ft_p[7]), (self.Ft_p[5], self.Ft_p[9]), (self.Ft_p[2], self.Ft_p[8])]
+        loss, loss_list = multi_term_loss(self.cri_pix, pairs)
         loss_list = loss_list[:num]
         if ret == 1:
             return loss, loss_list

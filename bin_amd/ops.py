@@ -274,6 +274,55 @@ def pixel_loss_grad(kind, x, y, gloss, eps=1e-6):
     return gx
 
 
+def multi_pixel_loss(kind, pairs, eps=1e-6):
+    """All terms of bin_model.get_loss in two launches (binhip_multi_loss_fwd): `pairs` = [(x, y)] contiguous fp32 device tensors
+    of one size.  Returns (loss = sum(terms) / T as Python's sum(list) / len(list) computes it, terms [T])."""
+    xs = [p[0] for p in pairs] + [p[1] for p in pairs]
+    _need_cuda(*xs)
+    n = pairs[0][0].numel()
+    T = len(pairs)
+    if T > L.LOSS_MAX_TERMS or any(t.numel() != n or t.dtype != torch.float32 or not t.is_contiguous() for t in xs):
+        raise ValueError("multi_pixel_loss: up to %d pairs of contiguous fp32 tensors of one size" % L.LOSS_MAX_TERMS)
+    lib = L.lib()
+    dev = pairs[0][0].device
+    t = L.BinLossTerms()
+    t.n_terms = T
+    for i, (x, y) in enumerate(pairs):
+        t.x[i], t.y[i] = x.data_ptr(), y.data_ptr()
+    part = torch.empty(T * lib.binhip_charbonnier_partials(n), dtype=torch.float32, device=dev)
+    terms = torch.empty(T, dtype=torch.float32, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    with on_device(pairs[0][0]):
+        L.check(lib.binhip_multi_loss_fwd(kind, C.byref(t), n, float(eps), _ptr(part), _ptr(terms), _ptr(loss), _stream()),
+                "multi_loss_fwd")
+    return loss, terms
+
+
+def multi_pixel_loss_grad(kind, pairs, gloss, wanted, eps=1e-6):
+    """Gradients of that loss in one launch (binhip_multi_loss_bwd).  `wanted`: [(like, [(term, sign), ...])] — one entry per
+    tensor that needs a gradient, with the (at most two) terms it appears in; returns the gradient tensors in that order."""
+    n = pairs[0][0].numel()
+    t = L.BinLossTerms()
+    t.n_terms = len(pairs)
+    for i, (x, y) in enumerate(pairs):
+        t.x[i], t.y[i] = x.data_ptr(), y.data_ptr()
+    g = L.BinLossGrads()
+    g.n_out = len(wanted)
+    outs = []
+    for k, (like, where) in enumerate(wanted):
+        if not 1 <= len(where) <= 2:
+            raise ValueError("multi_pixel_loss_grad: a tensor may appear in one or two terms")
+        o = torch.empty_like(like)
+        outs.append(o)
+        g.out[k] = o.data_ptr()
+        g.term_a[k], g.sign_a[k] = where[0]
+        g.term_b[k], g.sign_b[k] = where[1] if len(where) == 2 else (-1, 0.0)
+    gl = gloss.reshape(1).contiguous().float()
+    with on_device(pairs[0][0]):
+        L.check(L.lib().binhip_multi_loss_bwd(kind, C.byref(t), n, float(eps), _ptr(gl), C.byref(g), _stream()), "multi_loss_bwd")
+    return outs
+
+
 def charbonnier(x, y, eps=1e-6):
     """mean(sqrt((x-y)^2 + eps)) (reference loss.py:137-141), forward only."""
     return pixel_loss(L.LOSS_CHARBONNIER, x, y, eps)

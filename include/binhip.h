@@ -49,8 +49,8 @@ extern "C" {
 /* Interface version = what binhip_version() of a matching library returns (100 x round + revision); a binder checks
  * `binhip_version() == BINHIP_VERSION` after dlopen.  BINHIP_ABI_EXPORTS = number of BINHIP_API entry points below
  * (tests/test_cpu_host.py keeps it equal to the declarations and to `nm -D`). */
-#define BINHIP_VERSION 400
-#define BINHIP_ABI_EXPORTS 43
+#define BINHIP_VERSION 500
+#define BINHIP_ABI_EXPORTS 45
 
 #define BINHIP_E_ARG      (-1)   /* null pointer / bad enum */
 #define BINHIP_E_SHAPE    (-2)   /* unsupported shape */
@@ -230,6 +230,32 @@ BINHIP_API int binhip_pixel_loss_fwd(int kind, const float* x, const float* y, i
                           float* partials, float* loss, void* stream);
 BINHIP_API int binhip_pixel_loss_bwd(int kind, const float* x, const float* y, int64_t numel, float eps,
                           const float* gloss, float* gx, float* gy, void* stream);
+
+/* bin_model.get_loss (bin_model.py:395-425) as TWO launches forward and ONE backward (round 5; before: one pair of launches per
+ * term, the 17-term sum / division and their autograd as ~100 scalar ATen kernels between forward and backward):
+ *   terms[t] = criterion(x[t], y[t]) over `numel` floats each (same reduction, same bits as binhip_pixel_loss_fwd),
+ *   loss     = (((terms[0] + terms[1]) + ...) + terms[T-1]) / T   in fp32, left to right = Python's sum(list) / len(list).
+ * `partials`: n_terms * binhip_charbonnier_partials() floats.  A tensor may appear in several terms (the three cycle terms
+ * pair two network outputs with each other).                                                                             */
+#define BINHIP_LOSS_MAX_TERMS 24
+typedef struct {
+    const float* x[BINHIP_LOSS_MAX_TERMS];
+    const float* y[BINHIP_LOSS_MAX_TERMS];
+    int32_t n_terms;
+} BinLossTerms;
+BINHIP_API int binhip_multi_loss_fwd(int kind, const BinLossTerms* t, int64_t numel, float eps, float* partials, float* terms,
+                          float* loss, void* stream);
+/* d loss / d tensor for up to BINHIP_LOSS_MAX_TERMS distinct tensors in one launch: out[k] = gloss / T * sum over the (at most
+ * two) terms that contain tensor k of sign * criterion'(x[term] - y[term]) (sign +1 where the tensor is the term's x, -1 where
+ * it is its y; term_b[k] = -1: one term only).                                                                           */
+typedef struct {
+    float* out[BINHIP_LOSS_MAX_TERMS];
+    int32_t term_a[BINHIP_LOSS_MAX_TERMS], term_b[BINHIP_LOSS_MAX_TERMS];
+    float sign_a[BINHIP_LOSS_MAX_TERMS], sign_b[BINHIP_LOSS_MAX_TERMS];
+    int32_t n_out;
+} BinLossGrads;
+BINHIP_API int binhip_multi_loss_bwd(int kind, const BinLossTerms* t, int64_t numel, float eps, const float* gloss,
+                          const BinLossGrads* g, void* stream);
 
 /* ---- fused tail of a residual dense block: o3 = relu(conv3x3(blk[0:192])), y = LFF(cat(blk[0:192], o3)) + blk[0:96]
  * (RDN.py:141-147 for conv #3, :162-165 for LFF + residual) in one kernel; blk = 14-chunk dense-block buffer,

@@ -301,3 +301,39 @@ def test_streaming_cache_misses_after_a_weight_or_precision_change():
         c = net(*frames, stage1_cache=cache)
         fresh16 = net(*frames)
         assert all(torch.equal(x, y) for x, y in zip(c, fresh16)) and not torch.equal(b[0], c[0])
+
+
+@pytest.mark.parametrize("kind", ["cb", "l1", "l2"])
+def test_fused_multi_term_loss_equals_the_per_term_path_bit_for_bit(kind):
+    """bin_model.get_loss as one autograd node (binhip_multi_loss_fwd / _bwd: all terms + their mean in two launches, every
+    gradient in one) against what it replaces — one _PixelLossFn per term, `sum(list) / len(list)` and autograd's accumulation
+    in torch ops: the loss, the 17 terms and all 14 + 3 gradients agree BIT FOR BIT, for the three criteria, with tensors that sit
+    in two terms (the cycle pairs) on either side."""
+    from bin_amd.models.loss import CharbonnierLoss, L1SumLoss, L2SumLoss, multi_term_loss
+    crit = {"cb": CharbonnierLoss, "l1": L1SumLoss, "l2": L2SumLoss}[kind]()
+    g = torch.Generator().manual_seed(17)
+    mk = lambda: torch.rand(2, 3, 40, 56, generator=g).cuda()
+    outs = [mk().requires_grad_(True) for _ in range(14)]
+    gts = [mk() for _ in range(14)]
+    gts[3].requires_grad_(True)                                   # a target that wants a gradient too (sign -1)
+
+    def pairs(o):
+        return [(o[i], gts[i]) for i in range(14)] + [(o[1], o[7]), (o[5], o[9]), (o[2], o[8])]
+
+    loss, terms = multi_term_loss(crit, pairs(outs))
+    assert len(terms) == 17 and loss.grad_fn is not None
+    (0.7 * loss).backward()
+    fused = [o.grad.clone() for o in outs] + [gts[3].grad.clone()]
+    for o in outs:
+        o.grad = None
+    gts[3].grad = None
+    per = [crit(x, y) for x, y in pairs(outs)]
+    ref = sum(per) / len(per)
+    (0.7 * ref).backward()
+    assert torch.equal(loss.detach(), ref.detach())
+    assert all(torch.equal(a.detach(), b.detach()) for a, b in zip(terms, per))
+    for i, (a, b) in enumerate(zip(fused, [o.grad for o in outs] + [gts[3].grad])):
+        assert torch.equal(a, b), (i, float((a - b).abs().max()))
+    # an injected (non-product) criterion takes the plain loop
+    plain, pt = multi_term_loss(lambda x, y: ((x - y) ** 2).mean(), pairs([o.detach() for o in outs]))
+    assert len(pt) == 17 and float(plain) > 0
