@@ -495,7 +495,10 @@ static int bh_dispatch_conv(const ConvKArgs& a0, int k, int cp, int nt, int e, h
         return bh_launch_final_dot2(a, nt, s);
 #endif
     // UPNet.2 in the fp32-class mode: 16-row matrix tile over tap pairs (binhip_conv_x3.hip, round 4)
-    if (e == F && k == 3 && cp == 32 && a.cout <= 3 && nt == 3 && BINHIP_FINAL_M16 && BH_VARIANT(CLS_FINAL) < 0)
+    // (its LDS-resident weight slab holds 40 taps = 4 input chunks, UPNet.2's 64 channels; a wider FINAL conv — only reachable
+    //  through the per-op ABI — takes the 32-row tile below.  Round 5: the guard was `nchunks <= 5`, and 5 chunks silently
+    //  multiplied taps 40-44 with zeros; found by tests/test_gpu_round5.py::test_final_m16_kernel_vs_float64[80-3])
+    if (e == F && k == 3 && cp == 32 && a.cout <= 3 && nt == 3 && a.nchunks <= 4 && BINHIP_FINAL_M16 && BH_VARIANT(CLS_FINAL) < 0)
         return bh_launch_final_m16(a, s);
     //                                   KS MT WM R WN KC NT NBUF EPI
     if (nt == 1) {

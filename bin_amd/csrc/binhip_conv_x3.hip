@@ -692,7 +692,7 @@ final_m16_kernel(const ConvKArgs a, const float* __restrict__ bias) {
 int bh_launch_final_m16(const ConvKArgs& ka, hipStream_t s) {
     using C = X3Cfg<3, 2, 8>;
     static std::atomic<unsigned long long> lds_set{0};
-    if (ka.nchunks > 5) return BINHIP_E_SHAPE;                   // (5 weight pieces per plane = 40 taps)
+    if (ka.nchunks * 9 > M16::WPIECES * 8) return BINHIP_E_SHAPE;   // 5 weight pieces per plane = 40 taps = 4 chunks (UPNet.2: 64 inputs)
     if (int rc = bh_set_max_lds(&final_m16_kernel, M16::LDS_BYTES, lds_set)) return rc;
     ConvKArgs a = ka;
     a.tiles_x = (a.W + 31) / 32;

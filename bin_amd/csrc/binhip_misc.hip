@@ -133,6 +133,24 @@ __global__ void frame_to_u8_kernel(const float* __restrict__ x, int Hp, int Wp, 
 
 // ---- ConvLSTM cell ------------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
+// The per-pixel gate arithmetic of the cell (RDN.py:74-92) and of its backward, ONE definition for the one-pixel and the
+// four-pixel kernels, with the multiply-adds spelled out (fmaf / __fmul_rn) so that both compile to the same roundings.
+__device__ __forceinline__ void lstm_point_fwd(float gi, float gj, float gf, float go, float cprev, float fb, float& c1, float& h1) {
+    c1 = fmaf(cprev, sigmoidf_(gf + fb), __fmul_rn(sigmoidf_(gi), tanhf(gj)));
+    h1 = __fmul_rn(tanhf(c1), sigmoidf_(go));
+}
+__device__ __forceinline__ void lstm_point_bwd(float gi, float gj, float gf, float go, float cprev, float fb, float ghv, float gcv,
+                                               float& di, float& dj, float& df, float& dob, float& dcp) {
+    const float si = sigmoidf_(gi), tj = tanhf(gj), sf = sigmoidf_(gf + fb), so = sigmoidf_(go);
+    const float c1 = fmaf(cprev, sf, __fmul_rn(si, tj));
+    const float tc = tanhf(c1);
+    const float gct = fmaf(__fmul_rn(ghv, so), fmaf(-tc, tc, 1.f), gcv);
+    di = __fmul_rn(__fmul_rn(gct, tj), __fmul_rn(si, 1.f - si));
+    dj = __fmul_rn(__fmul_rn(gct, si), fmaf(-tj, tj, 1.f));
+    df = __fmul_rn(__fmul_rn(gct, cprev), __fmul_rn(sf, 1.f - sf));
+    dob = __fmul_rn(__fmul_rn(ghv, tc), __fmul_rn(so, 1.f - so));
+    dcp = __fmul_rn(gct, sf);
+}
 
 // one thread = one pixel; 3x3x6 neighbourhood from global (L1/L2 resident), weights via scalar loads
 __global__ void __launch_bounds__(256)
@@ -172,8 +190,8 @@ convlstm_kernel(const float* __restrict__ x, const float* __restrict__ cp, const
     for (int k = 0; k < 3; ++k) {           // i = g[0:3], j = g[3:6], f = g[6:9], o = g[9:12]  (RDN.py:79)
         const long long o = ((long long)n * 3 + k) * HW + pix;
         const float cprev = cp ? cp[o] : 0.f;
-        const float c1 = cprev * sigmoidf_(g[6 + k] + fb) + sigmoidf_(g[k]) * tanhf(g[3 + k]);
-        const float h1 = tanhf(c1) * sigmoidf_(g[9 + k]);
+        float c1, h1;
+        lstm_point_fwd(g[k], g[3 + k], g[6 + k], g[9 + k], cprev, fb, c1, h1);
         if (cn) cn[o] = c1;
         hn[o] = h1;
     }
@@ -265,8 +283,7 @@ convlstm4_kernel(const float* __restrict__ x, const float* __restrict__ cp, cons
         const float cpv[4] = {cprev[k].x, cprev[k].y, cprev[k].z, cprev[k].w};
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            c1[p] = cpv[p] * sigmoidf_(g[6 + k][p] + fb) + sigmoidf_(g[k][p]) * tanhf(g[3 + k][p]);
-            h1[p] = tanhf(c1[p]) * sigmoidf_(g[9 + k][p]);
+            lstm_point_fwd(g[k][p], g[3 + k][p], g[6 + k][p], g[9 + k][p], cpv[p], fb, c1[p], h1[p]);
         }
         c1v[k] = float4{c1[0], c1[1], c1[2], c1[3]};
         h1v[k] = float4{h1[0], h1[1], h1[2], h1[3]};
@@ -315,15 +332,7 @@ convlstm4_bwd_gates_kernel(const float* __restrict__ x, const float* __restrict_
         float di[4], dj[4], df[4], dob[4], dcp[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const float si = sigmoidf_(g[k][p]), tj = tanhf(g[3 + k][p]), sf = sigmoidf_(g[6 + k][p] + fb), so = sigmoidf_(g[9 + k][p]);
-            const float c1 = cpv[p] * sf + si * tj;
-            const float tc = tanhf(c1);
-            const float gct = gc4[p] + gh4[p] * so * (1.f - tc * tc);
-            di[p] = gct * tj * si * (1.f - si);
-            dj[p] = gct * si * (1.f - tj * tj);
-            df[p] = gct * cpv[p] * sf * (1.f - sf);
-            dob[p] = gh4[p] * tc * so * (1.f - so);
-            dcp[p] = gct * sf;
+            lstm_point_bwd(g[k][p], g[3 + k][p], g[6 + k][p], g[9 + k][p], cpv[p], fb, gh4[p], gc4[p], di[p], dj[p], df[p], dob[p], dcp[p]);
         }
         *reinterpret_cast<float4*>(dgates + d0 + (long long)(k) * HW) = float4{di[0], di[1], di[2], di[3]};
         *reinterpret_cast<float4*>(dgates + d0 + (long long)(3 + k) * HW) = float4{dj[0], dj[1], dj[2], dj[3]};
@@ -620,17 +629,16 @@ convlstm_bwd_gates_kernel(const float* __restrict__ x, const float* __restrict__
     for (int k = 0; k < 3; ++k) {
         const long long o = ((long long)n * 3 + k) * HW + pix;
         const float cprev = cp ? cp[o] : 0.f;
-        const float si = sigmoidf_(g[k]), tj = tanhf(g[3 + k]), sf = sigmoidf_(g[6 + k] + fb), so = sigmoidf_(g[9 + k]);
-        const float c1 = cprev * sf + si * tj;
-        const float tc = tanhf(c1);
         const float ghv = gh ? gh[o] : 0.f;
-        const float gct = (gc ? gc[o] : 0.f) + ghv * so * (1.f - tc * tc);
+        const float gcv = gc ? gc[o] : 0.f;
+        float di, dj, df, dob, dcp;
+        lstm_point_bwd(g[k], g[3 + k], g[6 + k], g[9 + k], cprev, fb, ghv, gcv, di, dj, df, dob, dcp);
         const long long d0 = ((long long)n * 12) * HW + pix;
-        dgates[d0 + (long long)(k) * HW] = gct * tj * si * (1.f - si);
-        dgates[d0 + (long long)(3 + k) * HW] = gct * si * (1.f - tj * tj);
-        dgates[d0 + (long long)(6 + k) * HW] = gct * cprev * sf * (1.f - sf);
-        dgates[d0 + (long long)(9 + k) * HW] = ghv * tc * so * (1.f - so);
-        if (gcp) gcp[o] = gct * sf;
+        dgates[d0 + (long long)(k) * HW] = di;
+        dgates[d0 + (long long)(3 + k) * HW] = dj;
+        dgates[d0 + (long long)(6 + k) * HW] = df;
+        dgates[d0 + (long long)(9 + k) * HW] = dob;
+        if (gcp) gcp[o] = dcp;
     }
 }
 // pass 2: dx / dh_prev = conv_transpose(dgates, w)

@@ -259,7 +259,9 @@ def test_lff_backward_data_epilogue_instantiation_vs_float64():
 @pytest.mark.parametrize("cin,nimg", [(64, 2), (64, 5), (80, 3)])
 def test_final_m16_kernel_vs_float64(cin, nimg):
     """UPNet.2 of the fp32-class mode (`final_m16_kernel`: 16x16x32 MFMA with tap pairs, 3 output channels + the mean of the
-    input frames) at N = 2 on ragged tiles, with 4 and 5 input chunks (5 = its weight-slab limit) and 2 / 3 / 5 frames."""
+    input frames) at N = 2 on ragged tiles with 2 / 5 frames; and a FINAL conv with FIVE input chunks, which does not fit that
+    kernel's LDS-resident weight slab (40 taps = 4 chunks) and must take the 32-row tile — this case found the round-4 guard
+    (`nchunks <= 5`) silently dropping taps 40-44."""
     from bin_amd import _lib as L, ops
     g = torch.Generator().manual_seed(93 + cin + nimg)
     n, h, w = 2, 18, 44
