@@ -63,7 +63,10 @@ class _MultiPixelLossFn(torch.autograd.Function):
 def multi_term_loss(criterion, pairs):
     """(loss, [terms]) of `criterion` over the (x, y) `pairs`, loss = sum(terms) / len(terms): fused when `criterion` is one of this
     module's (they carry `.kind`), the plain per-term loop otherwise (an injected criterion; tensors of different sizes)."""
+    import os
     kind = getattr(criterion, "kind", None)
+    if os.environ.get("BIN_AMD_FUSED_LOSS", "1") == "0":          # diagnostics / A-B only: the per-term path it replaced
+        kind = None
     n = pairs[0][0].numel()
     fusable = (kind is not None and len(pairs) <= L.LOSS_MAX_TERMS
                and all(t.is_cuda and t.numel() == n for p in pairs for t in p))

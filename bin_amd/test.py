@@ -149,6 +149,26 @@ def main(argv=None, stats=None):
                     if (clip0, fid) not in early:
                         early[(clip0, fid)] = pool.submit(data_util.imread_u8, os.path.join(args.input_path, clip0, frames0[fid]))
 
+    # ... and so do the page-locked buffers of the pipeline (a dozen decode staging images, ten 3-image output buffers):
+    # hipHostMalloc costs 1-3 ms apiece, which the first ten windows used to pay in line
+    stage_pool, stage_lock, pinned = [], threading.Lock(), []
+
+    def preallocate():
+        if not early:
+            return
+        first = next(iter(early.values())).result()
+        if first.ndim != 3 or first.shape[2] != 3:
+            return
+        for _ in range(12):
+            buf = torch.empty(first.shape, dtype=torch.uint8, pin_memory=True)
+            with stage_lock:
+                stage_pool.append(buf)
+        for _ in range(10):
+            pinned.append(torch.empty((3,) + tuple(first.shape), dtype=torch.uint8, pin_memory=True))
+    prealloc = threading.Thread(target=preallocate, daemon=True)
+    if torch.cuda.is_available():
+        prealloc.start()
+
     model = create_model(opt)
     netG = model.netG
     netG.eval()
@@ -162,8 +182,7 @@ def main(argv=None, stats=None):
     copy_stream = torch.cuda.Stream(device=dev)
     decoded, frames_dev, stage1_cache, pending = {}, {}, {}, []
     geom = None                                        # (h, w, pads) of the current clip
-    pinned = []                                        # recycled page-locked staging buffers (allocation is slow)
-    claimed = set()
+    claimed = set()                                    # (`pinned`: recycled page-locked output buffers, pre-allocated above)
     cur_clip, timer = None, AverageMeter()
 
     # Decoded frames reach the device WITHOUT ever blocking the launching thread (round 4): a copy from pageable memory is
@@ -171,7 +190,9 @@ def main(argv=None, stats=None):
     # then idled for the ~5 ms the host needs to queue the next window (steady state 0.90 of the in-HBM rate).  Now the decoder
     # thread leaves the image in a recycled page-locked buffer and the upload runs on its own stream behind an event.
     upload_stream = torch.cuda.Stream(device=dev)
-    stage_pool, stage_lock, in_flight = [], threading.Lock(), []
+    in_flight = []
+    if prealloc.ident is not None:                     # (started)
+        prealloc.join()
 
     def decode(path, ready=None):                      # (worker thread)
         img = data_util.imread_u8(path) if ready is None else ready.result()
