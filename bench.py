@@ -461,6 +461,7 @@ def harness_bench(precision, n_frames, gpu_only_fps, io_threads=12, steady_gpu_o
                 "gpu_only_steady_state_frames_per_s": None if steady_gpu_only_fps is None else round(steady_gpu_only_fps, 3),
                 "io_overlap_frac": None if not gpu_only_fps else round(fps / gpu_only_fps, 4),
                 "windows": stats["windows"], "input_frames": n_frames, "wall_s": round(stats["wall"], 3),
+                "timeline_s": stats.get("timeline"),
                 "net_and_glue_ms_per_window": round(stats["net_s_per_window"] * 1e3, 2), "png_files_written": n_png,
                 "precision": precision, "io_threads": io_threads,
                 "note": "second of two passes over the same folder into a fresh output folder; wall time covers decode, H2D, the "

@@ -25,6 +25,7 @@ class BinConvDesc(C.Structure):
 
 
 LOSS_MAX_TERMS = 24          # BINHIP_LOSS_MAX_TERMS
+CONV_HALF_LAST_CHUNK = 1     # BinConvDesc.reserved flag of binhip_conv2d_fwd (BINHIP_CONV_HALF_LAST_CHUNK)
 
 
 class BinLossTerms(C.Structure):

@@ -392,6 +392,7 @@ int bh_prepare_conv(const BhConvCall& c, ConvKArgs* out) {
     a.y_cpg = c.y_cpg; a.y_group_stride = c.y_group_stride;
     a.y_cpg_inv = c.y_cpg > 0 ? (unsigned)(((1u << 20) + c.y_cpg - 1) / c.y_cpg) : 0u;
     if (c.y_cpg > 128 || (c.y_cpg > 0 && d.cout_pad / 16 >= 4096)) return BINHIP_E_SHAPE;
+    a.half_last = (d.reserved & BINHIP_CONV_HALF_LAST_CHUNK) ? 1 : 0;
     a.y_unshuf = c.y_unshuf;
     if (c.y_unshuf && (d.epilogue != BINHIP_EPI_PLANES || c.y_cpg > 0 || (d.H & 1) || (d.W & 1) || c.y_unshuf * 16 < d.cout))
         return BINHIP_E_SHAPE;

@@ -43,6 +43,7 @@ struct ConvKArgs {
     int y_cpg;                // output chunk grouping (<=0: one group)
     unsigned y_cpg_inv;       // ceil(2^20 / y_cpg): och / y_cpg == (och * y_cpg_inv) >> 20 for och < 4096, y_cpg <= 128 (no SALU division per slot)
     long long y_group_stride;
+    int half_last;            // the last input chunk carries 8 real channels at most (BINHIP_CONV_HALF_LAST_CHUNK): 5x5 plane-split kernel
     int y_unshuf;             // XTRA kernels only: > 0 = the output goes out through an inverse PixelShuffle(2) — full-resolution
                               // pixel (Y, X), chunk c -> plane (2 (Y & 1) + (X & 1)) * y_unshuf + c at (Y / 2, X / 2) of the half-
                               // resolution tensor (the channel order UPNet.0's permuted rows use); y_unshuf = chunks per sub-position

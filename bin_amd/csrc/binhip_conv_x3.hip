@@ -154,6 +154,55 @@ __device__ __forceinline__ void x3_compute(const char* pb, const char* wb, int a
     }
 }
 
+// The LAST chunk of a layer whose upper 8 input channels are zero padding (SFENet1, RDN.py:187/245: 24 = 16 + 8 and 36 = 2 x 16 + 4
+// channels), round 5: the K = 16 of an MFMA is spent on TWO taps of the lower channel half instead of one tap of both halves.
+// Lanes 32-63 (k = 8..15) read the patch one row down and the weights of tap (dy + 1, dx), both from channel half 0, so one
+// instruction covers taps (dy, dx) and (dy + 1, dx); the last row tap dy = KS - 1 has no partner and keeps the plain form (its
+// k = 8..15 lanes see the zero half of patch and weights).  KS * KS -> KS * (KS + 1) / 2 K-steps for that chunk: 25 -> 15.
+// Same LDS images, same weight layout — only the per-lane addresses differ.  (The row below the pair's second tap is inside the
+// patch for every dy <= KS - 2; nothing is read beyond it.)
+template <class C, int KS, int R, bool HI>
+__device__ __forceinline__ void x3_compute_pair(const char* pb, const char* wb, int n, int kg, int wave, floatx16 (&acc)[R]) {
+    static_assert(KS & 1, "odd kernels");
+    constexpr int NP = KS / 2;                                          // paired steps per tap column (+ 1 plain step)
+    const int s16 = ((n >> 3) & 1) << 4;
+    const int a_pair = n * 32 + s16 + kg * (KS * 1024);                // half 0 (slot s) of tap (dy + kg, dx)
+    const int a_plain = n * 32 + ((kg << 4) ^ s16);                    // half kg of tap (KS - 1, dx)
+    const int b_pair = ((wave * R + kg) * C::PW + n) * 16;             // channel half 0, row + kg
+    const int b_plain = (kg * (C::PH * C::PW) + wave * R * C::PW + n) * 16;
+    half8 Bp[2][R + KS - 3], Bl[2][R];
+    half8 Ah[2], Al[2];
+    auto load_b = [&](int dx, half8 (&bp)[R + KS - 3], half8 (&bl)[R]) {
+#pragma unroll
+        for (int rr = 0; rr < R + KS - 3; ++rr) bp[rr] = x3_ld8(pb + b_pair + (rr * C::PW + dx) * 16);
+#pragma unroll
+        for (int r = 0; r < R; ++r) bl[r] = x3_ld8(pb + b_plain + ((r + KS - 1) * C::PW + dx) * 16);
+    };
+    auto load_a = [&](int s, half8& h, half8& l) {                     // step s = dx * (NP + 1) + j ; j < NP: pair (2j, 2j + 1), j == NP: plain
+        const int dx = s / (NP + 1), j = s % (NP + 1);
+        const int off = (j < NP) ? ((2 * j) * KS + dx) * 1024 + a_pair : ((KS - 1) * KS + dx) * 1024 + a_plain;
+        h = x3_ld8(wb + off);
+        if constexpr (HI) l = x3_ld8(wb + C::WP * 1024 + off);
+    };
+    constexpr int NS = KS * (NP + 1);
+    load_b(0, Bp[0], Bl[0]);
+    load_a(0, Ah[0], Al[0]);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int dx = s / (NP + 1), j = s % (NP + 1);
+        if (s + 1 < NS) load_a(s + 1, Ah[(s + 1) & 1], Al[(s + 1) & 1]);
+        if (j == 0 && dx + 1 < KS) load_b(dx + 1, Bp[(dx + 1) & 1], Bl[(dx + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const half8 b = (j < NP) ? Bp[dx & 1][r + 2 * j] : Bl[dx & 1][r];
+            if constexpr (HI) acc[r] = x3_mfma(Al[s & 1], b, acc[r]);
+            acc[r] = x3_mfma(Ah[s & 1], b, acc[r]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // One output tile (TH x 32 pixels, 32 output channels of column z) from prologue DMA to epilogue stores.  Every wave of
 // the workgroup calls it with the same arguments; LDS must be free of readers on entry.
 template <int KS, int R, int WN, int EPI, bool XTRA>
@@ -215,13 +264,25 @@ __device__ __forceinline__ void x3_tile(const ConvKArgs& a, const float* __restr
         __builtin_amdgcn_sched_barrier(0);
         x3_issue_patch<C>(a, smem, c, 1, 1, wave, voff, plane_elems, plane_bytes);
         if (c + 1 < nchunks) x3_issue_weights<C, KS>(a, smem, c + 1, (c + 1) & 1, wave, lane, z);
-        x3_compute<C, KS, R, true>(smem, wb, a_lane_off, b_lane_off, acc[0]);
+        // (5x5 only: the last chunk of a 24- / 36-channel layer on tap pairs, see x3_compute_pair)
+        const bool pair = (KS == 5) && !XTRA && a.half_last && (c + 1 == nchunks);
+        if constexpr (KS == 5 && !XTRA) {
+            if (pair) x3_compute_pair<C, KS, R, true>(smem, wb, n, kg, wave, acc[0]);
+            else x3_compute<C, KS, R, true>(smem, wb, a_lane_off, b_lane_off, acc[0]);
+        } else {
+            x3_compute<C, KS, R, true>(smem, wb, a_lane_off, b_lane_off, acc[0]);
+        }
         // ---- lo sub-stage: meanwhile the next chunk's hi patch plane lands
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < nchunks) x3_issue_patch<C>(a, smem, c + 1, 0, 0, wave, voff, plane_elems, plane_bytes);
-        x3_compute<C, KS, R, false>(smem + C::PATCH_BYTES, wb, a_lane_off, b_lane_off, acc[0]);
+        if constexpr (KS == 5 && !XTRA) {
+            if (pair) x3_compute_pair<C, KS, R, false>(smem + C::PATCH_BYTES, wb, n, kg, wave, acc[0]);
+            else x3_compute<C, KS, R, false>(smem + C::PATCH_BYTES, wb, a_lane_off, b_lane_off, acc[0]);
+        } else {
+            x3_compute<C, KS, R, false>(smem + C::PATCH_BYTES, wb, a_lane_off, b_lane_off, acc[0]);
+        }
     }
     conv_epilogue<1, R, 3, EPI, XTRA>(a, bias, acc, img, ty0 + wave * R, tx0, z * 32, z == 0, n, kg, plane_elems);
 }
@@ -230,8 +291,11 @@ __device__ __forceinline__ void x3_tile(const ConvKArgs& a, const float* __restr
 // columns — same code, separate symbols, so per-kernel profiles keep the dominant dense-block conv apart from the wide layers
 // XTRA: the epilogue also reads residual / accumulator / ReLU-mask planes (the backward-data convs); `bias`: the layer's bias
 // as the kernel's own restrict parameter, for scalar loads (binhip_conv_common.h)
+// (waves per SIMD: two workgroups per CU = WN / 2 -> at most 128 VGPRs; the 5x5 forward kernel runs ONE workgroup per CU (146 KB of
+//  LDS), and with the tap-pair path of its last chunk compiled in it needs more than 128: its bound is WN / 4 = 256 VGPRs)
 template <int KS, int R, int WN, int EPI, int WIDE, bool XTRA>
-__global__ void __launch_bounds__(64 * WN) __attribute__((amdgpu_waves_per_eu(WN / 2, WN / 2)))
+__global__ void __launch_bounds__(64 * WN)
+    __attribute__((amdgpu_waves_per_eu((KS == 5 && !XTRA) ? WN / 4 : WN / 2, (KS == 5 && !XTRA) ? WN / 4 : WN / 2)))
 conv_x3_kernel(const ConvKArgs a, const float* __restrict__ bias) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // 1-D grid of tiles x output columns, column fastest: after the XCD banding the `ncol` workgroups that share one input

@@ -130,6 +130,8 @@ int binhip_rdn_forward(const BinRdnPlan* p, const float* const* inputs, float* o
         c.d.N = N; c.d.H = Hc; c.d.W = Wc; c.d.ksize = ks; c.d.cin_chunks = cin_chunks; c.d.cout = cout;
         c.d.cout_pad = cout_pad; c.d.nterms = nt; c.d.epilogue = epi; c.d.relu = relu;
         c.d.x_cpg = cpg; c.d.x_group_stride = gstride; c.d.n_images = 0; c.d.reserved = 0; c.d.status = p->status;
+        // SFENet1 on 2 / 3 input frames: 24 / 36 channels = the last chunk's upper half is zero padding (packer and relayout)
+        if (layer == 0 && ks == 5 && (12 * nin) % 16 >= 1 && (12 * nin) % 16 <= 8) c.d.reserved = BINHIP_CONV_HALF_LAST_CHUNK;
         c.x_hi = HI(x_off); c.x_lo = LO(x_off, x_size);
         c.w_hi = p->w_hi[layer]; c.w_lo = p->w_lo[layer]; c.bias = p->bias[layer];
         c.r_hi = (r_off >= 0) ? HI(r_off) : nullptr;

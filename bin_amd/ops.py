@@ -208,6 +208,10 @@ def conv2d(x, cw, relu=False, residual=None, out=None, epilogue=L.EPI_PLANES, im
     d.cout, d.cout_pad, d.nterms, d.epilogue, d.relu = cw.cout, cw.cout_pad, cw.nterms, epilogue, int(relu)
     d.x_cpg, d.x_group_stride = x_cpg, x_group_stride
     d.n_images = len(images) if images else 0
+    # BINHIP_CONV_HALF_LAST_CHUNK: a 5x5 layer whose last chunk holds <= 8 real channels (x from nchw_to_planes / pack_inputs and
+    # the relayouted weights are zero there) may spend that chunk's K on tap pairs
+    if cw.ks == 5 and 1 <= cw.cin % 16 <= 8 and d.cin_chunks == cw.cin_chunks:
+        d.reserved = L.CONV_HALF_LAST_CHUNK
     dev = x.hi.device
     d.status = status_word(dev).data_ptr()
     y_f32, arr = None, None

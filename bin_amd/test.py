@@ -326,12 +326,17 @@ def main(argv=None, stats=None):
             if len(group) >= args.batch:
                 flush()
         flush()
+        t_loop = time.time()
+        torch.cuda.current_stream(dev).synchronize()
+        t_gpu = time.time()
         for jobs, _ in pending:
             for job in jobs:
                 job.result()
     torch.cuda.synchronize()
     ops.check_status(dev)                 # a frame that left the fp16 storage range is an error, not a result
     wall = time.time() - t_all
+    timeline = {"first_window_queued_s": round(stamps[0] - t_all, 4) if stamps else None,
+                "all_windows_queued_s": round(t_loop - t_all, 4), "gpu_done_s": round(t_gpu - t_all, 4), "files_done_s": round(wall, 4)}
     pool.shutdown()
     if args.manifest:
         with open(os.path.join(result_root, f"written.rank{rank}.txt"), "w") as f:
@@ -358,7 +363,7 @@ def main(argv=None, stats=None):
         log.info("windows: %d  wall: %.2f s  -> %.2f interpolated frames/s (IO included); net+glue per window %.4f s",
                  n_win, wall, n_win / max(wall, 1e-9), timer.avg)
         if stats is not None:
-            stats.update(windows=n_win, wall=wall, net_s_per_window=timer.avg, stamps=[t - t_all for t in stamps])
+            stats.update(windows=n_win, wall=wall, net_s_per_window=timer.avg, stamps=[t - t_all for t in stamps], timeline=timeline)
     return 0
 
 

@@ -98,9 +98,14 @@ typedef struct BinConvDesc {
                               /*   plane (2 (Y & 1) + (X & 1)) * y_unshuf + c at (Y / 2, X / 2) of a tensor  */
                               /*   of 4 * y_unshuf planes at H/2 x W/2 — what binhip_unshuffle_planes makes  */
                               /*   of the plain result (H, W even, y_cpg = 0, 16 * y_unshuf >= cout).        */
-                              /*   0 everywhere else.                                                        */
+                              /* binhip_conv2d_fwd: BINHIP_CONV_HALF_LAST_CHUNK = the caller guarantees that     */
+                              /*   channels 8-15 of the LAST input chunk are zero in x and in the weights (cin %   */
+                              /*   16 in 1..8: SFENet1's 24 / 36 inputs) — the 5x5 fp32-class kernel then spends  */
+                              /*   that chunk's K on tap pairs; other kernels ignore it.  0 everywhere else.       */
     void*   status;           /* device uint32 status word (BINHIP_STATUS_*), OR-ed into; or NULL */
 } BinConvDesc;
+
+#define BINHIP_CONV_HALF_LAST_CHUNK 1
 
 /* Rows per weight block for a (ksize, cout_pad, nterms) configuration (relayout needs it). */
 BINHIP_API int binhip_conv_cout_block(int ksize, int cout_pad, int nterms);

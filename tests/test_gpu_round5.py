@@ -339,3 +339,29 @@ def test_fused_multi_term_loss_equals_the_per_term_path_bit_for_bit(kind):
     # an injected (non-product) criterion takes the plain loop
     plain, pt = multi_term_loss(lambda x, y: ((x - y) ** 2).mean(), pairs([o.detach() for o in outs]))
     assert len(pt) == 17 and float(plain) > 0
+
+
+@pytest.mark.parametrize("cin", [24, 36, 60])
+def test_sfenet1_tap_pair_path_vs_float64_and_the_plain_path(cin):
+    """SFENet1 (RDN.py:187/245/299: 5x5, 24 / 36 / 60 -> 96).  With 24 or 36 inputs the last 16-channel chunk is half empty and
+    the fp32-class kernel spends its K on tap PAIRS (`BINHIP_CONV_HALF_LAST_CHUNK`, x3_compute_pair: 25 -> 15 K-steps for that
+    chunk); 60 inputs keep the plain form.  Against fp64, and against the plain path on the same planes (the same weights declared
+    with their channels padded to a whole chunk, which switches the flag off): N = 2, ragged tiles, both at 2e-6."""
+    from bin_amd import ops
+    g = torch.Generator().manual_seed(300 + cin)
+    n, h, w = 2, 18, 44
+    wt = ((torch.rand(96, cin, 5, 5, generator=g) - 0.5) / 12).cuda()
+    b = (torch.rand(96, generator=g) - 0.5).cuda()
+    x = (torch.rand(n, cin, h, w, generator=g) - 0.3).cuda()
+    xp = _planes(x)
+    got = ops.planes_to_nchw(ops.conv2d(xp, ops.ConvWeights(wt, b, nterms=3)), 96).double()
+    xq = ops.planes_to_nchw(xp, cin).double()
+    ref = torch.nn.functional.conv2d(xq, wt.double(), b.double(), padding=2)
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 2e-6 * scale
+    pad = (-cin) % 16
+    wpad = torch.cat((wt, torch.zeros(96, pad, 5, 5, device="cuda")), 1) if pad else wt
+    plain = ops.planes_to_nchw(ops.conv2d(xp, ops.ConvWeights(wpad, b, nterms=3)), 96).double()
+    assert float((plain - ref).abs().max()) <= 2e-6 * scale and float((plain - got).abs().max()) <= 2e-6 * scale
+    if 1 <= cin % 16 <= 8:
+        assert not torch.equal(plain, got)          # (different summation order: the pair path really ran)
