@@ -365,6 +365,9 @@ int bh_launch_final_m16(const ConvKArgs& a, hipStream_t s);                     
 #ifndef BINHIP_FINAL_M16
 #define BINHIP_FINAL_M16 1    // 0 (side builds): UPNet.2 of the fp32-class mode on the 32-row tile of conv_x3_kernel (rounds 2-3)
 #endif
+#ifndef BINHIP_K5_PAIR
+#define BINHIP_K5_PAIR 1      // 0 (side builds): ignore BINHIP_CONV_HALF_LAST_CHUNK (SFENet1's last chunk on the plain 25-tap loop)
+#endif
 #ifndef BINHIP_K5_X3
 #define BINHIP_K5_X3 1        // 0 (side builds): the 5x5 layers of the fp32-class mode on the generic single-buffered kernel (rounds 1-3)
 #endif
@@ -392,7 +395,7 @@ int bh_prepare_conv(const BhConvCall& c, ConvKArgs* out) {
     a.y_cpg = c.y_cpg; a.y_group_stride = c.y_group_stride;
     a.y_cpg_inv = c.y_cpg > 0 ? (unsigned)(((1u << 20) + c.y_cpg - 1) / c.y_cpg) : 0u;
     if (c.y_cpg > 128 || (c.y_cpg > 0 && d.cout_pad / 16 >= 4096)) return BINHIP_E_SHAPE;
-    a.half_last = (d.reserved & BINHIP_CONV_HALF_LAST_CHUNK) ? 1 : 0;
+    a.half_last = ((d.reserved & BINHIP_CONV_HALF_LAST_CHUNK) && BINHIP_K5_PAIR) ? 1 : 0;
     a.y_unshuf = c.y_unshuf;
     if (c.y_unshuf && (d.epilogue != BINHIP_EPI_PLANES || c.y_cpg > 0 || (d.H & 1) || (d.W & 1) || c.y_unshuf * 16 < d.cout))
         return BINHIP_E_SHAPE;
