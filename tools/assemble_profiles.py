@@ -1,6 +1,6 @@
 """Build the committed profile summaries of a round from what a `tools/gpu.sh` profile run left under gpurun_out/.
 
-    gpurun --timeout 3000 -- bash tools/gpu.sh "tag r4p" \
+    gpurun --timeout 3000 -- bash tools/gpu.sh "tag r5p" \
         "kt x3 --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-power" \
         "kt f16 --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-power --precision f16" \
         "env BIN_AMD_WGRAD_STREAM=0" "kt train --mode train --batch 8 --steps 2 --warmup 1 --no-power" \
@@ -8,7 +8,7 @@
         "traffic f16x3 --steps 1 --warmup 1 --no-cpu-baseline --no-extras --no-power --calib" \
         "traffic f16 --steps 1 --warmup 1 --no-cpu-baseline --no-extras --no-power --calib --precision f16" \
         "sq rdb 3 160" "sq tail 3 192" "sq wgrad 3 160" "bench" "bench --mode train"
-    python tools/assemble_profiles.py --tag r4p --round 4
+    python tools/assemble_profiles.py --tag r5p --round 5
 
 Writes profiles/rNN_kernel_stats_720p.md, rNN_train_kernel_stats.md, rNN_pmc_traffic.md/.json, rNN_pmc_sq.md, rNN_bench_f16x3.json,
 rNN_bench_train.json.  Every number in the prose is computed here from the run's own files; nothing is typed in by hand.
@@ -29,8 +29,8 @@ WG3 = "wgrad3x3_xrow_kernel<3>"
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tag", default="r4p")
-    ap.add_argument("--round", type=int, default=4)
+    ap.add_argument("--tag", default="r5p")
+    ap.add_argument("--round", type=int, default=5)
     a = ap.parse_args()
     T, R = a.tag, f"r{a.round:02d}"
 
@@ -54,6 +54,12 @@ def main():
         v = (d or {}).get(k)
         return v.get("mean") if isinstance(v, dict) else None
 
+    def xcd(d):
+        return ((d or {}).get("xcd_clock_mhz") or {}).get("mean")
+
+    def xcd_z(pb_):
+        return ((((pb_ or {}).get("other_domains") or {}).get("xcd_clock_mhz") or {}).get("zero") or {}).get("mean")
+
     sx, sf, st = read("stats_x3.md"), read("stats_f16.md"), read("stats_train.md")
     bp = jline("kt_x3.log")                      # the bench line printed INSIDE the profiled run
     b, bt = jline("bench_1.json"), jline("bench_2.json")
@@ -75,15 +81,17 @@ holds 8 forwards (1 warm-up + 3 timed + 1 + 3 of the serial roofline leg); per f
 fused tails, 34 wide 3x3 layers, 17 each of UPNet.0, UPNet.2, GFF.0, SFENet1.  bench.py's line in the same (profiled) run: {bp['value']} frames/s,
 {bp['ms_per_step']} ms / window, live HIP-event average of the dominant kernel {bp['roofline']['avg_kernel_us']} us.  Un-profiled on the same box
 (`{R}_bench_f16x3.json`): **{b['value']} frames/s, {b['ms_per_step']} ms / window**, dominant kernel {roof['avg_kernel_us']} us by events,
-{mean(b.get('power'), 'clock_mhz')} MHz at {mean(b.get('power'), 'power_w')} W (sampled in a pass of its own right after the timed region); the same forwards on
-ALL-ZERO operands: {pb.get('ms_zero')} ms at {(pb.get('clock_mhz') or {}).get('zero')} MHz / {(pb.get('power_w') or {}).get('zero')} W -> `power_bound.ratio` {pb.get('ratio')}
-against a clock ratio of {pb.get('clock_ratio')}.
+{xcd(b.get('power'))} MHz (per-XCD mean; amdsmi's GFX clk = the fastest XCD: {mean(b.get('power'), 'clock_mhz')}) at {(b.get('power') or {}).get('power_from_energy_w')} W by the energy
+counter ({mean(b.get('power'), 'power_w')} W point-sampled; a pass of its own right after the timed region); the same forwards on ALL-ZERO operands: {pb.get('ms_zero')} ms
+at {xcd_z(pb)} MHz -> time ratio {pb.get('ratio')} against a clock ratio of {pb.get('clock_ratio_used')}, cycle ratio {pb.get('cycle_ratio')}.
+`power_bound.reading`: "{pb.get('reading')}"
 
 Dominant kernel: **{avg:.2f} us** average over {n} launches -> {gflop / 3:.1f} GFLOP x 3 products / {avg:.2f} us = {gflop / avg:.3f} PFLOP/s =
 **{gflop / avg / 2.5:.3f} of the 2.5 PFLOP/s dense fp16 peak** (`roofline.bound` = "{roof['bound']}": {roof['arithmetic_intensity_flop_per_byte']} FLOP/B on a ridge of
 {roof['ridge_flop_per_byte']} for three products); by bytes, {ab / 1e6:.1f} MB algorithmic (4 B per element) / {avg:.2f} us = {ab / avg / 1e6:.2f} TB/s =
 {ab / avg / 1e6 / 8:.3f} of the 8 TB/s HBM peak; PMC traffic {tr / 1e6:.1f} MB per launch (`{R}_pmc_traffic.md`) = {tr / ab:.2f} x algorithmic.  The fused
-dense-block tail (`{TAIL_X3}`, round 4: residual as a VALU add, o3 through registers): {avgt:.2f} us over {nt_} launches.
+dense-block tail (`{TAIL_X3}`): {avgt:.2f} us over {nt_} launches.  SFENet1 (`conv_x3_kernel<5, 2, 8, 0, 1, false>`; round 5: the half-empty last
+chunk of the 24- / 36-channel calls on tap pairs): {row(sx, 'conv_x3_kernel<5, 2, 8, 0, 1, false>')[2]:.1f} us (round 4: 155.2).
 
 {sx.strip()}
 
@@ -102,9 +110,9 @@ UPNet.2 runs as `final_dot2_kernel<1>` here.
 
 `BIN_AMD_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --mode train --batch 8 --steps 2 --warmup 1 --no-power`
 (the side stream is off so that kernel durations do not include each other; written by `tools/assemble_profiles.py`).  Un-profiled on the
-same box (`{R}_bench_train.json`): **{bt['ms_per_step']} ms / step = {bt['value']} samples/s**, {mean(bt.get('power'), 'power_w')} W at
-{mean(bt.get('power'), 'clock_mhz')} MHz; the same steps on all-zero operands: {tpb.get('ms_zero')} ms at {(tpb.get('clock_mhz') or {}).get('zero')} MHz /
-{(tpb.get('power_w') or {}).get('zero')} W (`power_bound.ratio` {tpb.get('ratio')}, clock ratio {tpb.get('clock_ratio')}).
+same box (`{R}_bench_train.json`): **{bt['ms_per_step']} ms / step = {bt['value']} samples/s**, {(bt.get('power') or {}).get('power_from_energy_w')} W (energy counter) at
+{xcd(bt.get('power'))} MHz (per-XCD mean); the same steps on all-zero operands: {tpb.get('ms_zero')} ms at {xcd_z(tpb)} MHz (time ratio {tpb.get('ratio')},
+clock ratio {tpb.get('clock_ratio_used')}, cycle ratio {tpb.get('cycle_ratio')}).  `power_bound.reading`: "{tpb.get('reading')}"
 
 The 3x3 weight gradient (`{WG3}`): {avgw:.1f} us average over the {nw} launches of this trace (all batch sizes of the four-call
 schedule); bench.py's own event-timed average of the 192 dense-block launches per step, side stream off: {dk['avg_kernel_us']} us
