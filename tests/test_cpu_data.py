@@ -457,3 +457,30 @@ def test_video_base_model_training_step_matches_the_reference(tmp_path, case):
     assert float(m.fake_H.double().mean()) == pytest.approx(float(g[f"{case}/test_mean"]), abs=1e-6)
     if f"{case}/test" in g.files:
         assert np.abs(m.fake_H.numpy() - g[f"{case}/test"]).max() <= 1e-5
+
+
+def test_striped_png_writer_decodes_to_the_same_pixels(tmp_path):
+    """util.png_bytes_striped (the folder runner's PNG writer since round 5: DEFLATE in independent bands stitched into one zlib
+    stream, 'Up' row filter): a standard PNG — Pillow decodes it to exactly the pixels handed in, for any band count, with and
+    without a pool, on ragged sizes; and `imread_u8` reads the written file back."""
+    import io
+    from concurrent.futures import ThreadPoolExecutor
+    from PIL import Image
+    from bin_amd.data import util as data_util
+    from bin_amd.utils import util
+    g = np.random.Generator(np.random.PCG64(5))
+    pool = ThreadPoolExecutor(3)
+    for shape in ((1, 1, 3), (5, 7, 3), (64, 96, 3), (33, 130, 3)):
+        img = g.integers(0, 256, shape, dtype=np.uint8)
+        smooth = (np.add.outer(np.arange(shape[0]), np.arange(shape[1]))[:, :, None] * np.array([1, 2, 3]) % 256).astype(np.uint8)
+        for a in (img, smooth):
+            for strips, p in ((1, None), (4, None), (4, pool), (1000, pool)):
+                b = util.png_bytes_striped(a, p, strips)
+                back = np.asarray(Image.open(io.BytesIO(b)).convert("RGB"))[:, :, ::-1]
+                assert np.array_equal(back, a), (shape, strips)
+    path = str(tmp_path / "x.png")
+    util.save_png_striped(img, path, pool, 4)
+    assert np.array_equal(data_util.imread_u8(path), img)
+    with pytest.raises(ValueError):
+        util.png_bytes_striped(np.zeros((4, 4), dtype=np.uint8))
+    pool.shutdown()
