@@ -188,9 +188,10 @@ def png_bytes_striped(img_bgr, pool=None, strips=4, level=1):
     one band's deflate instead of a whole image's (bin_amd/test.py)."""
     import struct
     import zlib
-    a = np.ascontiguousarray(np.asarray(img_bgr)[:, :, ::-1])                  # RGB, HWC
+    a = np.asarray(img_bgr)
     if a.ndim != 3 or a.shape[2] != 3 or a.dtype != np.uint8:
         raise ValueError("png_bytes_striped: HWC uint8 image with 3 channels")
+    a = np.ascontiguousarray(a[:, :, ::-1])                                    # RGB, HWC
     h, w, _ = a.shape
     rows = a.reshape(h, w * 3)
     filt = np.empty((h, 1 + w * 3), dtype=np.uint8)
