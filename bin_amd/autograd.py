@@ -11,7 +11,8 @@ Training precision defaults to "f16x3" (fp32-class gradients, ~5e-6 relative vs 
 Training in "f16" (single fp16 product in forward AND backward) is NOT a supported mode: its forward's ~1e-3 activation error
 flips ReLU masks, and individual parameter gradients come out 1-25 % off (tests/test_gpu_backward.py only checks it to
 2.5e-1).  Since round 4 it is GATED: a differentiable call of an RDN whose precision resolves to "f16" raises unless the
-module carries `allow_f16_training = True` (diagnostics / that test).  The supported speed/accuracy trade is
+module carries `allow_f16_training = True` (diagnostics / that test) — or none of its parameters requires a gradient (round 5:
+input-gradient-only calls warn once instead).  The supported speed/accuracy trade is
 `backward_precision = "f16"` (a per-network attribute, bench.py's "mixed") behind the f16x3 forward: exact loss and masks,
 ~2e-3 relative gradient error.
 """
@@ -63,6 +64,16 @@ def train_precision(module):
     from .models.archs.RDN import PRECISIONS
     p = module.precision or os.environ.get("BIN_AMD_TRAIN_PRECISION", "f16x3")
     if PRECISIONS[p] == 1 and not getattr(module, "allow_f16_training", False):
+        if not any(q.requires_grad for q in module.parameters()):
+            # input-gradient-only use (saliency maps, adversarial examples) with frozen parameters: nothing is being TRAINED; the
+            # input gradients carry the single-product mode's few-percent noise — say so once per module, do not refuse (advisor r04)
+            if not getattr(module, "_warned_f16_input_grads", False):
+                import warnings
+                warnings.warn("bin_amd: differentiating through an RDN in precision 'f16' with frozen parameters: input gradients "
+                              "are computed with single fp16 products (a few per cent of noise); use 'f16x3' for fp32-class gradients",
+                              stacklevel=3)
+                module._warned_f16_input_grads = True
+            return PRECISIONS[p]
         raise RuntimeError(
             "bin_amd: training with precision 'f16' (one fp16 product in forward and backward) is not a supported mode — its "
             "parameter gradients are only verified to 25 %.  Train in 'f16x3' (the default; set network_G.precision: f16x3 or "

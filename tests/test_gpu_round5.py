@@ -365,3 +365,27 @@ def test_sfenet1_tap_pair_path_vs_float64_and_the_plain_path(cin):
     assert float((plain - ref).abs().max()) <= 2e-6 * scale and float((plain - got).abs().max()) <= 2e-6 * scale
     if 1 <= cin % 16 <= 8:
         assert not torch.equal(plain, got)          # (different summation order: the pair path really ran)
+
+
+def test_f16_gate_lets_input_gradient_only_calls_through_with_a_warning():
+    """advisor r04: the f16 training gate also refused saliency-style uses (frozen parameters, gradient w.r.t. the input).  Now: a
+    differentiable f16 call raises only when a parameter of the sub-network requires a gradient; with all of them frozen it warns
+    once and runs."""
+    import warnings
+    from bin_amd.models.archs.RDN import RDN_residual_interp_2_input
+    net = RDN_residual_interp_2_input(G0=96, D=12, C=4, G=32).cuda()
+    net.precision = "f16"
+    a = torch.rand(1, 3, 32, 48, device="cuda", requires_grad=True)
+    b = torch.rand(1, 3, 32, 48, device="cuda")
+    with pytest.raises(RuntimeError, match="not a supported mode"):
+        net(a, b)
+    for p in net.parameters():
+        p.requires_grad_(False)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        y = net(a, b)
+        y.sum().backward()
+        net(a, b).sum().backward()                       # second call: no second warning
+    assert sum("frozen parameters" in str(x.message) for x in w) == 1
+    assert a.grad is not None and torch.isfinite(a.grad).all() and float(a.grad.abs().max()) > 0
+    assert all(p.grad is None for p in net.parameters())
