@@ -640,6 +640,9 @@ def kernel_roofline(prec, kern_ms, kern_n, hp, wp, ms, reuse_schedule):
     traffic, traffic_src = pmc_traffic(prec)
     hbm = {"achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}
     mfma = {"achieved": round(mf, 1), "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(mf / MFMA_PEAK_TF, 4),
+            "algorithmic": {"achieved": round(mf / PRODUCTS[prec], 1), "frac": round(mf / PRODUCTS[prec] / MFMA_PEAK_TF, 4),
+                            "note": "the conv's own FLOPs (one product per multiply-add) against the same peak: what the emulation of "
+                                    "22-bit significands with fp16 products costs is the factor between the two fractions"},
             "note": f"executed MFMA FLOPs = {PRODUCTS[prec]} x the conv's algorithmic FLOPs; peak = nominal dense fp16 "
                     "at 2.4 GHz — scale by power.clock_mhz / 2400 for the peak at the clock this run held",
             "reference_sustained_at_power_cap": {
