@@ -696,7 +696,10 @@ convlstm_bwd_weight_kernel(const float* __restrict__ dgates, const float* __rest
         const int yy = y0 + r, xx = x0 + c;
         sd[o][r][c] = (yy < H && xx < W) ? dgates[((long long)n * 12 + o) * HW + (long long)yy * W + xx] : 0.f;
     }
-    for (int i = threadIdx.x; i < 6 * (CL_TH + 2) * (CL_TW + 2); i += 256) {
+    // (no previous state — every cell of bin_stage4's two-window schedule, RDN.py:57-68 — means the recurrent half of the gates
+    //  conv saw zeros: its 324 weight gradients are exactly zero and neither their inputs nor their sums are formed; round 5)
+    const int nci = hp ? 6 : 3;
+    for (int i = threadIdx.x; i < nci * (CL_TH + 2) * (CL_TW + 2); i += 256) {
         const int ci = i / ((CL_TH + 2) * (CL_TW + 2)), r = (i / (CL_TW + 2)) % (CL_TH + 2), c = i % (CL_TW + 2);
         const int yy = y0 + r - 1, xx = x0 + c - 1;
         float v = 0.f;
@@ -711,8 +714,9 @@ convlstm_bwd_weight_kernel(const float* __restrict__ dgates, const float* __rest
         float acc = 0.f;
         if (k < 648) {
             const int o = k / 54, ci = (k / 9) % 6, dy = (k % 9) / 3, dx = k % 3;
-            for (int r = 0; r < CL_TH; ++r)
-                for (int c = 0; c < CL_TW; ++c) acc = fmaf(sd[o][r][c], sx[ci][r + dy][c + dx], acc);
+            if (ci < nci)
+                for (int r = 0; r < CL_TH; ++r)
+                    for (int c = 0; c < CL_TW; ++c) acc = fmaf(sd[o][r][c], sx[ci][r + dy][c + dx], acc);
         } else {
             const int o = k - 648;
             for (int r = 0; r < CL_TH; ++r)
