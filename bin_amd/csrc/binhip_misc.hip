@@ -106,55 +106,6 @@ __global__ void pack_inputs_kernel(PackArgs a, _Float16* __restrict__ y_hi, _Flo
     if (sat != 0 && flags) atomicOr(flags, BINHIP_FLAG_SATURATED);
 }
 
-// The same, two output pixels per thread (round 5; full-resolution W % 4 == 0 and 16-byte aligned frames, else the kernel above):
-// a thread owns channel half `s` of chunk `ch` at the half-resolution pixel pair (y, 2 xp), (y, 2 xp + 1).  Its 8 channels are
-// the 2 x 2 sub-positions of TWO colour planes, i.e. full-resolution rows 2y, 2y + 1, columns 4 xp .. 4 xp + 3 of each: four
-// 16-byte loads (a wave's lanes walk xp: 1 KiB contiguous per instruction) instead of sixteen 4-byte ones.
-__global__ void __launch_bounds__(256)
-pack_inputs2_kernel(PackArgs a, _Float16* __restrict__ y_hi, _Float16* __restrict__ y_lo, unsigned* __restrict__ flags) {
-    const int h = a.H / 2, w = a.W / 2, w2 = w / 2;
-    const int C = 12 * a.nimg;
-    const int nch = (C + 15) / 16;
-    const long long total = (long long)nch * a.N * h * w2 * 2;
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    long long u = t;
-    const int xp = (int)(u % w2); u /= w2;
-    const int s = (int)(u & 1); u >>= 1;
-    const int y = (int)(u % h); u /= h;
-    const int n = (int)(u % a.N);
-    const int ch = (int)(u / a.N);
-    float v[2][8];                                             // [pixel of the pair][channel e]
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {                              // the thread's two colour planes: cc = (ch * 16 + s * 8) / 4 + q
-        const int cc = ch * 4 + s * 2 + q;
-        float4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
-        if (4 * cc < C) {
-            const int im = cc / 3, rgb = cc - im * 3;
-            const float* p = a.img[im] + (((long long)n * 3 + rgb) * a.H + 2 * y) * a.W + 4 * xp;
-            r0 = *reinterpret_cast<const float4*>(p);
-            r1 = *reinterpret_cast<const float4*>(p + a.W);
-        }
-        // channel e = 4 q + 2 i + j  <-  row 2y + i, column 2x + j   (RDN.py:128-132)
-        v[0][4 * q + 0] = r0.x; v[0][4 * q + 1] = r0.y; v[0][4 * q + 2] = r1.x; v[0][4 * q + 3] = r1.y;
-        v[1][4 * q + 0] = r0.z; v[1][4 * q + 1] = r0.w; v[1][4 * q + 2] = r1.z; v[1][4 * q + 3] = r1.w;
-    }
-    unsigned sat = 0;
-#pragma unroll
-    for (int px = 0; px < 2; ++px) {
-        half8 hv, lv;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            hv[e] = split_hi(v[px][e], sat);
-            lv[e] = split_lo(v[px][e], hv[e]);
-        }
-        const long long o = (((((long long)ch * a.N + n) * h + y) * w + 2 * xp + px) * 2 + s) * 8;
-        *reinterpret_cast<half8*>(y_hi + o) = hv;
-        if (y_lo) *reinterpret_cast<half8*>(y_lo + o) = lv;
-    }
-    if (sat != 0 && flags) atomicOr(flags, BINHIP_FLAG_SATURATED);
-}
-
 // ---- harness glue: the per-frame host work of test.py moved onto the device -----------------
 // u8 HWC BGR image -> fp32 CHW RGB in [0,1] (read_image, test.py:44-56) + ReplicationPad2d (test.py:348-371)
 __global__ void u8_to_frame_kernel(const unsigned char* __restrict__ img, int H, int W, int pl, int pt, int Hp, int Wp,
@@ -855,14 +806,8 @@ int binhip_pack_inputs(const float* const* images, int n_images, int N, int H, i
     for (int i = 0; i < n_images; ++i) if (!images[i]) return BINHIP_E_ARG;
     a.nimg = n_images; a.N = N; a.H = H; a.W = W;
     const long long total = (long long)bh_chunks(12 * n_images) * N * (H / 2) * (W / 2) * 2;
-    uintptr_t align = 0;
-    for (int i = 0; i < n_images; ++i) align |= (uintptr_t)images[i];
-    if ((W & 3) == 0 && (align & 15) == 0)
-        hipLaunchKernelGGL(pack_inputs2_kernel, dim3((unsigned)((total / 2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                           a, (_Float16*)y_hi, (_Float16*)y_lo, (unsigned*)status);
-    else
-        hipLaunchKernelGGL(pack_inputs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                           a, (_Float16*)y_hi, (_Float16*)y_lo, (unsigned*)status);
+    hipLaunchKernelGGL(pack_inputs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       a, (_Float16*)y_hi, (_Float16*)y_lo, (unsigned*)status);
     BH_CHECK_LAUNCH();
     return 0;
 }

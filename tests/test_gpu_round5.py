@@ -389,22 +389,3 @@ def test_f16_gate_lets_input_gradient_only_calls_through_with_a_warning():
     assert sum("frozen parameters" in str(x.message) for x in w) == 1
     assert a.grad is not None and torch.isfinite(a.grad).all() and float(a.grad.abs().max()) > 0
     assert all(p.grad is None for p in net.parameters())
-
-
-@pytest.mark.parametrize("nimg,shape", [(2, (2, 36, 40)), (3, (1, 18, 44)), (5, (1, 64, 96))])
-def test_pack_inputs_two_pixel_kernel_equals_the_one_pixel_kernel(nimg, shape):
-    """binhip_pack_inputs (pixel_reshuffle(cat(frames), 2) into chunk planes, RDN.py:107-132) takes a two-pixels-per-thread kernel
-    with 16-byte loads when W % 4 == 0 and the frames are 16-byte aligned (round 5), the one-pixel kernel otherwise: same planes,
-    bit for bit (forced by mis-aligning the frames by one float), and both equal torch's pixel_unshuffle."""
-    from bin_amd import ops
-    n, h, w = shape
-    g = torch.Generator().manual_seed(nimg * 100 + h)
-    imgs = [(torch.rand(n, 3, h, w, generator=g) * 3 - 1).cuda() for _ in range(nimg)]
-    fast = ops.pack_inputs(imgs, 3)
-    slow = ops.pack_inputs([_off1(t) for t in imgs], 3)
-    assert torch.equal(fast.hi, slow.hi) and torch.equal(fast.lo, slow.lo)
-    ref = torch.nn.functional.pixel_unshuffle(torch.cat(imgs, 1), 2)
-    got = ops.planes_to_nchw(fast, 12 * nimg)
-    assert float((got - ref).abs().max()) <= 2e-6
-    if (12 * nimg) % 16:                                            # padded channels of the last chunk are zeros
-        assert float(fast.hi[-1, ..., (12 * nimg) % 16:].abs().max()) == 0.0
