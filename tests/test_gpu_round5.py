@@ -124,8 +124,10 @@ def test_bench_power_bound_reading_is_computed_from_the_numbers_beside_it():
     assert pb["cycles_zero_M"] == pytest.approx(pb["ms_zero"] * fz * 1e-3, rel=1e-3)
     assert pb["cycle_ratio"] == pytest.approx(pb["cycles_data_M"] / pb["cycles_zero_M"], rel=1e-3)
     assert pb["cycle_ratio"] == pytest.approx(pb["ratio"] / pb["clock_ratio_used"], rel=2e-3)
-    if x:                          # amdsmi's GFX clk is the fastest XCD: never below the per-XCD mean
-        assert pb["clock_mhz"]["data"] >= x["data"]["mean"] - 1.0 and x["data"]["slowest_xcd_mean"] <= x["data"]["mean"]
+    if x:                          # amdsmi's GFX clk lies within the XCDs' range (it tracks the fastest one; the two are read by
+        xd = x["data"]             # separate calls a moment apart, so only the range is asserted — a box whose XCDs run level
+        assert xd["slowest_xcd_mean"] <= xd["mean"] <= xd["fastest_xcd_mean"]          # put clk 0.25 % under the mean once)
+        assert 0.98 * xd["slowest_xcd_mean"] <= pb["clock_mhz"]["data"] <= 1.02 * xd["fastest_xcd_mean"]
     if kind == "not at the cap":
         assert pb["at_cap"] is False
     else:
