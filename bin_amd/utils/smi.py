@@ -308,7 +308,16 @@ class Sampler:
         if xs:
             out["xcd_clock_mhz"] = {"xcds": len(xs[0]), "mean": round(sum(sum(x) / len(x) for x in xs) / len(xs), 1),
                                     "slowest_xcd_mean": round(sum(min(x) for x in xs) / len(xs), 1),
-                                    "fastest_xcd_mean": round(sum(max(x) for x in xs) / len(xs), 1)}
+                                    "fastest_xcd_mean": round(sum(max(x) for x in xs) / len(xs), 1),
+                                    "per_xcd_mean": [round(sum(x[i] for x in xs) / len(xs), 1) for i in range(len(xs[0]))]}
+            # which XCD is amdsmi's single GFX `clk`?  (two calls a moment apart: nearest XCD per sample, counted)
+            near = {}
+            for s_ in S:
+                if s_.get("clock") and s_.get("xcd_clocks"):
+                    i = min(range(len(s_["xcd_clocks"])), key=lambda k: abs(s_["xcd_clocks"][k] - s_["clock"]))
+                    near[i] = near.get(i, 0) + 1
+            if near:
+                out["xcd_clock_mhz"]["gfx_clk_nearest_xcd_counts"] = {str(k): v for k, v in sorted(near.items())}
         out["limiter"] = self._limiter()
         if self._e0 and self._e1 and self._t1 and self._t1 > self._t0:
             joules = (self._e1[0] - self._e0[0]) * self._e1[1]
