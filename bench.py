@@ -270,15 +270,15 @@ def power_bound_reading(ms, ms_zero, power, zero):
     else:
         at_cap, how = None, "no limiter data and no power samples"
     out["at_cap"], out["at_cap_rule"] = at_cap, how
-    # Which clock?  amdsmi's GFX `clk` is the FASTEST XCD's clock (measured round 5: it equals fastest_xcd_mean to the digit); under
-    # the package limit the eight XCDs settle 5-8 % apart, and every XCD runs its own band of tiles, so the device-wide mean
+    # Which clock?  amdsmi's GFX `clk` is ONE XCD's clock — XCD 0 (measured round 5: the nearest XCD in 140 of 140 samples) — and under
+    # the package limit the eight XCDs settle 5-8 % apart (even-numbered ones ~5 % above odd-numbered ones on the boxes seen), and every XCD runs its own band of tiles, so the device-wide mean
     # (and, for the tail of a launch, the slowest XCD) is what the work sees.  Cycles are counted at the per-XCD MEAN when
     # the gpu_metrics table has it, at `clk` otherwise; both figures are on the line.
     xd, xz = (power or {}).get("xcd_clock_mhz"), (zero or {}).get("xcd_clock_mhz")
     use_xcd = bool(xd and xz and xd.get("mean") and xz.get("mean"))
     fd, fz = (xd["mean"], xz["mean"]) if use_xcd else (ck_d, ck_z)
     out["cycles_clock"] = ("per-XCD mean shader clock (gpu_metrics current_gfxclks)" if use_xcd
-                           else "amdsmi GFX clk (= the fastest XCD; no per-XCD table on this box)")
+                           else "amdsmi GFX clk (= XCD 0 only; no per-XCD table on this box)")
     if not (fd and fz and ms and ms_zero):
         out.update(cycles_data_M=None, cycles_zero_M=None, cycle_ratio=None,
                    reading="undetermined: a clock or a time is missing (no smi source on this box?)")
@@ -318,7 +318,7 @@ def power_bound_reading(ms, ms_zero, power, zero):
                 cand.append(f"{k} {v['data']:.0f} vs {v['zero']:.0f}")
         if "xcd_clock_mhz" in other:
             x = other["xcd_clock_mhz"]
-            cand.append(f"cycle ratio at the GFX clk (fastest XCD) {x['cycle_ratio_at_gfx_clk']}, at the slowest XCD "
+            cand.append(f"cycle ratio at the GFX clk (XCD 0) {x['cycle_ratio_at_gfx_clk']}, at the slowest XCD "
                         f"{x['cycle_ratio_at_slowest_xcd']:.3f}")
         if cr < 1.0 and share is not None:
             cand.append(f"fewer cycles on real data = a clock-independent share of the run (HBM-bound kernels, gaps): implied "
@@ -341,7 +341,7 @@ def power_bound_object(ms, power, zero, what):
            "ms": round(ms, 3), "ms_data_pass": ms_data, "ms_zero": ms_zero,
            "ratio": None if not ms_zero else round(ms / ms_zero, 4),
            "clock_mhz": {"data": mean(power, "clock_mhz"), "zero": mean(zero, "clock_mhz"),
-                         "note": "amdsmi GFX clk = the fastest XCD; the per-XCD mean / slowest are in other_domains.xcd_clock_mhz"},
+                         "note": "amdsmi GFX clk = XCD 0 only, one of the faster XCDs; the per-XCD mean / slowest are in other_domains.xcd_clock_mhz"},
            "clock_ratio": (None if not (mean(power, "clock_mhz") and mean(zero, "clock_mhz"))
                            else round(mean(zero, "clock_mhz") / mean(power, "clock_mhz"), 4)),
            "power_w": {"data": mean(power, "power_w"), "zero": mean(zero, "power_w")},

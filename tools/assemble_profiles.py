@@ -81,7 +81,7 @@ holds 8 forwards (1 warm-up + 3 timed + 1 + 3 of the serial roofline leg); per f
 fused tails, 34 wide 3x3 layers, 17 each of UPNet.0, UPNet.2, GFF.0, SFENet1.  bench.py's line in the same (profiled) run: {bp['value']} frames/s,
 {bp['ms_per_step']} ms / window, live HIP-event average of the dominant kernel {bp['roofline']['avg_kernel_us']} us.  Un-profiled on the same box
 (`{R}_bench_f16x3.json`): **{b['value']} frames/s, {b['ms_per_step']} ms / window**, dominant kernel {roof['avg_kernel_us']} us by events,
-{xcd(b.get('power'))} MHz (per-XCD mean; amdsmi's GFX clk = the fastest XCD: {mean(b.get('power'), 'clock_mhz')}) at {(b.get('power') or {}).get('power_from_energy_w')} W by the energy
+{xcd(b.get('power'))} MHz (per-XCD mean; amdsmi's GFX clk = XCD 0 alone: {mean(b.get('power'), 'clock_mhz')}) at {(b.get('power') or {}).get('power_from_energy_w')} W by the energy
 counter ({mean(b.get('power'), 'power_w')} W point-sampled; a pass of its own right after the timed region); the same forwards on ALL-ZERO operands: {pb.get('ms_zero')} ms
 at {xcd_z(pb)} MHz -> time ratio {pb.get('ratio')} against a clock ratio of {pb.get('clock_ratio_used')}, cycle ratio {pb.get('cycle_ratio')}.
 `power_bound.reading`: "{pb.get('reading')}"
