@@ -644,7 +644,7 @@ def kernel_roofline(prec, kern_ms, kern_n, hp, wp, ms, reuse_schedule):
                             "note": "the conv's own FLOPs (one product per multiply-add) against the same peak: what the emulation of "
                                     "22-bit significands with fp16 products costs is the factor between the two fractions"},
             "note": f"executed MFMA FLOPs = {PRODUCTS[prec]} x the conv's algorithmic FLOPs; peak = nominal dense fp16 "
-                    "at 2.4 GHz — scale by power.clock_mhz / 2400 for the peak at the clock this run held",
+                    "at 2.4 GHz — scale by power.xcd_clock_mhz.mean / 2400 for the peak at the clock this run held",
             "reference_sustained_at_power_cap": {
                 "random_fp16": 1663.0, "zeros": 2473.0, "unit": "TFLOP/s",
                 "source": "profiles/r02_power_cap.md (register-resident v_mfma_f32_32x32x16_f16 alone, "
