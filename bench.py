@@ -351,6 +351,95 @@ def power_bound_object(ms, power, zero, what):
     return out
 
 
+def step_spread(ms_list):
+    """min / median / max of the per-step device times of a timed region (one HIP event per step boundary on the launch stream):
+    a single stalled step is invisible in `ms_per_step` = total / steps."""
+    v = sorted(float(x) for x in ms_list)
+    if not v:
+        return None
+    med = v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+    return {"ms_min": round(v[0], 3), "ms_median": round(med, 3), "ms_max": round(v[-1], 3),
+            "max_over_median": round(v[-1] / med, 4) if med else None, "steps": len(v)}
+
+
+def clock_fields(ms, power):
+    """Box-independent yardstick: cycles per step = ms x the per-XCD mean shader clock of the power pass that
+    follows the timed region (boxes hold 1.6-1.9 GHz at the package limit; the cycle count moves far less than the milliseconds)."""
+    x = (power or {}).get("xcd_clock_mhz") or {}
+    f = x.get("mean") or ((power or {}).get("clock_mhz") or {}).get("mean")
+    return {"xcd_clock_mhz_mean": f, "cycles_per_step_M": None if not (f and ms) else round(ms * f * 1e-3, 2),
+            "cycles_clock": "per-XCD mean (gpu_metrics)" if x.get("mean") else "amdsmi GFX clk (XCD 0 only)"}
+
+
+def timed_steps(fn, steps, sync_all):
+    """The contract's timed region (EXACTLY `steps` calls of fn, closed by sync_all) plus one HIP event per step boundary."""
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record()
+    for i in range(steps):
+        fn(i)
+        ev[i + 1].record()
+    sync_all()
+    dt = time.perf_counter() - t0
+    return dt, [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+
+
+def make_train_model(prec, bwd_prec, world, rank, B, zero_data=False, S=256):
+    """The training model of --mode train (BASELINE config 3/4) with one synthetic batch fed; also used by tools/stall_hunt.py."""
+    import tempfile
+    from bin_amd.models import create_model
+    from bin_amd.weights import reference_state_dict
+    tmp = tempfile.mkdtemp()
+    opt = {"model": "bin", "gpu_ids": [0], "is_train": True, "dist": world > 1,
+           "network_G": {"which_model_G": "bin_stage4", "nframes": 6, "version": 2, "precision": prec,
+                         "backward_precision": bwd_prec},
+           "path": {"pretrain_model_G": None, "strict_load": True, "models": tmp, "training_state": tmp},
+           "train": {"pixel_criterion": "cb", "pixel_weight": 1.0, "weight_decay_G": 0, "ft_tsa_only": None,
+                     "lr_G": 1e-4, "beta1": 0.9, "beta2": 0.99, "lr_scheme": "MultiStepLR", "lr_steps": [100000],
+                     "restarts": None, "restart_weights": None, "lr_gamma": 0.5, "clear_state": False}}
+    m = create_model(opt)
+    m.netG.module.load_state_dict(reference_state_dict(0), strict=True)
+    if prec == "f16":                        # timing diagnostic only: single-product training is gated (bin_amd/autograd.py)
+        for mod in m.netG.module.rdn_modules():
+            mod.allow_f16_training = True
+    g = torch.Generator().manual_seed(7 + rank)
+    batch = {"LQs": torch.rand(B, 6, 3, S, S, generator=g), "GTenh": torch.rand(B, 6, 3, S, S, generator=g),
+             "GTinp": torch.rand(B, 5, 3, S, S, generator=g)}
+    if zero_data:                            # diagnostic (invalid as a result): the same launches on all-zero operands
+        batch = {k: torch.zeros_like(v) for k, v in batch.items()}
+        with torch.no_grad():
+            for prm in m.netG.module.parameters():
+                prm.zero_()
+    m.feed_data(batch)
+    return m, batch
+
+
+def make_train_step(batch=8, precision="f16x3"):
+    m, _ = make_train_model(precision, None, 1, 0, batch)
+    n = [0]
+
+    def step():
+        n[0] += 1
+        m.optimize_parameters(n[0])
+    return step
+
+
+def make_infer_step(precision="f16x3"):
+    from bin_amd.models.archs.RDN import bin_stage4_lstm
+    from bin_amd.utils import util
+    from bin_amd.weights import reference_state_dict, synthetic_frames
+    dev = torch.device("cuda", torch.cuda.current_device())
+    net = bin_stage4_lstm()
+    net.load_state_dict(reference_state_dict(0), strict=True)
+    net = net.to(dev).eval().set_precision(precision)
+    frames = [util.replicate_pad(f, util.pad_sizes(H, W)).to(dev) for f in synthetic_frames(1234, 1, H, W, 6)]
+
+    def step():
+        with torch.no_grad():
+            net(*frames)
+    return step
+
+
 def max_over_ranks(dt, dev, world):
     """Slowest rank's time (the contract's max-over-ranks).  nccl (= RCCL) reduces on the device; the gloo hook used to run
     the N > 1 flow on ONE GPU (tests/test_gpu_round3.py) reduces a host tensor."""
@@ -477,39 +566,15 @@ def train_bench(args, rank, world, dev, steps=None, warmup=None, standalone=True
     """Secondary metric (BASELINE.json config 4): training samples/s, one process per GPU, DP gradient all-reduce.
     standalone=False: called from the default inference run (rank 0, N = 1) to put a driver-timed training figure on
     the same JSON line; returns the dict instead of printing it."""
-    import tempfile
     import torch.distributed as dist
-    from bin_amd.models import create_model
-    from bin_amd.weights import reference_state_dict
     prec = args.train_precision
     bwd_prec = None
     if prec == "mixed":                      # fp32-class forward (exact loss / ReLU masks), single-product backward
         prec, bwd_prec = "f16x3", "f16"
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
-    tmp = tempfile.mkdtemp()
-    opt = {"model": "bin", "gpu_ids": [0], "is_train": True, "dist": world > 1,
-           "network_G": {"which_model_G": "bin_stage4", "nframes": 6, "version": 2, "precision": prec,
-                         "backward_precision": bwd_prec},
-           "path": {"pretrain_model_G": None, "strict_load": True, "models": tmp, "training_state": tmp},
-           "train": {"pixel_criterion": "cb", "pixel_weight": 1.0, "weight_decay_G": 0, "ft_tsa_only": None,
-                     "lr_G": 1e-4, "beta1": 0.9, "beta2": 0.99, "lr_scheme": "MultiStepLR", "lr_steps": [100000],
-                     "restarts": None, "restart_weights": None, "lr_gamma": 0.5, "clear_state": False}}
-    m = create_model(opt)
-    m.netG.module.load_state_dict(reference_state_dict(0), strict=True)
-    if prec == "f16":                        # timing diagnostic only: single-product training is gated (bin_amd/autograd.py)
-        for mod in m.netG.module.rdn_modules():
-            mod.allow_f16_training = True
-    g = torch.Generator().manual_seed(7 + rank)
+    m, batch = make_train_model(prec, bwd_prec, world, rank, args.batch, args.zero_data)
     B, S = args.batch, 256
-    batch = {"LQs": torch.rand(B, 6, 3, S, S, generator=g), "GTenh": torch.rand(B, 6, 3, S, S, generator=g),
-             "GTinp": torch.rand(B, 5, 3, S, S, generator=g)}
-    if args.zero_data:                       # diagnostic (invalid as a result): the same launches on all-zero operands
-        batch = {k: torch.zeros_like(v) for k, v in batch.items()}
-        with torch.no_grad():
-            for prm in m.netG.module.parameters():
-                prm.zero_()
-    m.feed_data(batch)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -523,11 +588,7 @@ def train_bench(args, rank, world, dev, steps=None, warmup=None, standalone=True
     for i in range(warmup):
         m.optimize_parameters(i + 1)
     sync_all()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        m.optimize_parameters(warmup + i + 1)
-    sync_all()
-    dt = time.perf_counter() - t0
+    dt, step_ms = timed_steps(lambda i: m.optimize_parameters(warmup + i + 1), steps, sync_all)
     ops.check_status()                       # no activation / gradient left the fp16 storage range
     loss_value = float(m.loss.detach())
     # clock / package power of the same steps, sampled in a pass of its own (every rank runs it: collectives stay matched)
@@ -600,7 +661,9 @@ def train_bench(args, rank, world, dev, steps=None, warmup=None, standalone=True
         "backend": (dist.get_backend() if dist.is_initialized() else None),
         "power": power,
         "power_bound": power_bound,
-        "roofline": train_roofline(B, S, dt / steps, prec, bwd_prec, kern, kern_overlapped),
+        "step_ms": step_spread(step_ms),
+        "roofline": {**train_roofline(B, S, dt / steps, prec, bwd_prec, kern, kern_overlapped), **clock_fields(dt / steps * 1e3, power),
+                     "step_ms": step_spread(step_ms)},
         "config": {"workload": f"Adobe240 training, 256x256 crops, batch {B} per GPU, Charbonnier x17, Adam, "
                                f"DP flat gradient all-reduce (45.77 MB)", "precision": prec,
                    "backward_precision": bwd_prec or prec}}
@@ -851,11 +914,12 @@ def main():
         # every CU, so another stream's kernels only slip into the ramp/drain.  Off by default.
         kw_in = {"input_events": []} if (net.resolved_streams() > 1 and not args.four_calls and args.pipeline) else {}
         from bin_amd.utils.smi import power_pass
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = net(*frames, **kw_in)
-        sync_all()
-        dt = time.perf_counter() - t0
+        outs = [None]
+
+        def one_window(i):
+            outs[0] = net(*frames, **kw_in)
+        dt, step_ms = timed_steps(one_window, args.steps, sync_all)
+        out = outs[0]
         # shader clock / package power of the same forwards, in a pass of its own right after the timed region
         do_power = rank == 0 and not args.no_power
         power = power_pass(lambda: net(*frames, **kw_in), dev, min_seconds=1.0, sync=torch.cuda.synchronize) if do_power else None
@@ -980,6 +1044,9 @@ def main():
         ms = dt / args.steps * 1e3
         # (kernel_roofline refuses a byte yardstick that would exceed the HBM peak: round 1's f16 line did)
         roof = kernel_roofline(prec, kern_ms, kern_n, hp, wp, ms, net.reuse_schedule) if prof else None
+        if roof is not None:
+            roof.update(clock_fields(ms, power))
+            roof["step_ms"] = step_spread(step_ms)
         line = {
             "metric": "interpolated frames/sec at 1280x720", "value": round(value, 4),
             "unit": "interpolated frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -994,6 +1061,7 @@ def main():
                        "four_call_schedule": bool(args.four_calls),
                        "parity": "max-abs <= 2e-5 (f16x3) vs the fp32 reference (tests/)" if prec == "f16x3"
                                  else "max-abs <= 1e-3 (f16) vs the fp32 reference (tests/)"},
+            "step_ms": step_spread(step_ms),
             "roofline": roof,
             "power": power,
             "power_bound": power_bound,

@@ -61,7 +61,8 @@ def build_library(force=False, verbose=True, defines=(), out=None):
     # Dynamic symbols = exactly the entry points include/binhip.h declares (sources are compiled -fvisibility=hidden; the
     # version script also makes the host-side kernel handles hipcc emits with default visibility local).
     vmap = os.path.join(objdir, "binhip_exports" + tag + ".map")
-    names = abi_symbols() + (list(TUNING_SYMBOLS) if any(d.startswith("BINHIP_TUNING") for d in defines) else [])
+    names = abi_symbols() + (list(TUNING_SYMBOLS) if any(d.startswith("BINHIP_TUNING") for d in defines) else []) + \
+        (["binhip_set_timeline"] if any(d.startswith("BINHIP_TIMELINE") for d in defines) else [])
     with open(vmap, "w") as f:
         f.write("{\n  global:\n" + "".join(f"    {n};\n" for n in names) + "  local: *;\n};\n")
     # -z defs: a kernel template the host pass silently failed to instantiate shows up as an undefined symbol HERE, not at dlopen

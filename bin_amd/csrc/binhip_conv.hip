@@ -413,6 +413,9 @@ int bh_prepare_conv(const BhConvCall& c, ConvKArgs* out) {
     a.xcd_remap = 1;
     a.dbg = 0;
     a.wt = 0;
+#if BINHIP_TIMELINE
+    a.tl = nullptr; a.tl_launch = 0; a.tl_base = 0;
+#endif
     const int P = BINHIP_EPI_PLANES, S = BINHIP_EPI_SHUFFLE, F = BINHIP_EPI_FINAL;
     if (d.epilogue == P) {
         if (!c.y_hi || (d.nterms == 3 && !c.y_lo)) return BINHIP_E_ARG;
@@ -841,6 +844,18 @@ BINHIP_API int binhip_set_variant(int layer_class, int variant) {
     if (layer_class < 0 || layer_class >= 8) return BINHIP_E_ARG;
     g_variant[layer_class] = variant;
     return 0;
+}
+#endif
+
+#if BINHIP_TIMELINE
+// side builds only: `buf` = zeroed device memory holding a BhTlBuf with room for `cap` records, null = stamps off.
+// Returns the number of records reserved since the previous call.
+BINHIP_API int binhip_set_timeline(void* buf, unsigned cap) {
+    const unsigned used = g_bh_tl_next.exchange(0);
+    g_bh_tl_buf = buf;
+    g_bh_tl_cap = cap;
+    g_bh_tl_serial.store(0);
+    return (int)(used < g_bh_tl_cap || !buf ? used : used);
 }
 #endif
 

@@ -3,6 +3,9 @@
 // PixelShuffle scatter, fp32 NCHW final output).  Internal — not part of the C ABI.
 #pragma once
 #include "binhip_internal.h"
+#ifndef BINHIP_TIMELINE
+#define BINHIP_TIMELINE 0     // side builds only: per-workgroup time stamps (BhTl below)
+#endif
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -44,10 +47,76 @@ struct ConvKArgs {
     unsigned y_cpg_inv;       // ceil(2^20 / y_cpg): och / y_cpg == (och * y_cpg_inv) >> 20 for och < 4096, y_cpg <= 128 (no SALU division per slot)
     long long y_group_stride;
     int half_last;            // the last input chunk carries 8 real channels at most (BINHIP_CONV_HALF_LAST_CHUNK): 5x5 plane-split kernel
+#if BINHIP_TIMELINE
+    void* tl;                 // BINHIP_TIMELINE side builds: per-workgroup time-stamp records (BhTlBuf) or null
+    unsigned tl_launch;       // (kernel kind << 24) | launch serial
+    unsigned tl_base;         // first record of this launch (records are pre-assigned: base + tile index, no atomics)
+#endif
     int y_unshuf;             // XTRA kernels only: > 0 = the output goes out through an inverse PixelShuffle(2) — full-resolution
                               // pixel (Y, X), chunk c -> plane (2 (Y & 1) + (X & 1)) * y_unshuf + c at (Y / 2, X / 2) of the half-
                               // resolution tensor (the channel order UPNet.0's permuted rows use); y_unshuf = chunks per sub-position
 };
+
+// ---- BINHIP_TIMELINE side builds (tools/wg_timeline.py; never in the product): wave 0 of every workgroup of the dominant
+// fp32-class kernels stamps the constant-rate 100 MHz counter (s_memrealtime: one time base for all XCDs, whose shader clocks
+// differ under the package limit) at entry / first MFMA / last MFMA / last store issued / stores drained, plus the shader-clock
+// counter (s_memtime) at entry and exit and the hardware ids of where it ran.
+#if BINHIP_TIMELINE
+#include <atomic>
+struct BhTlRec {
+    unsigned kind_launch, bid, hwid, xcc;
+    unsigned long long rt[5];
+    unsigned long long clk[2];
+    unsigned long long pad;
+};
+static_assert(sizeof(BhTlRec) == 80, "record size (tools/wg_timeline.py)");
+struct BhTlBuf { unsigned cursor, cap, pad[2]; BhTlRec rec[1]; };
+inline void* g_bh_tl_buf = nullptr;                       // host side: set by binhip_set_timeline()
+inline unsigned g_bh_tl_cap = 0;
+inline std::atomic<unsigned> g_bh_tl_serial{0}, g_bh_tl_next{0};
+// reserve `n` records for one launch; returns the buffer (or null when full / off) and the first record's index
+inline void* bh_tl_reserve(unsigned n, unsigned* base) {
+    if (!g_bh_tl_buf) return nullptr;
+    const unsigned b = g_bh_tl_next.fetch_add(n);
+    *base = b;
+    return (b + n <= g_bh_tl_cap) ? g_bh_tl_buf : nullptr;
+}
+struct BhTl {
+    unsigned long long rt[5], clk[2];
+    __device__ __forceinline__ void stamp(int i) {
+        __builtin_amdgcn_sched_barrier(0);
+        rt[i] = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void begin() { clk[0] = __builtin_amdgcn_s_memtime(); stamp(0); }
+    __device__ __forceinline__ void finish(void* tl, unsigned kind_launch, unsigned i) {
+        stamp(3);
+        if (threadIdx.x < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // wave 0 only: the others end as in the product
+        stamp(4);
+        clk[1] = __builtin_amdgcn_s_memtime();
+        if (tl && threadIdx.x == 0) {
+            BhTlBuf* b = (BhTlBuf*)tl;
+            {
+                BhTlRec& r = b->rec[i];
+                r.kind_launch = kind_launch; r.bid = blockIdx.x;
+                r.hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
+                r.xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // XCC_ID
+                for (int k = 0; k < 5; ++k) r.rt[k] = rt[k];
+                r.clk[0] = clk[0]; r.clk[1] = clk[1];
+            }
+        }
+    }
+};
+#define BH_TL_DECL BhTl tl__
+#define BH_TL_BEGIN() tl__.begin()
+#define BH_TL_STAMP(i) tl__.stamp(i)
+#define BH_TL_FINISH(a, i) tl__.finish((a).tl, (a).tl_launch, (a).tl_base + (unsigned)(i))
+#else
+#define BH_TL_DECL
+#define BH_TL_BEGIN()
+#define BH_TL_STAMP(i)
+#define BH_TL_FINISH(a, i)
+#endif
 
 // internal epilogue code (never crosses the ABI): chunk planes with the extras pattern of the LFF backward-data tile
 #define BINHIP_EPI_PLANES_LFFD 3

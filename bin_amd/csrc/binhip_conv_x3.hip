@@ -203,12 +203,25 @@ __device__ __forceinline__ void x3_compute_pair(const char* pb, const char* wb, 
     }
 }
 
+// Dependency gate of the one-launch dense block (conv_x3_rdbs_kernel below): the input chunks >= `chunk` of this tile (and of its
+// halo) are produced by OTHER workgroups of the same launch; `flags[tile]` == `epoch` says a tile's share of them is visible.
+// Chunks < `chunk` were checked by an earlier phase, so the K loop runs them ungated — only the last chunks wait.
+struct X3Gate {
+    const unsigned* flags;    // per-tile "previous phase visible" words (null: nothing to wait for)
+    unsigned epoch;
+    int chunk;                // first chunk that needs the neighbours' previous phase
+    unsigned* status;         // device status word for the bounded-spin bit
+};
+constexpr unsigned RDB3_SPIN_LIMIT = 1u << 22;
+
 // One output tile (TH x 32 pixels, 32 output channels of column z) from prologue DMA to epilogue stores.  Every wave of
 // the workgroup calls it with the same arguments; LDS must be free of readers on entry.
-template <int KS, int R, int WN, int EPI, bool XTRA>
+template <int KS, int R, int WN, int EPI, bool XTRA, bool GATED = false>
 __device__ __forceinline__ void x3_tile(const ConvKArgs& a, const float* __restrict__ bias, char* smem, int img, int ty, int tx,
-                                        int z) {
+                                        int z, const X3Gate gate = X3Gate{nullptr, 0u, 1 << 30, nullptr}) {
     using C = X3Cfg<KS, R, WN>;
+    BH_TL_DECL;
+    BH_TL_BEGIN();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -246,6 +259,26 @@ __device__ __forceinline__ void x3_tile(const ConvKArgs& a, const float* __restr
     const int b_lane_off = (kg * (C::PH * C::PW) + wave * R * C::PW + n) * 16;
 
     x3_issue_weights<C, KS>(a, smem, 0, 0, wave, lane, z);
+    if constexpr (GATED) {
+        if (gate.chunk <= 0 && gate.flags) {              // every input chunk is gated: wait before the first patch DMA
+            if (tid < 9) {
+                const int ny = ty + tid / 3 - 1, nx = tx + tid % 3 - 1;
+                if (ny >= 0 && ny < a.tiles_y && nx >= 0 && nx < a.tiles_x) {
+                    const unsigned* f = gate.flags + ((size_t)img * a.tiles_y + ny) * a.tiles_x + nx;
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gate.epoch) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > RDB3_SPIN_LIMIT) {
+                            if (gate.status) atomicOr(gate.status, BINHIP_STATUS_SYNC_TIMEOUT);
+                            break;
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
     x3_issue_patch<C>(a, smem, 0, 0, 0, wave, voff, plane_elems, plane_bytes);
     for (int c = 0; c < nchunks; ++c) {
         const char* wb = smem + 2 * C::PATCH_BYTES + (c & 1) * C::WBUF_BYTES;
@@ -262,8 +295,24 @@ __device__ __forceinline__ void x3_tile(const ConvKArgs& a, const float* __restr
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+#if BINHIP_TIMELINE
+        if (c == 0) BH_TL_STAMP(1);
+#endif
         x3_issue_patch<C>(a, smem, c, 1, 1, wave, voff, plane_elems, plane_bytes);
         if (c + 1 < nchunks) x3_issue_weights<C, KS>(a, smem, c + 1, (c + 1) & 1, wave, lane, z);
+        // GATED: one sub-stage before the first DMA of a gated chunk (the hi plane of chunk c + 1, issued in the lo sub-stage
+        // below), lanes 0-8 of wave 0 fetch the flags of the 3 x 3 tile neighbourhood; the loads ride under this sub-stage's MFMAs
+        unsigned gate_seen = gate.epoch;
+        const unsigned* gate_word = nullptr;
+        if constexpr (GATED) {
+            if (c + 1 == gate.chunk && gate.flags && tid < 9) {
+                const int ny = ty + tid / 3 - 1, nx = tx + tid % 3 - 1;
+                if (ny >= 0 && ny < a.tiles_y && nx >= 0 && nx < a.tiles_x) {
+                    gate_word = gate.flags + ((size_t)img * a.tiles_y + ny) * a.tiles_x + nx;
+                    gate_seen = __hip_atomic_load(gate_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
         // (5x5 only: the last chunk of a 24- / 36-channel layer on tap pairs, see x3_compute_pair)
         const bool pair = (KS == 5) && !XTRA && a.half_last && (c + 1 == nchunks);
         if constexpr (KS == 5 && !XTRA) {
@@ -276,6 +325,23 @@ __device__ __forceinline__ void x3_tile(const ConvKArgs& a, const float* __restr
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (GATED) {
+            if (c + 1 == gate.chunk && gate.flags) {      // (workgroup-uniform)
+                if (gate_word) {
+                    unsigned spins = 0;
+                    while (gate_seen != gate.epoch) {
+                        __builtin_amdgcn_s_sleep(2);
+                        gate_seen = __hip_atomic_load(gate_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (++spins > RDB3_SPIN_LIMIT) {
+                            if (gate.status) atomicOr(gate.status, BINHIP_STATUS_SYNC_TIMEOUT);
+                            break;
+                        }
+                    }
+                }
+                __builtin_amdgcn_s_barrier();             // every wave: the neighbourhood's previous phase is visible
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         if (c + 1 < nchunks) x3_issue_patch<C>(a, smem, c + 1, 0, 0, wave, voff, plane_elems, plane_bytes);
         if constexpr (KS == 5 && !XTRA) {
             if (pair) x3_compute_pair<C, KS, R, false>(smem + C::PATCH_BYTES, wb, n, kg, wave, acc[0]);
@@ -284,7 +350,9 @@ __device__ __forceinline__ void x3_tile(const ConvKArgs& a, const float* __restr
             x3_compute<C, KS, R, false>(smem + C::PATCH_BYTES, wb, a_lane_off, b_lane_off, acc[0]);
         }
     }
+    BH_TL_STAMP(2);
     conv_epilogue<1, R, 3, EPI, XTRA>(a, bias, acc, img, ty0 + wave * R, tx0, z * 32, z == 0, n, kg, plane_elems);
+    BH_TL_FINISH(a, (((img * a.tiles_y + ty) * a.tiles_x + tx) * a.ncol + z));
 }
 
 // WIDE only names the instantiation: 0 = one 32-row output block (the dense-block convs, UPNet.2), 1 = several workgroup
@@ -315,70 +383,68 @@ conv_x3_kernel(const ConvKArgs a, const float* __restrict__ bias) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // The three Cout = 32 convolutions of a residual dense block (RDN.py:135-147: convs 0, 1, 2 of `RDB.convs`) as phases of
-// ONE launch.  Conv p+1 of a tile needs conv p's output of the tile and of its 8 neighbours (1-pixel halo), nothing else,
-// so there is no grid-wide barrier: workgroups take (phase, tile) items from an atomic counter in phase-major raster order
-// and, before a phase >= 1 item, poll the per-tile "done" flags of the 3 x 3 neighbourhood of the previous phase.
-//   * No deadlock for ANY grid size or residency: every item an item waits for has a smaller index, so it was handed out
-//     earlier to a workgroup that is running (it executed the atomic) and that itself only waits for still smaller indices.
+// ONE launch with STATIC tile ownership (round 6; rounds 2-5 handed (phase, tile) items out of an atomic work queue and lost
+// 2-3 % to it).  What the per-workgroup timeline of the per-conv launches showed (profiles/r06_wg_timeline.md): the two
+// workgroups of a CU do NOT share the matrix pipe evenly — the older one runs as if alone (30 us), the younger one gets the
+// gaps and then runs 20 us by itself with its prologue, epilogue and barrier waits exposed; every launch then waits for the
+// slowest CU (span 57 us for a mean pair time of 50) and the next launch starts 3.7 us later.  Here a workgroup keeps its
+// tile(s) for all three convs:
+//   * conv p+1 of a tile needs conv p's output of the tile and of its 8 neighbours (1-pixel halo) — and ONLY for its last
+//     two input chunks (planes 6+2p, 7+2p of the block buffer); the chunks before them were complete before this phase
+//     began.  The K loop runs in natural order, so the dependency comes last by itself: a workgroup that finishes conv p
+//     early streams 6+2p of the 8+2p chunks of conv p+1 while its neighbours finish, and only then looks at their flags
+//     (X3Gate) — the chip never drains between the convs, and the CU's other workgroup fills every gap.
+//   * grid = min(tiles, 2 x CUs) workgroups, all co-resident (the launcher checks the occupancy: 76 KB of LDS and <= 128
+//     VGPRs give two per CU); workgroup b owns tiles b, b + grid, ... in every phase, so nothing is handed out at run
+//     time.  No deadlock: an item only waits for items of the PREVIOUS phase, and every workgroup finishes its phase-p
+//     items before it starts a phase-(p+1) item.
 //   * Visibility across CUs / XCDs (MI355X: per-XCD L2s are not coherent, a CU's L1 is never refreshed): the producer's
 //     output stores are the write-through (sc1) 16-byte plane stores the kernel uses anyway; every wave drains them
 //     (s_waitcnt vmcnt(0)), the workgroup barriers, ONE lane publishes the flag with an agent-scope (sc1) store.  The
-//     consumer polls with agent-scope loads, barriers, and only then issues its LDS-DMA: the planes it now reads (chunks
-//     6+2p, 7+2p of the block buffer) were never read in this launch before their flags were set, so no L1 / L2 holds a
-//     stale line of them (kernel boundaries invalidate both).
+//     consumer polls with agent-scope loads, barriers, and only then issues its LDS-DMA of the gated planes: they were
+//     never read in this launch before their flags were set, so no L1 / L2 holds a stale line of them (kernel boundaries
+//     invalidate both).
 //   * A bounded spin (RDB3_SPIN_LIMIT polls with s_sleep) turns a protocol error into a status bit instead of a hang.
+// Same arithmetic in the same order as the per-conv launches: bit-identical outputs (tests/test_gpu_conv.py).
 struct Rdb3Args {
     ConvKArgs conv[3];
-    unsigned* counter;        // work-queue head, 0 at launch
     unsigned* flags;          // [2][T] "phase p of tile t is visible" == epoch
     unsigned epoch;           // value that means "done" in this launch (flags are reused by later launches)
     int T;                    // tiles per phase = tiles_x * tiles_y * N
 };
-constexpr unsigned RDB3_SPIN_LIMIT = 1u << 22;
 
 template <int R, int WN>
 __global__ void __launch_bounds__(64 * WN) __attribute__((amdgpu_waves_per_eu(WN / 2, WN / 2)))
-conv_x3_rdb3_kernel(const Rdb3Args a, const float* __restrict__ bias0, const float* __restrict__ bias1,
+conv_x3_rdbs_kernel(const Rdb3Args a, const float* __restrict__ bias0, const float* __restrict__ bias1,
                     const float* __restrict__ bias2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ unsigned s_idx;
     const int tiles_x = a.conv[0].tiles_x, tiles_y = a.conv[0].tiles_y;
-    const unsigned total = 3u * (unsigned)a.T;
-    for (;;) {
-        if (threadIdx.x == 0) s_idx = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        const unsigned idx = s_idx;
-        if (idx >= total) break;
-        const int p = (int)(idx / (unsigned)a.T);
-        int t = (int)(idx - (unsigned)p * (unsigned)a.T);
-        const int tx = t % tiles_x;
-        t /= tiles_x;
-        const int ty = t % tiles_y;
-        const int img = t / tiles_y;
-        if (p > 0) {
-            if (threadIdx.x < 9) {            // one lane per neighbour of the 3 x 3 neighbourhood
-                const int ny = ty + (int)threadIdx.x / 3 - 1, nx = tx + (int)threadIdx.x % 3 - 1;
-                if (ny >= 0 && ny < tiles_y && nx >= 0 && nx < tiles_x) {
-                    const unsigned* f = a.flags + (size_t)(p - 1) * a.T + ((size_t)img * tiles_y + ny) * tiles_x + nx;
-                    unsigned spins = 0;
-                    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
-                        __builtin_amdgcn_s_sleep(2);
-                        if (++spins > RDB3_SPIN_LIMIT) {
-                            if (a.conv[0].flags) atomicOr(a.conv[0].flags, BINHIP_STATUS_SYNC_TIMEOUT);
-                            break;
-                        }
-                    }
-                }
-            }
+    const int G = (int)gridDim.x;
+    const int b = xcd_band((int)blockIdx.x, G);           // consecutive owners = neighbouring tiles on one XCD
+#pragma unroll 1
+    for (int p = 0; p < 3; ++p) {
+        const ConvKArgs& ka = a.conv[p];
+        const float* bias = p == 0 ? bias0 : (p == 1 ? bias1 : bias2);
+        X3Gate gate;
+        gate.flags = p > 0 ? a.flags + (size_t)(p - 1) * a.T : nullptr;
+        gate.epoch = a.epoch;
+        gate.chunk = ka.nchunks - 2;
+        gate.status = ka.flags;
+#pragma unroll 1
+        for (int t0 = b; t0 < a.T; t0 += G) {
+            int t = t0;
+            const int tx = t % tiles_x;
+            t /= tiles_x;
+            const int ty = t % tiles_y;
+            const int img = t / tiles_y;
+            x3_tile<3, R, WN, BINHIP_EPI_PLANES, false, true>(ka, bias, smem, img, ty, tx, 0, gate);
+            // publish: this wave's write-through stores have left (vmcnt(0)), then all waves', then the flag; the barrier
+            // also frees LDS for the next tile's prologue
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0 && p < 2)
+                __hip_atomic_store(a.flags + (size_t)p * a.T + t0, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        __syncthreads();                      // also: every wave has read s_idx before lane 0 overwrites it
-        x3_tile<3, R, WN, BINHIP_EPI_PLANES, false>(a.conv[p], p == 0 ? bias0 : (p == 1 ? bias1 : bias2), smem, img, ty, tx, 0);
-        // publish: this wave's write-through stores have left (vmcnt(0)), then all waves', then the flag
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0 && p < 2)
-            __hip_atomic_store(a.flags + (size_t)p * a.T + (idx - (unsigned)p * (unsigned)a.T), a.epoch, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -392,6 +458,11 @@ static int launch_x3_x(const ConvKArgs& ka, int cout_pad, hipStream_t s) {
     a.tiles_y = (a.H + C::TH - 1) / C::TH;
     a.ncol = cout_pad / 32;
     dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N * a.ncol));
+#if BINHIP_TIMELINE
+    // kind: 1 = the dense-block conv (3x3, one 32-row column, plane epilogue, no extras), 3 = every other instantiation
+    a.tl = bh_tl_reserve(grid.x, &a.tl_base);
+    a.tl_launch = ((KS == 3 && EPI == BINHIP_EPI_PLANES && WIDE == 0 && !XTRA ? 1u : 3u) << 24) | (g_bh_tl_serial.fetch_add(1) & 0xFFFFFFu);
+#endif
     conv_x3_kernel<KS, R, WN, EPI, WIDE, XTRA><<<grid, dim3(64 * C::NW), C::LDS_BYTES, s>>>(a, a.bias);
     BH_CHECK_LAUNCH();
     return 0;
@@ -404,25 +475,44 @@ static int launch_x3(const ConvKArgs& ka, int cout_pad, hipStream_t s) {
     return launch_x3_x<KS, R, WN, EPI, WIDE, false>(ka, cout_pad, s);
 }
 
-// the three-phase dense-block launch: `convs` are the fully prepared kernel arguments of convs 0, 1, 2 (same N, H, W;
-// write-through stores required), `sync` = [counter][2 * T flags] device words, counter zeroed by the caller
-int bh_launch_rdb3_x3(const ConvKArgs* convs, unsigned* counter, unsigned* flags, unsigned epoch, int cus, hipStream_t s) {
+// the one-launch dense block: `convs` are the fully prepared kernel arguments of convs 0, 1, 2 (same N, H, W; write-through
+// stores required), `flags` = 2 * T device words whose values differ from `epoch` (the caller zeroes them once per RDN call and
+// passes epoch = block index + 1).  Returns BINHIP_E_SHAPE when the kernel cannot keep two workgroups per CU resident.
+int bh_launch_rdb3_x3(const ConvKArgs* convs, unsigned* flags, unsigned epoch, int cus, hipStream_t s) {
     using C = X3Cfg<3, BINHIP_X3_R, BINHIP_X3_WN>;
     static std::atomic<unsigned long long> lds_set{0};
-    if (int rc = bh_set_max_lds(&conv_x3_rdb3_kernel<BINHIP_X3_R, BINHIP_X3_WN>, C::LDS_BYTES, lds_set)) return rc;
+    static std::atomic<int> per_cu{-1};
+    if (int rc = bh_set_max_lds(&conv_x3_rdbs_kernel<BINHIP_X3_R, BINHIP_X3_WN>, C::LDS_BYTES, lds_set)) return rc;
+    int occ = per_cu.load(std::memory_order_acquire);
+    if (occ < 0) {             // co-residency of the whole grid is what makes the flag waits safe: ask the runtime once
+        int n = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_x3_rdbs_kernel<BINHIP_X3_R, BINHIP_X3_WN>, 64 * C::NW,
+                                                                    C::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        occ = n > 2 ? 2 : n;
+        per_cu.store(occ, std::memory_order_release);
+    }
+    if (occ < 1) return BINHIP_E_SHAPE;
     Rdb3Args a;
     for (int p = 0; p < 3; ++p) {
         a.conv[p] = convs[p];
         a.conv[p].tiles_x = (convs[p].W + 31) / 32;
         a.conv[p].tiles_y = (convs[p].H + C::TH - 1) / C::TH;
-        if (!a.conv[p].wt) return BINHIP_E_SHAPE;
+        if (!a.conv[p].wt || a.conv[p].nchunks < 3) return BINHIP_E_SHAPE;
+#if BINHIP_TIMELINE
+        // kinds 4, 5, 6 = phases 0, 1, 2 of the one-launch dense block
+        a.conv[p].tl = bh_tl_reserve((unsigned)(a.conv[p].tiles_x * a.conv[p].tiles_y * a.conv[p].N), &a.conv[p].tl_base);
+        a.conv[p].tl_launch = ((4u + p) << 24) | (g_bh_tl_serial.load() & 0xFFFFFFu);
+#endif
     }
+#if BINHIP_TIMELINE
+    g_bh_tl_serial.fetch_add(1);
+#endif
     a.T = a.conv[0].tiles_x * a.conv[0].tiles_y * a.conv[0].N;
-    a.counter = counter; a.flags = flags; a.epoch = epoch;
-    const long long items = 3ll * a.T;
-    const long long slots = 2ll * (cus > 0 ? cus : 256);
-    const unsigned grid = (unsigned)(items < slots ? items : slots);
-    conv_x3_rdb3_kernel<BINHIP_X3_R, BINHIP_X3_WN><<<dim3(grid), dim3(64 * C::NW), C::LDS_BYTES, s>>>(a, a.conv[0].bias, a.conv[1].bias,
+    a.flags = flags; a.epoch = epoch;
+    const long long slots = (long long)occ * (cus > 0 ? cus : 256);
+    const unsigned grid = (unsigned)(a.T < slots ? a.T : slots);
+    conv_x3_rdbs_kernel<BINHIP_X3_R, BINHIP_X3_WN><<<dim3(grid), dim3(64 * C::NW), C::LDS_BYTES, s>>>(a, a.conv[0].bias, a.conv[1].bias,
                                                                                                    a.conv[2].bias);
     BH_CHECK_LAUNCH();
     return 0;

@@ -11,6 +11,10 @@ struct TailKArgs {
     _Float16 *o3_hi, *o3_lo;           // optional: where to keep o3 (2 chunks) for the backward pass
     unsigned* flags;                   // device status word (BINHIP_STATUS_*), may be null
     int N, H, W, tiles_x, tiles_y, xcd_remap, wt;
+#if BINHIP_TIMELINE
+    void* tl;                          // side builds: see BhTl (binhip_conv_common.h)
+    unsigned tl_launch, tl_base;
+#endif
 };
 
 int bh_launch_tail_x3(const TailKArgs& a, hipStream_t s);     // binhip_fused_x3.hip (nterms = 3)

@@ -214,6 +214,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 rdb_tail_x3_kernel(const TailKArgs a, const float* __restrict__ bias_c, const float* __restrict__ bias_l) {
     // (the two biases again as the kernel's own restrict parameters: scalar loads in the epilogues, binhip_conv_common.h)
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    BH_TL_DECL;
+    BH_TL_BEGIN();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -276,6 +278,9 @@ rdb_tail_x3_kernel(const TailKArgs a, const float* __restrict__ bias_c, const fl
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+#if BINHIP_TIMELINE
+        if (c == 0) BH_TL_STAMP(1);
+#endif
         tx_issue_patch(a, smem, c, 1, wave, voff, plane_elems, plane_bytes);
         if (c + 1 < TX::NCHUNK) tx_issue_weights(a, smem, c + 1, (c + 1) & 1, wave, lane);
         else tx_issue_tailw(a, smem, wave, lane);                // weight buffer 0: chunk 10's, read for the last time in lo(10)
@@ -383,6 +388,7 @@ rdb_tail_x3_kernel(const TailKArgs a, const float* __restrict__ bias_c, const fl
         }
     }
     if (a.flags && __builtin_amdgcn_ballot_w64(sat != 0) != 0 && lane == 0) atomicOr(a.flags, BINHIP_FLAG_SATURATED);
+    BH_TL_STAMP(2);
 
     // ---- LFF epilogue: bias (the block input = RDB residual is already in the accumulators) -> 6 output planes -------
     ConvKArgs e;
@@ -393,6 +399,7 @@ rdb_tail_x3_kernel(const TailKArgs a, const float* __restrict__ bias_c, const fl
     e.relu = 0; e.has_res = 0; e.cout = 96; e.wt = a.wt;
     e.och_limit = 6; e.res_chunks = 0; e.mask_from = 0; e.y_cpg = 0; e.y_cpg_inv = 0; e.y_group_stride = 0; e.y_unshuf = 0;
     conv_epilogue<3, TX::R, 3, BINHIP_EPI_PLANES, false>(e, bias_l, accl, img, ty0 + wave * TX::R, tx0, 0, true, n, kg, plane_elems);
+    BH_TL_FINISH(a, blockIdx.x);
 }
 
 }  // namespace
@@ -403,6 +410,10 @@ int bh_launch_tail_x3(const TailKArgs& a0, hipStream_t s) {
     TailKArgs a = a0;
     a.tiles_x = (a.W + 31) / 32;
     a.tiles_y = (a.H + TX::TH - 1) / TX::TH;
+#if BINHIP_TIMELINE
+    a.tl = bh_tl_reserve((unsigned)(a.tiles_x * a.tiles_y * a.N), &a.tl_base);
+    a.tl_launch = (2u << 24) | (g_bh_tl_serial.fetch_add(1) & 0xFFFFFFu);      // kind 2 = the fused tail
+#endif
     rdb_tail_x3_kernel<<<dim3((unsigned)(a.tiles_x * a.tiles_y * a.N)), dim3(256), TX::LDS_BYTES, s>>>(a, a.bc, a.bl);
     BH_CHECK_LAUNCH();
     return 0;

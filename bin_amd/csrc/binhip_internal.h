@@ -74,7 +74,7 @@ void bh_prof_end(BinhipProfiler* pr, hipStream_t s);
 struct ConvKArgs;
 int bh_prepare_conv(const BhConvCall& c, ConvKArgs* out);
 // convs 0-2 of a residual dense block as three phases of one launch (binhip_conv_x3.hip); nterms = 3 only
-int bh_launch_rdb3_x3(const ConvKArgs* convs, unsigned* counter, unsigned* flags, unsigned epoch, int cus, hipStream_t s);
+int bh_launch_rdb3_x3(const ConvKArgs* convs, unsigned* flags, unsigned epoch, int cus, hipStream_t s);
 
 // weight gradients in two phases, so a plan can reduce several layers' partials with one launch
 #define BH_WGRAD_BATCH 8

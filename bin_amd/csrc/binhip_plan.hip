@@ -187,8 +187,9 @@ int binhip_rdn_forward(const BinRdnPlan* p, const float* const* inputs, float* o
                 ok3 = ok3 && ka[c].wt;
             }
             if (ok3) {
-                if ((rc = bh_launch_rdb3_x3(ka, sync_words + d, sync_words + 32, (unsigned)(d + 1), cus, s))) return rc;
-                done3 = true;
+                rc = bh_launch_rdb3_x3(ka, sync_words + 32, (unsigned)(d + 1), cus, s);
+                if (rc == 0) done3 = true;
+                else if (rc != BINHIP_E_SHAPE) return rc;          // E_SHAPE: not co-resident on this device -> per-conv launches
             }
         }
         for (int c = 0; c < (fuse ? C - 1 : C) && !done3; ++c) {

@@ -431,7 +431,6 @@ def _forward_streams(self, B, stage1_cache=None, input_events=None):
     nterms = {k: PRECISIONS[v.precision or default_precision()] for k, v in mods.items()}
     wkeys = {k: v._weights_key(nterms[k]) for k, v in mods.items()}     # (precision, device, generation, every parameter's version)
     stale = [v._wcache is None or v._wcache[0] != wkeys[k] for k, v in mods.items()]
-    wstamp = {k: hash(wkeys[k]) for k in mods}
     relayout_pending = any(stale)
     kw = {k: v.kernel_weights(nterms[k]) for k, v in mods.items()}       # relayouts (if any) on the main stream
     lib = L.lib()
@@ -526,7 +525,7 @@ def _forward_streams(self, B, stage1_cache=None, input_events=None):
             return rdn(si, k, *ins)
         # the weight set's state is part of the key (advisor r04): a cache dict that survives an optimizer step,
         # load_state_dict, set_precision or invalidate_kernel_weights() must miss, not serve the old weights' outputs
-        key = (k, wstamp[k]) + tuple(id(t) for t in ins)
+        key = (k, wkeys[k]) + tuple(id(t) for t in ins)      # the weight state itself, not its hash (advisor r05)
         touched.add(key)
         hit = stage1_cache.get(key)
         if hit is not None and all(a is b for a, b in zip(hit[1], ins)):

@@ -61,6 +61,17 @@ class BaseModel:
         self.is_train = opt["is_train"]
         # reference rule (base_model.py:11): any gpu_ids => 'cuda' (the process's current HIP device), else cpu
         self.device = torch.device("cpu" if opt["gpu_ids"] is None else "cuda")
+        # The reference's non-distributed default wraps the generator in nn.DataParallel over `gpu_ids` (bin_model.py:41-42; the
+        # shipped yml has gpu_ids: [2, 3] with dist: false).  Here a process drives ONE GPU: several ids without `dist` would
+        # silently train on one device at the full batch, so that is an error with the way out spelled out.
+        ids = opt["gpu_ids"]
+        if ids is not None and len(ids) > 1 and not opt["dist"]:
+            raise RuntimeError(
+                f"bin_amd: gpu_ids = {list(ids)} with dist = false asks for nn.DataParallel over {len(ids)} GPUs (reference "
+                "bin_model.py:41-42); this build runs one process per GPU over RCCL instead.  Launch\n"
+                f"  python -m torch.distributed.run --nnodes=1 --nproc-per-node={len(ids)} --master-addr 127.0.0.1 "
+                "-m bin_amd.train -opt <yml> --launcher pytorch\n"
+                "(each rank takes gpu_ids = [LOCAL_RANK], batch_size is per process), or list a single id.")
         self.optimizers = []
         self.schedulers = []
 

@@ -51,8 +51,10 @@ class _MultiPixelLossFn(torch.autograd.Function):
         grads = [None] * len(ts)
         # one launch covers every tensor that sits in one or two terms (all of bin_model's); further pairs of terms are added
         chunks = {k: [where[k][i:i + 2] for i in range(0, len(where[k]), 2)] for k in need}
-        if need:
-            for k, o in zip(need, ops.multi_pixel_loss_grad(ctx.kind, pairs, g, [(ts[k], chunks[k][0]) for k in need], ctx.eps)):
+        # (one launch writes at most LOSS_MAX_TERMS gradients: 13-24 pairs with both sides needing one exceed that — advisor r05)
+        for i0 in range(0, len(need), L.LOSS_MAX_TERMS):
+            part = need[i0:i0 + L.LOSS_MAX_TERMS]
+            for k, o in zip(part, ops.multi_pixel_loss_grad(ctx.kind, pairs, g, [(ts[k], chunks[k][0]) for k in part], ctx.eps)):
                 grads[k] = o
         for k in need:
             for w in chunks[k][1:]:
@@ -67,9 +69,11 @@ def multi_term_loss(criterion, pairs):
     kind = getattr(criterion, "kind", None)
     if os.environ.get("BIN_AMD_FUSED_LOSS", "1") == "0":          # diagnostics / A-B only: the per-term path it replaced
         kind = None
-    n = pairs[0][0].numel()
+    # fused only when it means what the per-term path means: every pair of ONE shape (equal numel with different shapes, or two
+    # devices, raised there and must not be summed silently here — advisor r05)
+    x0 = pairs[0][0]
     fusable = (kind is not None and len(pairs) <= L.LOSS_MAX_TERMS
-               and all(t.is_cuda and t.numel() == n for p in pairs for t in p))
+               and all(t.is_cuda and t.device == x0.device and t.shape == x0.shape for p in pairs for t in p))
     if not fusable:
         terms = [criterion(x, y) for x, y in pairs]
         return sum(terms) / len(terms), terms

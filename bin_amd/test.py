@@ -146,7 +146,8 @@ def main(argv=None, stats=None):
         clip0, frames0, index0 = windows[begin]
         for ahead in range(0, 3):
             if begin + ahead < end and windows[begin + ahead][0] == clip0:
-                for fid in harness.window_frame_ids(index0 + ahead, len(frames0)):
+                # (the window's OWN index: list_windows need not hand out consecutive indices — advisor r05)
+                for fid in harness.window_frame_ids(windows[begin + ahead][2], len(frames0)):
                     if (clip0, fid) not in early:
                         early[(clip0, fid)] = pool.submit(data_util.imread_u8, os.path.join(args.input_path, clip0, frames0[fid]))
 
@@ -154,18 +155,26 @@ def main(argv=None, stats=None):
     # hipHostMalloc costs 1-3 ms apiece, which the first ten windows used to pay in line
     stage_pool, stage_lock, pinned = [], threading.Lock(), []
 
+    first_early = next(iter(early.values()), None)
+
     def preallocate():
-        if not early:
-            return
-        first = next(iter(early.values())).result()
-        if first.ndim != 3 or first.shape[2] != 3:
-            return
-        for _ in range(12):
-            buf = torch.empty(first.shape, dtype=torch.uint8, pin_memory=True)
-            with stage_lock:
-                stage_pool.append(buf)
-        for _ in range(10):
-            pinned.append(torch.empty((3,) + tuple(first.shape), dtype=torch.uint8, pin_memory=True))
+        # best effort on a daemon thread: a failure here (unreadable first frame, no page-locked memory left) must be SAID — the
+        # pipeline then allocates its buffers in line as before round 5 — not die silently with the thread (advisor r05)
+        try:
+            if first_early is None:
+                return
+            first = first_early.result()
+            if first.ndim != 3 or first.shape[2] != 3:
+                return
+            for _ in range(12):
+                buf = torch.empty(first.shape, dtype=torch.uint8, pin_memory=True)
+                with stage_lock:
+                    stage_pool.append(buf)
+            for _ in range(10):
+                pinned.append(torch.empty((3,) + tuple(first.shape), dtype=torch.uint8, pin_memory=True))
+        except Exception as e:
+            logging.getLogger("base").warning("bin_amd.test: pre-allocation of the page-locked buffers skipped (%s: %s)",
+                                              type(e).__name__, e)
     prealloc = threading.Thread(target=preallocate, daemon=True)
     if torch.cuda.is_available():
         prealloc.start()
@@ -298,6 +307,8 @@ def main(argv=None, stats=None):
                 cur_clip = clip
                 decoded.clear(); frames_dev.clear(); stage1_cache.clear()
                 os.makedirs(os.path.join(result_root, clip), exist_ok=True)
+            if wi == begin + 3:
+                early.clear()            # the early decodes belong to the first three windows; whatever was not taken is dropped
             names = output_names(frames, index)
             clip_dir = os.path.join(result_root, clip)
             # who writes what follows from the GLOBAL window index alone, as in the serial reference loop: <num+12>
