@@ -442,7 +442,7 @@ def make_infer_step(precision="f16x3"):
 
 def max_over_ranks(dt, dev, world):
     """Slowest rank's time (the contract's max-over-ranks).  nccl (= RCCL) reduces on the device; the gloo hook used to run
-    the N > 1 flow on ONE GPU (tests/test_gpu_round3.py) reduces a host tensor."""
+    the N > 1 flow on ONE GPU (tests/test_gpu_dist.py) reduces a host tensor."""
     import torch.distributed as dist
     if world == 1:
         return dt

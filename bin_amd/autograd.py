@@ -9,7 +9,7 @@
 * `_ConvLstmFn` — ConvLSTMCell (RDN.py:50-95) forward/backward kernels.
 Training precision defaults to "f16x3" (fp32-class gradients, ~5e-6 relative vs torch autograd of the oracle).
 Training in "f16" (single fp16 product in forward AND backward) is NOT a supported mode: its forward's ~1e-3 activation error
-flips ReLU masks, and individual parameter gradients come out 1-25 % off (tests/test_gpu_backward.py only checks it to
+flips ReLU masks, and individual parameter gradients come out 1-25 % off (tests/test_gpu_train.py only checks it to
 2.5e-1).  Since round 4 it is GATED: a differentiable call of an RDN whose precision resolves to "f16" raises unless the
 module carries `allow_f16_training = True` (diagnostics / that test) — or none of its parameters requires a gradient (round 5:
 input-gradient-only calls warn once instead).  The supported speed/accuracy trade is

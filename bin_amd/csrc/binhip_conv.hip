@@ -820,6 +820,7 @@ int binhip_conv2d_bwd_data(const BinConvDesc* d, const void* gy_hi, const void* 
                            int y_cpg, int64_t y_group_stride, void* gx_hi, void* gx_lo, void* stream) {
     if (!d) return BINHIP_E_ARG;
     if (d->epilogue != BINHIP_EPI_PLANES) return BINHIP_E_ARG;
+    if (d->reserved < 0) return BINHIP_E_ARG;               // y_unshuf is a plane count
     BhConvCall c;
     c.d = *d;
     c.x_hi = gy_hi; c.x_lo = gy_lo; c.w_hi = wt_hi; c.w_lo = wt_lo; c.bias = zero_bias;
@@ -925,6 +926,10 @@ int binhip_conv2d_fwd(const BinConvDesc* d, const void* x_hi, const void* x_lo, 
                       const void* w_lo, const float* bias, const void* res_hi, const void* res_lo,
                       void* y_hi, void* y_lo, float* y_f32, const float* const* images, void* stream) {
     if (!d) return BINHIP_E_ARG;
+    // `reserved`: the one defined bit, and only where it is legal (the promise concerns the 5x5 layer's last chunk; a wrong promise
+    // would give wrong sums silently because the real cin is not in the descriptor) — advisor r05
+    if (d->reserved & ~BINHIP_CONV_HALF_LAST_CHUNK) return BINHIP_E_ARG;
+    if ((d->reserved & BINHIP_CONV_HALF_LAST_CHUNK) && d->ksize != 5) return BINHIP_E_ARG;
     BhConvCall c;
     c.d = *d;
     c.x_hi = x_hi; c.x_lo = x_lo; c.w_hi = w_hi; c.w_lo = w_lo; c.bias = bias;

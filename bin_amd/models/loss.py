@@ -27,7 +27,7 @@ class _MultiPixelLossFn(torch.autograd.Function):
     """bin_model.get_loss's whole arithmetic as ONE autograd node (round 5): T terms of one criterion and their mean in two
     launches, every gradient in one — instead of a pair of launches and an autograd node per term plus ~100 scalar ATen kernels
     for `sum(loss_list) / len(loss_list)` and its backward, all of which sat between the forward and the backward pass with the
-    chip idle.  Same reductions, same rounding order: bit-identical to the per-term path (tests/test_gpu_round5.py)."""
+    chip idle.  Same reductions, same rounding order: bit-identical to the per-term path (tests/test_gpu_loss.py)."""
 
     @staticmethod
     def forward(ctx, kind, eps, index_pairs, *tensors):

@@ -8,7 +8,7 @@ given set of weights runs — by reading the planes back out of a call's workspa
 magnitude, the smallest non-zero magnitude, and the share of values below the fp16 normal range.  The pretrained
 `adobe_bin.pth` is not available (model_weights/download_adobe_bin.txt:1 is a Drive link), so the numbers are taken on
 the synthetic initialisation and on weights after a number of real optimisation steps
-(tools/fp16_headroom.py -> profiles/r03_fp16_headroom.md; tests/test_gpu_round3.py asserts the headroom).
+(tools/fp16_headroom.py -> profiles/r03_fp16_headroom.md; tests/test_gpu_train.py asserts the headroom).
 """
 import ctypes as C
 

@@ -49,7 +49,7 @@ extern "C" {
 /* Interface version = what binhip_version() of a matching library returns (100 x round + revision); a binder checks
  * `binhip_version() == BINHIP_VERSION` after dlopen.  BINHIP_ABI_EXPORTS = number of BINHIP_API entry points below
  * (tests/test_cpu_host.py keeps it equal to the declarations and to `nm -D`). */
-#define BINHIP_VERSION 500
+#define BINHIP_VERSION 600
 #define BINHIP_ABI_EXPORTS 45
 
 #define BINHIP_E_ARG      (-1)   /* null pointer / bad enum */
@@ -97,11 +97,14 @@ typedef struct BinConvDesc {
                               /*   inverse PixelShuffle(2): full-resolution pixel (Y, X), chunk c goes to    */
                               /*   plane (2 (Y & 1) + (X & 1)) * y_unshuf + c at (Y / 2, X / 2) of a tensor  */
                               /*   of 4 * y_unshuf planes at H/2 x W/2 — what binhip_unshuffle_planes makes  */
-                              /*   of the plain result (H, W even, y_cpg = 0, 16 * y_unshuf >= cout).        */
-                              /* binhip_conv2d_fwd: BINHIP_CONV_HALF_LAST_CHUNK = the caller guarantees that     */
-                              /*   channels 8-15 of the LAST input chunk are zero in x and in the weights (cin %   */
-                              /*   16 in 1..8: SFENet1's 24 / 36 inputs) — the 5x5 fp32-class kernel then spends  */
-                              /*   that chunk's K on tap pairs; other kernels ignore it.  0 everywhere else.       */
+                              /*   of the plain result (H, W even, y_cpg = 0, 16 * y_unshuf >= cout); a      */
+                              /*   negative value is BINHIP_E_ARG.                                           */
+                              /* binhip_conv2d_fwd: BINHIP_CONV_HALF_LAST_CHUNK (ksize 5 only) = the caller        */
+                              /*   guarantees that input channels 8-15 of the LAST chunk are zero IN THE WEIGHTS   */
+                              /*   (cin % 16 in 1..8: SFENet1's 24 / 36 inputs; the relayout pads them with zeros) */
+                              /*   — the 5x5 fp32-class kernel then spends that chunk's K on tap pairs and never   */
+                              /*   reads x's channels 8-15 of it; other kernels ignore the bit.  Any other bit, or */
+                              /*   the bit with ksize != 5, is BINHIP_E_ARG.  0 everywhere else.                   */
     void*   status;           /* device uint32 status word (BINHIP_STATUS_*), OR-ed into; or NULL */
 } BinConvDesc;
 

@@ -1,5 +1,5 @@
 """RDN configurations other than bin_stage4's used by fixture g10_rdn_shapes (tests/golden/make_golden_shapes.py runs them on
-the reference's classes, tests/test_gpu_round3.py on bin_amd's): tag -> (input frames, (G0, D, C, G), N, H, W)."""
+the reference's classes, tests/test_gpu_net.py on bin_amd's): tag -> (input frames, (G0, D, C, G), N, H, W)."""
 CASES = {
     "rdn2_default_args": (2, (64, 6, 4, 32), 1, 32, 48),      # the classes' own default arguments (RDN.py:169-172)
     "rdn3_wide_growth": (3, (32, 2, 3, 64), 2, 16, 32),       # G = 64, odd C, G0 = 32

@@ -433,7 +433,7 @@ def test_video_base_model_training_step_matches_the_reference(tmp_path, case):
     g = load_golden("g13_videobase_step")
     ft, crit, method, pair = VC.CASES[case]
     # (the product's criteria are HIP kernels and refuse CPU tensors: here the criterion is the plain-torch statement of the
-    #  same formula, so this test pins the wrapper's own logic; tests/test_gpu_round5.py runs the same fixture on the device
+    #  same formula, so this test pins the wrapper's own logic; tests/test_gpu_train.py runs the same fixture on the device
     #  with the product's criteria)
     cri = {"cb": _Cb(), "l1": torch.nn.L1Loss(reduction="sum"), "l2": torch.nn.MSELoss(reduction="sum")}[crit]
     m = VideoBaseModel(VC.opt(tmp_path, ft, crit), netG=VC.StubVSR(), cri_pix=VC.PairCriterion(cri) if pair else cri)

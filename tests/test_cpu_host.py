@@ -105,6 +105,85 @@ def test_integration_doc_names_exist_in_the_header():
         assert any(e.startswith(name) for e in entries), f"INTEGRATION.md mentions {name}(), not in the ABI"
 
 
+def test_integration_doc_states_the_version_and_export_count_once_and_right():
+    """INTEGRATION.md carried 400 / 43 in one section and 500 / 45 in another: every number the document puts next to
+    BINHIP_VERSION / BINHIP_ABI_EXPORTS / "entry points" must be the header's, and the header's count must be the ABI's."""
+    import re
+    from bin_amd import build
+    hdr = open(os.path.join(REPO, "include", "binhip.h")).read()
+    doc = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    ver = int(re.search(r"#define\s+BINHIP_VERSION\s+(\d+)", hdr).group(1))
+    n = int(re.search(r"#define\s+BINHIP_ABI_EXPORTS\s+(\d+)", hdr).group(1))
+    assert n == len(build.abi_symbols())
+    near_ver = re.findall(r"BINHIP_VERSION`?[^.\n]{0,60}?\*{0,2}(\d{3})\*{0,2}", doc)
+    near_cnt = re.findall(r"BINHIP_ABI_EXPORTS`?[^.\n]{0,80}?\*{0,2}(\d{2})\*{0,2}", doc) + re.findall(r"(\d{2}) entry points", doc)
+    assert near_ver and all(int(v) == ver for v in near_ver), (near_ver, ver)
+    assert near_cnt and all(int(c) == n for c in near_cnt), (near_cnt, n)
+    design = open(os.path.join(REPO, "DESIGN.md")).read()
+    assert all(int(v) == ver for v in re.findall(r"BINHIP_VERSION`? (\d{3})", design))
+    assert all(int(c) == n for c in re.findall(r"(\d{2}) entry points", design))
+
+
+def test_several_gpu_ids_without_dist_raise_with_the_launch_recipe(tmp_path):
+    """The reference's default multi-GPU mode is nn.DataParallel over gpu_ids (bin_model.py:41-42; the shipped yml has gpu_ids:
+    [2, 3], dist: false).  One process per GPU cannot honour that silently on one device (VERDICT r05 missing 4)."""
+    from bin_amd.models.Video_base_model import VideoBaseModel
+    from bin_amd.models.bin_model import bin_model
+    opt = _opt(tmp_path)
+    opt["gpu_ids"] = [2, 3]
+    for cls in (bin_model, VideoBaseModel):
+        with pytest.raises(RuntimeError, match=r"torch\.distributed\.run --nnodes=1 --nproc-per-node=2"):
+            cls(opt, netG=torch.nn.Conv2d(3, 3, 1))
+    from bin_amd.models.base_model import BaseModel
+    opt["gpu_ids"] = [0]
+    assert BaseModel(opt).device.type == "cuda"          # one id: fine; several ids under dist: each rank has its own
+    opt["gpu_ids"], opt["dist"] = [0, 1], True
+    BaseModel(opt)
+
+
+def test_module_util_mirror_is_importable_and_shaped_like_the_reference():
+    """reference models/module_util.py:7-52 — names, constructor arguments, state_dict keys; the forward has no CPU path."""
+    from bin_amd.models import module_util as MU
+    blk = MU.ResidualBlock_noBN(nf=16)
+    assert sorted(blk.state_dict()) == ["conv1.bias", "conv1.weight", "conv2.bias", "conv2.weight"]
+    assert blk.conv1.weight.shape == (16, 16, 3, 3) and float(blk.conv2.bias.abs().max()) == 0.0
+    assert float(blk.conv1.weight.std()) < 0.05           # kaiming-normal x 0.1 (module_util.py:47)
+    seq = MU.make_layer(lambda: MU.ResidualBlock_noBN(8), 3)
+    assert len(seq) == 3 and len({id(m) for m in seq}) == 3
+    lin = torch.nn.Linear(4, 4)
+    bn = torch.nn.BatchNorm2d(4)
+    MU.initialize_weights([lin, bn], scale=2.0)
+    assert float(lin.bias.abs().max()) == 0.0 and float(bn.weight.min()) == 1.0
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        blk(torch.zeros(1, 16, 4, 4))
+
+
+def test_bench_step_spread_and_cycle_fields():
+    import bench
+    sp = bench.step_spread([10.0, 10.2, 9.9, 31.0, 10.1])
+    assert sp == {"ms_min": 9.9, "ms_median": 10.1, "ms_max": 31.0, "max_over_median": round(31.0 / 10.1, 4), "steps": 5}
+    assert bench.step_spread([]) is None and bench.step_spread([2.0, 4.0])["ms_median"] == 3.0
+    cf = bench.clock_fields(70.0, {"xcd_clock_mhz": {"mean": 1800.0}, "clock_mhz": {"mean": 1850.0}})
+    assert cf["cycles_per_step_M"] == 126.0 and cf["xcd_clock_mhz_mean"] == 1800.0 and "per-XCD" in cf["cycles_clock"]
+    cf = bench.clock_fields(70.0, {"clock_mhz": {"mean": 2000.0}})
+    assert cf["cycles_per_step_M"] == 140.0 and "XCD 0" in cf["cycles_clock"]
+    assert bench.clock_fields(70.0, None)["cycles_per_step_M"] is None
+
+
+def test_trained_like_weights_have_the_advertised_distribution():
+    from bin_amd.weights import canonical_weights, state_dict_from_canonical, reference_state_dict, trained_like_weights
+    w = trained_like_weights(0)
+    base = canonical_weights(0)
+    assert list(w) == list(base) and all(w[k].shape == base[k].shape and w[k].dtype == np.float32 for k in w)
+    conv = np.concatenate([np.abs(v).ravel() for k, v in w.items() if k.endswith(".weight") and ".Gates." not in k])
+    nz = conv[conv > 0]
+    assert 0.29 < 1 - nz.size / conv.size < 0.31
+    assert nz.min() < 1e-4 and nz.max() > 1.0 and (nz < 0.125).mean() > 0.9
+    assert all(float(np.abs(v).max()) == 0.0 for k, v in w.items() if k.endswith(".bias") and ".Gates." not in k)
+    a, b = state_dict_from_canonical(base), reference_state_dict(0)
+    assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a)
+
+
 def test_library_host_queries():
     from bin_amd import _lib
     lib = _lib.lib()

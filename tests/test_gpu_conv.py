@@ -1,0 +1,510 @@
+"""-m gpu: the convolution kernels through the C ABI — layouts, pixel-unshuffle packer, every conv epilogue (planes / PixelShuffle / final), the fused dense-block tail, the one-launch dense block, backward-data variants, SFENet1 tap pairs, weight relayout, the status word — against the reference-generated fixtures (tests/golden) and float64."""
+import hashlib
+import json
+import os
+import socket
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+CONVS_OPS = {
+    "k2_sfe1_24": ("model1.SFENet1", 5), "k2_sfe1_36": ("model2.SFENet1", 5), "k2_sfe1_60": ("model3.SFENet1", 5),
+    "k3_sfe2": ("model1.SFENet2", 3),
+    "k4_rdbconv0": ("model1.RDBs.0.convs.0.conv.0", 3), "k4_rdbconv1": ("model1.RDBs.0.convs.1.conv.0", 3),
+    "k4_rdbconv2": ("model1.RDBs.0.convs.2.conv.0", 3), "k4_rdbconv3": ("model1.RDBs.0.convs.3.conv.0", 3),
+    "k5_lff": ("model1.RDBs.0.LFF", 1), "k6_gff0": ("model1.GFF.0", 1),
+}
+
+
+TOL_OPS = {1: 2e-3, 3: 2e-5}
+
+
+def _rel_ops(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-6))
+
+
+@pytest.mark.parametrize("nterms", [3, 1])
+def test_layout_roundtrip(nterms):
+    from bin_amd import ops
+    x = torch.randn(2, 37, 9, 13, device="cuda")
+    cp = ops.nchw_to_planes(x, nterms)
+    assert cp.hi.shape == (3, 2, 9, 13, 16)
+    y = ops.planes_to_nchw(cp)
+    tol = 1e-6 if nterms == 3 else 1e-3
+    assert float((x - y).abs().max()) <= tol * float(x.abs().max())
+
+
+def test_pixel_reshuffle_function_exact():
+    """The module-level pixel_reshuffle (API parity with reference RDN.py:107-132) is an exact permutation."""
+    from bin_amd.models.archs.RDN import pixel_reshuffle
+    g = load_golden("g1_pixel_reshuffle")
+    assert torch.equal(pixel_reshuffle(torch.from_numpy(g["x"]).cuda(), 2).cpu(), torch.from_numpy(g["y"]))
+    x = torch.randn(2, 5, 12, 18)
+    assert torch.equal(pixel_reshuffle(x.cuda(), 3).cpu(), torch.nn.functional.pixel_unshuffle(x, 3))
+
+
+@pytest.mark.parametrize("nterms", [3, 1])
+def test_pixel_reshuffle_pack(nterms):
+    """K1 against the reference's own pixel_reshuffle output (g1_pixel_reshuffle) — 6 = 2 frames x 3."""
+    from bin_amd import ops
+    g = load_golden("g1_pixel_reshuffle")
+    x = torch.from_numpy(g["x"]).cuda()
+    y = ops.planes_to_nchw(ops.pack_inputs([x[:, :3], x[:, 3:]], nterms), 24)
+    ref = torch.from_numpy(g["y"]).cuda()
+    assert float((y - ref).abs().max()) <= (1e-6 if nterms == 3 else 2e-3) * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("nterms", [3, 1])
+@pytest.mark.parametrize("key", sorted(CONVS_OPS))
+def test_conv_forward_golden(key, nterms, canon_gpu):
+    from bin_amd import ops
+    g = load_golden("g1_convs")
+    wname, ks = CONVS_OPS[key]
+    x = torch.from_numpy(g[key + ".x"]).cuda()
+    ref = torch.from_numpy(g[key + ".y"]).cuda()
+    cw = ops.ConvWeights(canon_gpu[wname + ".weight"], canon_gpu[wname + ".bias"], nterms=nterms)
+    y = ops.planes_to_nchw(ops.conv2d(ops.nchw_to_planes(x, nterms), cw), cw.cout)
+    assert y.shape == ref.shape
+    assert _rel_ops(y, ref) <= TOL_OPS[nterms], (key, _rel_ops(y, ref))
+
+
+@pytest.mark.parametrize("nterms", [3, 1])
+def test_conv_shuffle_golden(nterms, canon_gpu):
+    """K8: conv 96->256 + PixelShuffle(2) fused store vs F.pixel_shuffle of the reference conv output."""
+    from bin_amd import ops
+    g = load_golden("g1_convs")
+    x = torch.from_numpy(g["k8_up0.x"]).cuda()
+    ref = torch.nn.functional.pixel_shuffle(torch.from_numpy(g["k8_up0.y"]).cuda(), 2)
+    cw = ops.ConvWeights(canon_gpu["model1.UPNet.0.weight"], canon_gpu["model1.UPNet.0.bias"], nterms=nterms,
+                         shuffle=True)
+    from bin_amd import _lib as L
+    y = ops.planes_to_nchw(ops.conv2d(ops.nchw_to_planes(x, nterms), cw, epilogue=L.EPI_SHUFFLE), 64)
+    assert y.shape == ref.shape
+    assert _rel_ops(y, ref) <= TOL_OPS[nterms]
+
+
+@pytest.mark.parametrize("nterms", [3, 1])
+@pytest.mark.parametrize("nimg", [0, 2, 3, 5])
+def test_conv_final_golden(nterms, nimg, canon_gpu):
+    """K9: conv 64->3 + mean(inputs) -> fp32 NCHW."""
+    from bin_amd import ops, _lib as L
+    g = load_golden("g1_convs")
+    x = torch.from_numpy(g["k9_up2.x"]).cuda()
+    ref = torch.from_numpy(g["k9_up2.y"]).cuda()
+    imgs = [torch.rand_like(ref) for _ in range(nimg)]
+    if nimg:
+        s = imgs[0]
+        for t in imgs[1:]:
+            s = s + t
+        ref = ref + s / nimg
+    cw = ops.ConvWeights(canon_gpu["model1.UPNet.2.weight"], canon_gpu["model1.UPNet.2.bias"], nterms=nterms)
+    y = ops.conv2d(ops.nchw_to_planes(x, nterms), cw, epilogue=L.EPI_FINAL, images=imgs)
+    assert y.shape == ref.shape
+    assert _rel_ops(y, ref) <= TOL_OPS[nterms]
+
+
+@pytest.mark.parametrize("nterms", [3, 1])
+@pytest.mark.parametrize("shape", [(1, 1, 1), (1, 7, 5), (2, 33, 65), (1, 40, 100), (3, 17, 31)])
+@pytest.mark.parametrize("ks,cin,cout,relu,res", [(3, 96, 32, True, False), (3, 96, 96, False, True),
+                                                  (1, 224, 96, False, True), (5, 36, 96, False, False),
+                                                  (3, 64, 64, True, True)])
+def test_conv_vs_oracle_ragged(nterms, shape, ks, cin, cout, relu, res):
+    """Ragged / tiny / multi-batch shapes (partial tiles on every side) vs plain F.conv2d in fp64."""
+    from bin_amd import ops
+    n, h, w = shape
+    gen = torch.Generator(device="cpu").manual_seed(h * 1000 + w + ks)
+    x = torch.randn(n, cin, h, w, generator=gen)
+    wt = torch.randn(cout, cin, ks, ks, generator=gen) / (cin * ks * ks) ** 0.5
+    b = torch.randn(cout, generator=gen)
+    r = torch.randn(n, cout, h, w, generator=gen) if res else None
+    ref = torch.nn.functional.conv2d(x.double(), wt.double(), b.double(), padding=ks // 2)
+    if res:
+        ref = ref + r.double()
+    if relu:
+        ref = ref.relu()
+    cw = ops.ConvWeights(wt.cuda(), b.cuda(), nterms=nterms)
+    y = ops.conv2d(ops.nchw_to_planes(x.cuda(), nterms), cw, relu=relu,
+                   residual=ops.nchw_to_planes(r.cuda(), nterms) if res else None)
+    y = ops.planes_to_nchw(y, cout).cpu().double()
+    assert _rel_ops(y, ref) <= TOL_OPS[nterms]
+
+
+@pytest.mark.parametrize("nterms", [3, 1])
+def test_resblock_nobn_golden(nterms):
+    """`bin_amd.models.module_util.ResidualBlock_noBN(64)` (reference module_util.py:35-52, dead code there) against
+    the reference module's own output: the importable mirror, its state_dict keys, the no-grad path on the fused conv epilogues and
+    the autograd path (gradients vs torch autograd of the same block in float64)."""
+    from bin_amd.models.module_util import ResidualBlock_noBN, initialize_weights, make_layer
+    g = load_golden("g5_resblock")
+    blk = ResidualBlock_noBN(64, precision="f16x3" if nterms == 3 else "f16")
+    assert sorted(blk.state_dict()) == ["conv1.bias", "conv1.weight", "conv2.bias", "conv2.weight"]
+    blk.load_state_dict({"conv1.weight": torch.from_numpy(g["w1"]), "conv1.bias": torch.from_numpy(g["b1"]),
+                         "conv2.weight": torch.from_numpy(g["w2"]), "conv2.bias": torch.from_numpy(g["b2"])}, strict=True)
+    blk = blk.cuda()
+    x = torch.from_numpy(g["x"]).cuda()
+    ref = torch.from_numpy(g["y"]).cuda()
+    with torch.no_grad():
+        y = blk(x)
+    assert _rel_ops(y, ref) <= TOL_OPS[nterms]
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        blk(x.cpu())
+    if nterms == 3:
+        xg = x.clone().requires_grad_(True)
+        yg = blk(xg)                                                   # parameters require grad: the differentiable path
+        assert _rel_ops(yg.detach(), ref) <= TOL_OPS[3]
+        go = torch.randn(yg.shape, generator=torch.Generator().manual_seed(3)).cuda()
+        yg.backward(go)
+        F = torch.nn.functional
+        xd = x.double().requires_grad_(True)
+        wd = [p.detach().double().requires_grad_(True) for p in (blk.conv1.weight, blk.conv1.bias, blk.conv2.weight, blk.conv2.bias)]
+        yd = xd + F.conv2d(F.relu(F.conv2d(xd, wd[0], wd[1], padding=1)), wd[2], wd[3], padding=1)
+        yd.backward(go.double())
+        assert _rel_ops(xg.grad.double(), xd.grad) <= 1e-4
+        for p, q in zip((blk.conv1.weight, blk.conv1.bias, blk.conv2.weight, blk.conv2.bias), wd):
+            assert _rel_ops(p.grad.double(), q.grad) <= 1e-4
+    # make_layer / initialize_weights (module_util.py:7-32)
+    seq = make_layer(lambda: ResidualBlock_noBN(32), 2)
+    assert len(seq) == 2 and seq[0] is not seq[1]
+    initialize_weights(seq, scale=0.5)
+    assert float(seq[0].conv1.bias.abs().max()) == 0.0 and 0.0 < float(seq[1].conv2.weight.std()) < 0.1
+
+
+def test_conv2d_reserved_bits_are_validated():
+    """BinConvDesc.reserved (advisor r05): binhip_conv2d_fwd knows ONE bit and only for 5x5 layers; binhip_conv2d_bwd_data takes a
+    plane count (>= 0).  Anything else is BINHIP_E_ARG, not silence."""
+    import ctypes as C
+    from bin_amd import _lib as L, ops
+    lib = L.lib()
+    x = ops.nchw_to_planes(torch.rand(1, 16, 8, 32).cuda(), 3)
+    w3 = ops.ConvWeights(torch.rand(32, 16, 3, 3).cuda() * 0.1, torch.zeros(32).cuda(), nterms=3)
+    y = ops.CP.empty(2, 1, 8, 32, 3, x.hi.device)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+
+    def fwd(ks, reserved, cw):
+        d = L.BinConvDesc(N=1, H=8, W=32, ksize=ks, cin_chunks=1, cout=32, cout_pad=32, nterms=3, epilogue=L.EPI_PLANES, relu=0,
+                          x_cpg=0, x_group_stride=0, n_images=0, reserved=reserved, status=None)
+        return lib.binhip_conv2d_fwd(C.byref(d), p(x.hi), p(x.lo), p(cw.w_hi), p(cw.w_lo), p(cw.bias), None, None, p(y.hi), p(y.lo),
+                                     None, None, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert fwd(3, 0, w3) == 0
+    assert fwd(3, L.CONV_HALF_LAST_CHUNK, w3) < 0          # the promise concerns the 5x5 layer only
+    assert fwd(3, 2, w3) < 0 and fwd(3, -1, w3) < 0         # unknown bits
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "f16"])
+def test_fused_rdb_tail_equals_unfused(prec, canon_gpu):
+    """binhip_rdb_tail_fwd (conv #3 + LFF + residual in one kernel) vs the two-kernel path: identical up to fp32
+    summation order (the fused kernel adds the residual x inside the K-loop as an identity MFMA, the unfused one in the
+    epilogue), and bit-identical with / without keeping o3 for the backward pass."""
+    from bin_amd import _lib as L, rdn_plan
+    from bin_amd.models.archs.RDN import PRECISIONS
+    from bin_amd.rdn_plan import RdnWeights, rdn_forward
+    g = torch.Generator().manual_seed(21)
+    for (n, h, w) in ((1, 64, 96), (2, 40, 72)):
+        ins = [torch.rand(n, 3, h, w, generator=g).cuda() for _ in range(3)]
+        wts = RdnWeights(canon_gpu, 3, PRECISIONS[prec], prefix="model2.")
+        a = rdn_forward(wts, ins, flags=0)
+        b = rdn_forward(wts, ins, flags=L.PLAN_NO_FUSE)
+        c = rdn_forward(wts, ins, flags=L.PLAN_KEEP_ACTS)
+        assert torch.equal(a, c)
+        tol = 2e-6 if prec == "f16x3" else 1.5e-3          # f16: 1-ulp fp16 storage differences propagate
+        assert float((a - b).abs().max()) <= tol * float(b.abs().max())
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+# ------------------------------------------------------------------------------------------------ dense block, per-op ABI
+@pytest.mark.parametrize("nterms,tol_y,tol_g", [(3, 2e-6, 3e-5), (1, 2e-3, 2.5e-1)])
+def test_rdb_block_forward_and_gather_backward_golden(nterms, tol_y, tol_g, canon_gpu):
+    """RDB(96, 32, 4) of model1 on the reference's own fixture (g2_rdb: x, y, gy -> gx and all ten parameter
+    gradients from the reference module's autograd).  Forward = three plane-concat convs + the fused tail; backward =
+    the launch sequence of binhip_plan.hip's dense-block section issued op by op through the C ABI: LFF wgrad/dgrad,
+    then per conv its wgrad and the GATHER-form backward-data (every concat group written once).
+    nterms = 1 (single fp16 product, the inference mode): ~1e-3 operand rounding in the forward flips ~0.3 % of the ReLU
+    masks, which on this white-noise upstream gradient costs up to ~20 % on individual weight-gradient tensors (same
+    bar as tests/test_gpu_train.py::test_rdn_backward_vs_oracle_autograd[f16]); training defaults to nterms = 3."""
+    from bin_amd import ops
+    g = load_golden("g2_rdb")
+    pre = "model1.RDBs.0."
+    x = torch.from_numpy(g["x"]).cuda()
+    gy = torch.from_numpy(g["gy"]).cuda()
+    n, _, h, w = x.shape
+    W = [canon_gpu[f"{pre}convs.{c}.conv.0.weight"] for c in range(4)]
+    Bc = [canon_gpu[f"{pre}convs.{c}.conv.0.bias"] for c in range(4)]
+    WL, BL = canon_gpu[pre + "LFF.weight"], canon_gpu[pre + "LFF.bias"]
+    cw = [ops.ConvWeights(W[c], Bc[c], nterms=nterms) for c in range(4)]
+    cwl = ops.ConvWeights(WL, BL, nterms=nterms)
+    # ---- forward (RDN.py:135-165): blk planes 0-5 = x, conv c writes planes 6+2c, 7+2c, the tail keeps o3 in 12, 13
+    blk = ops.CP.empty(14, n, h, w, nterms, x.device)
+    xin = ops.nchw_to_planes(x, nterms)
+    blk.hi[0:6].copy_(xin.hi)
+    if nterms == 3:
+        blk.lo[0:6].copy_(xin.lo)
+    for c in range(3):
+        ops.conv2d(blk, cw[c], relu=True, out=blk.sub(6 + 2 * c, 2), cin_chunks=6 + 2 * c)
+    y = ops.planes_to_nchw(ops.rdb_tail(blk, cw[3], cwl, store_o3=True), 96)
+    ref_y = torch.from_numpy(g["y"]).cuda()
+    assert _rel(y, ref_y) <= tol_y
+    # ---- backward (autograd of the same lines), gather form
+    gyp = ops.nchw_to_planes(gy, nterms)
+    dWL, dbL = ops.conv2d_bwd_weight(blk, gyp, 96, 224, 1, nterms)
+    gcat = ops.conv2d_bwd_data(gyp, ops.DgradWeights(WL, nterms), res=gyp, res_chunks=6, mask=blk, mask_from=12)
+    assert gcat.hi.shape[0] == 14
+    grads = {}
+    gx = None
+    for c in (3, 2, 1, 0):
+        gyc = gcat.sub(6 + 2 * c, 2 * (4 - c))                     # stacked output gradients of convs c..3
+        grads[c] = ops.conv2d_bwd_weight(blk, gyc, 32, 96 + 32 * c, 3, nterms)
+        gw = ops.RdbGatherWeights(W, c, nterms)
+        if c > 0:
+            slot = gcat.sub(4 + 2 * c, 2)                          # conv c-1's output slot: G_{c-1} = relu'(L_c + sum dgrads)
+            ops.conv2d_bwd_data(gyc, gw, res=slot, mask=blk.sub(4 + 2 * c, 2), mask_from=0, out=slot)
+        else:
+            gx = ops.planes_to_nchw(ops.conv2d_bwd_data(gyc, gw, res=gcat.sub(0, 6)), 96)
+    torch.cuda.synchronize()
+    ops.check_status()
+    assert _rel(gx, torch.from_numpy(g["gx"]).cuda()) <= tol_g, "block input gradient"
+    assert _rel(dWL, torch.from_numpy(g["g.LFF.weight"]).cuda()) <= tol_g
+    assert _rel(dbL, torch.from_numpy(g["g.LFF.bias"]).cuda()) <= tol_g
+    for c in range(4):
+        assert _rel(grads[c][0], torch.from_numpy(g[f"g.convs.{c}.conv.0.weight"]).cuda()) <= tol_g, c
+        assert _rel(grads[c][1], torch.from_numpy(g[f"g.convs.{c}.conv.0.bias"]).cuda()) <= tol_g, c
+
+
+def test_concurrent_host_threads_share_the_library():
+    """include/binhip.h: the library holds no mutable process-global state, entry points are re-entrant.  Two host
+    threads run forwards of two independent networks on their own streams at the same time; each result equals the
+    serial one bit for bit."""
+    from bin_amd.models.archs.RDN import bin_stage4_lstm
+    from bin_amd.weights import reference_state_dict, synthetic_frames
+    nets, frames, serial = [], [], []
+    for i, prec in enumerate(("f16x3", "f16")):
+        net = bin_stage4_lstm()
+        net.load_state_dict(reference_state_dict(0), strict=True)
+        nets.append(net.cuda().eval().set_precision(prec))
+        frames.append([f.cuda() for f in synthetic_frames(40 + i, 1, 64, 64, 6)])
+    with torch.no_grad():
+        for net, fr in zip(nets, frames):
+            serial.append([o.clone() for o in net(*fr)])
+    torch.cuda.synchronize()
+    results, errors = [None, None], []
+
+    def work(i):
+        try:
+            s = torch.cuda.Stream()
+            with torch.no_grad(), torch.cuda.stream(s):
+                for _ in range(3):
+                    out = nets[i](*frames[i])
+                s.synchronize()
+            results[i] = out
+        except Exception as e:       # surfaced below
+            errors.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors
+    for i in range(2):
+        for a, b in zip(results[i], serial[i]):
+            assert torch.equal(a, b)
+
+
+def test_three_phase_dense_block_launch_is_bit_identical(canon_gpu):
+    """BINHIP_PLAN_RDB3 (opt-in): convs 0-2 of every dense block as three phases of ONE launch — (phase, tile) items from an
+    atomic work queue, per-tile neighbour flags instead of kernel boundaries, write-through stores + drained flag for
+    cross-XCD visibility.  Must return the per-launch path's bits on ragged and multi-image shapes, repeatedly and while
+    another stream loads the chip unevenly, and must never trip the bounded-spin status bit."""
+    from bin_amd import _lib as L, ops
+    from bin_amd.rdn_plan import RdnWeights, rdn_forward
+    ops.check_status()
+    g = torch.Generator().manual_seed(5)
+    wts = RdnWeights(canon_gpu, 3, 3, prefix="model2.")
+    noise = torch.randn(2048, 2048, device="cuda")
+    side = torch.cuda.Stream()
+    for (n, h, w) in ((1, 64, 96), (2, 40, 72), (3, 130, 190), (1, 384, 672)):
+        ins = [torch.rand(n, 3, h, w, generator=g).cuda() for _ in range(3)]
+        ref = rdn_forward(wts, ins, flags=0).clone()
+        for rep in range(4):
+            if rep >= 2:
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        noise @ noise
+            out = rdn_forward(wts, ins, flags=L.PLAN_RDB3)
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref), (n, h, w, rep)
+        ops.check_status()
+
+
+# ------------------------------------------------------------------------------------------------ status word
+def test_status_word_timeout_and_unknown_bits_raise():
+    from bin_amd import ops, _lib as L
+    dev = torch.device("cuda")                            # no index: means the current device (as in status_word)
+    w = ops.status_word(dev)
+    assert w is ops.status_word(torch.device("cuda", torch.cuda.current_device()))
+    ops.check_status(dev)                                 # clean word: no error
+    w.fill_(L.STATUS_SYNC_TIMEOUT)
+    with pytest.raises(RuntimeError, match="timed out waiting for a neighbour"):
+        ops.check_status(dev)
+    assert int(w.item()) == 0                             # reset by the check
+    w.fill_(L.STATUS_SYNC_TIMEOUT | L.STATUS_SATURATED)
+    with pytest.raises(RuntimeError, match="timed out"):
+        ops.check_status()
+    w.fill_(64)
+    with pytest.raises(RuntimeError, match="unknown status bits 0x40"):
+        ops.check_status(dev)
+    w.fill_(L.STATUS_SATURATED)
+    with pytest.raises(RuntimeError, match="fp16 range exceeded"):
+        ops.check_status(torch.device("cuda"))
+    ops.check_status()
+
+
+# ------------------------------------------------------------------------------------------------ batched relayout
+def test_batched_relayout_equals_per_layer_relayout(canon_gpu):
+    """binhip_weights_relayout_batch (66 forward + 66 backward layouts of a weight set in a few launches) writes the same
+    bytes as the per-layer entry points."""
+    import ctypes as C
+    from bin_amd import ops, _lib as L
+    from bin_amd.rdn_plan import RdnWeights, RdnDgradWeights, layer_names
+    params = {k[len("model1."):]: v for k, v in canon_gpu.items() if k.startswith("model1.")}
+    for nt in (3, 1):
+        fw = RdnWeights(params, 2, nt)                                  # batched
+        bw = RdnDgradWeights(params, 2, nt)
+        lib = L.lib()
+        for i, nm in enumerate(layer_names()):
+            w, b = params[nm + ".weight"], params[nm + ".bias"]
+            one = ops.ConvWeights(w, b, nterms=nt, shuffle=nm == "UPNet.0", cin_chunks=2 if nm == "SFENet1" else None)
+            assert torch.equal(one.w_hi, fw.layers[i].w_hi) and torch.equal(one.bias, fw.layers[i].bias), nm
+            assert nt == 1 or torch.equal(one.w_lo, fw.layers[i].w_lo), nm
+            if ".convs." in nm:
+                d, g = int(nm.split(".")[1]), int(nm.split(".")[3])
+                ref = ops.RdbGatherWeights([params[f"RDBs.{d}.convs.{c}.conv.0.weight"] for c in range(4)], g, nt)
+            else:
+                ref = ops.DgradWeights(w, nterms=nt, shuffle=nm == "UPNet.0")
+            assert torch.equal(ref.w_hi, bw.w_hi[i]), nm
+            assert nt == 1 or torch.equal(ref.w_lo, bw.w_lo[i]), nm
+    null = C.c_void_p(0)
+    assert lib.binhip_weights_relayout_batch(None, 1, null) == -1
+    bad = L.BinRelayoutItem()
+    assert lib.binhip_weights_relayout_batch(C.byref(bad), 1, null) == -1
+
+
+# ------------------------------------------------------------------------------------------------ per-op tests of the round-4 device paths
+# (advisor r04: the LFF backward-data epilogue instantiation, the fused inverse-PixelShuffle store and final_m16_kernel were only
+#  exercised through whole-RDN tests at 32x48 and the 720p golden).  Shapes: N = 2, 18 x 44 — partial 16 x 32 tiles in both dimensions.
+def _planes(t, nt=3):
+    from bin_amd import ops
+    return ops.nchw_to_planes(t, nt)
+
+
+def test_bwd_data_fused_inverse_pixelshuffle_equals_the_two_pass_form():
+    """UPNet.2's backward-data (64 <- 3 channels, 3x3, at full resolution) storing straight through the inverse PixelShuffle
+    (`BinConvDesc.reserved` = y_unshuf = 4 chunks per sub-position) == the plain backward-data followed by
+    binhip_unshuffle_planes, bit for bit — both precisions, N > 1, ragged tiles."""
+    import ctypes as C
+    from bin_amd import _lib as L, ops
+    g = torch.Generator().manual_seed(91)
+    n, h, w = 2, 18, 44
+    wt = ((torch.rand(3, 64, 3, 3, generator=g) - 0.5) / 8).cuda()
+    gy = (torch.rand(n, 3, h, w, generator=g) - 0.5).cuda()
+    for nt in (3, 1):
+        dgw = ops.DgradWeights(wt, nterms=nt)
+        gp = _planes(gy, nt)
+        plain = ops.conv2d_bwd_data(gp, dgw)                                  # 4 chunks at h x w
+        two = ops.CP.empty(16, n, h // 2, w // 2, nt, gy.device)
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        L.check(L.lib().binhip_unshuffle_planes(p(plain.hi), p(plain.lo), n, h // 2, w // 2, 4, p(two.hi), p(two.lo),
+                                                C.c_void_p(torch.cuda.current_stream().cuda_stream)), "unshuffle_planes")
+        fused = ops.conv2d_bwd_data(gp, dgw, y_unshuf=4)
+        assert tuple(fused.hi.shape) == (16, n, h // 2, w // 2, 16)
+        assert torch.equal(fused.hi, two.hi), nt
+        if nt == 3:
+            assert torch.equal(fused.lo, two.lo)
+        # and the values: conv_transpose of gy, un-shuffled (channel order of UPNet.0's permuted rows = pixel_unshuffle's)
+        ref = torch.nn.functional.conv_transpose2d(gy.double(), wt.double(), padding=1)
+        got = ops.planes_to_nchw(plain, 64).double()
+        assert float((got - ref).abs().max()) <= (2e-6 if nt == 3 else 2e-3) * float(ref.abs().max())
+
+
+def test_lff_backward_data_epilogue_instantiation_vs_float64():
+    """The LFF 1x1 backward-data tile with its own epilogue (EPI_PLANES_LFFD: residual on the first 6 chunks, ReLU mask from
+    chunk 12, 14 output chunks) — the call pattern binhip_plan.hip issues per dense block — against the same arithmetic in fp64:
+        gcat = W^T gy ;  gcat[:, :96] += gy ;  gcat[:, 192:] *= (act[:, 192:] > 0)."""
+    from bin_amd import ops
+    g = torch.Generator().manual_seed(92)
+    n, h, w = 2, 18, 44
+    wt = ((torch.rand(96, 224, 1, 1, generator=g) - 0.5) / 6).cuda()
+    gy = (torch.rand(n, 96, h, w, generator=g) - 0.5).cuda()
+    act = (torch.rand(n, 224, h, w, generator=g) - 0.4).cuda()                 # ~40 % of the masked channels are <= 0
+    gp, ap = _planes(gy), _planes(act)
+    dgw = ops.DgradWeights(wt, nterms=3)
+    out = ops.conv2d_bwd_data(gp, dgw, res=gp, res_chunks=6, mask=ap, mask_from=12)
+    got = ops.planes_to_nchw(out, 224).double()
+    gyq = ops.planes_to_nchw(gp, 96).double()                                  # what the kernel really read (hi + lo)
+    ref = torch.nn.functional.conv_transpose2d(gyq, wt.double())
+    ref[:, :96] += gyq
+    ref[:, 192:] *= (ops.planes_to_nchw(ops.CP(ap.hi, None, 224), 224)[:, 192:] > 0)      # the mask reads the hi plane
+    assert float((got - ref).abs().max()) <= 3e-6 * float(ref.abs().max())
+    assert float(got[:, 192:][ref[:, 192:] == 0].abs().max()) == 0.0          # masked means exactly zero
+    # the generic extras path (same call without the mask: a different instantiation) agrees on the unmasked chunks
+    nomask = ops.planes_to_nchw(ops.conv2d_bwd_data(gp, dgw, res=gp, res_chunks=6), 224).double()
+    assert torch.equal(nomask[:, :192], got[:, :192])
+
+
+@pytest.mark.parametrize("cin,nimg", [(64, 2), (64, 5), (80, 3)])
+def test_final_m16_kernel_vs_float64(cin, nimg):
+    """UPNet.2 of the fp32-class mode (`final_m16_kernel`: 16x16x32 MFMA with tap pairs, 3 output channels + the mean of the
+    input frames) at N = 2 on ragged tiles with 2 / 5 frames; and a FINAL conv with FIVE input chunks, which does not fit that
+    kernel's LDS-resident weight slab (40 taps = 4 chunks) and must take the 32-row tile — this case found the round-4 guard
+    (`nchunks <= 5`) silently dropping taps 40-44."""
+    from bin_amd import _lib as L, ops
+    g = torch.Generator().manual_seed(93 + cin + nimg)
+    n, h, w = 2, 18, 44
+    wt = ((torch.rand(3, cin, 3, 3, generator=g) - 0.5) / 10).cuda()
+    b = (torch.rand(3, generator=g) - 0.5).cuda()
+    x = (torch.rand(n, cin, h, w, generator=g) - 0.3).cuda()
+    imgs = [torch.rand(n, 3, h, w, generator=g).cuda() for _ in range(nimg)]
+    xp = _planes(x)
+    cw = ops.ConvWeights(wt, b, nterms=3)
+    got = ops.conv2d(xp, cw, epilogue=L.EPI_FINAL, images=imgs).double()
+    xq = ops.planes_to_nchw(xp, cin).double()
+    ref = torch.nn.functional.conv2d(xq, wt.double(), b.double(), padding=1) + sum(i.double() for i in imgs) / nimg
+    assert float((got - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
+    f16 = ops.conv2d(_planes(x, 1), ops.ConvWeights(wt, b, nterms=1), epilogue=L.EPI_FINAL, images=imgs).double()
+    assert float((f16 - ref).abs().max()) <= 3e-3                             # the single-product mode's kernel (v_dot2 lanes)
+
+
+@pytest.mark.parametrize("cin", [24, 36, 60])
+def test_sfenet1_tap_pair_path_vs_float64_and_the_plain_path(cin):
+    """SFENet1 (RDN.py:187/245/299: 5x5, 24 / 36 / 60 -> 96).  With 24 or 36 inputs the last 16-channel chunk is half empty and
+    the fp32-class kernel spends its K on tap PAIRS (`BINHIP_CONV_HALF_LAST_CHUNK`, x3_compute_pair: 25 -> 15 K-steps for that
+    chunk); 60 inputs keep the plain form.  Against fp64, and against the plain path on the same planes (the same weights declared
+    with their channels padded to a whole chunk, which switches the flag off): N = 2, ragged tiles, both at 2e-6."""
+    from bin_amd import ops
+    g = torch.Generator().manual_seed(300 + cin)
+    n, h, w = 2, 18, 44
+    wt = ((torch.rand(96, cin, 5, 5, generator=g) - 0.5) / 12).cuda()
+    b = (torch.rand(96, generator=g) - 0.5).cuda()
+    x = (torch.rand(n, cin, h, w, generator=g) - 0.3).cuda()
+    xp = _planes(x)
+    got = ops.planes_to_nchw(ops.conv2d(xp, ops.ConvWeights(wt, b, nterms=3)), 96).double()
+    xq = ops.planes_to_nchw(xp, cin).double()
+    ref = torch.nn.functional.conv2d(xq, wt.double(), b.double(), padding=2)
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 2e-6 * scale
+    pad = (-cin) % 16
+    wpad = torch.cat((wt, torch.zeros(96, pad, 5, 5, device="cuda")), 1) if pad else wt
+    plain = ops.planes_to_nchw(ops.conv2d(xp, ops.ConvWeights(wpad, b, nterms=3)), 96).double()
+    assert float((plain - ref).abs().max()) <= 2e-6 * scale and float((plain - got).abs().max()) <= 2e-6 * scale
+    if 1 <= cin % 16 <= 8:
+        assert not torch.equal(plain, got)          # (different summation order: the pair path really ran)
