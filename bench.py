@@ -126,7 +126,7 @@ def pmc_traffic(precision):
     return None, None
 
 
-PMC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")
+PMC_FILES = ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")
 TRAFFIC_NOTE = ("HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same command (separate FETCH_SIZE / "
                 "WRITE_SIZE runs, gfx950 corrections per MI355X_MICROARCH.md); PMC counters cannot be read in-process, so this "
                 "is NOT measured by this run — `traffic_source` names the file")

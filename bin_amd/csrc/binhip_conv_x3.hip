@@ -76,6 +76,31 @@ __device__ __forceinline__ void x3_issue_patch(const ConvKArgs& a, char* smem, i
     }
 }
 
+// piece j of the patch DMA alone (BINHIP_X3_SPREAD)
+template <class C>
+__device__ __forceinline__ void x3_issue_patch_piece(const ConvKArgs& a, char* smem, int c, int pl, int buf, int wave, int j,
+                                                     const unsigned* voff, long long plane_elems, unsigned plane_bytes) {
+    const _Float16* xb = pl ? a.x_lo : a.x_hi;
+    const long long coff = (a.cpg > 0) ? (long long)(c / a.cpg) * a.group_stride + (long long)(c % a.cpg) * plane_elems
+                                       : (long long)c * plane_elems;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(xb + coff), 0, plane_bytes, 0x00020000);
+    const int i = wave + C::NW * j;
+    if ((C::PP % C::NW == 0) || (i < C::PP))
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(smem + buf * C::PATCH_BYTES + i * 1024), 16, voff[j], 0, 0, 0);
+}
+template <class C, int KS>
+__device__ __forceinline__ void x3_issue_weights_piece(const ConvKArgs& a, char* smem, int c, int buf, int wave, int lane, int z, int j) {
+    const long long woff = ((long long)z * a.nchunks + c) * (KS * KS * 32 * 16);
+    const int i = wave + C::NW * j;
+    if (((2 * C::WP) % C::NW == 0) || (i < 2 * C::WP)) {
+        const bool lo = i >= C::WP;
+        const int t = lo ? i - C::WP : i;
+        __amdgpu_buffer_rsrc_t w = __builtin_amdgcn_make_buffer_rsrc((void*)((lo ? a.w_lo : a.w_hi) + woff), 0, KS * KS * 1024, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w, (lds_void_t*)(smem + 2 * C::PATCH_BYTES + buf * C::WBUF_BYTES + i * 1024), 16,
+                                                 (unsigned)(lane * 16), t * 1024, 0, 0);
+    }
+}
+
 template <class C, int KS>
 __device__ __forceinline__ void x3_issue_weights(const ConvKArgs& a, char* smem, int c, int buf, int wave, int lane, int z) {
     const long long woff = ((long long)z * a.nchunks + c) * (KS * KS * 32 * 16);
@@ -118,9 +143,18 @@ __device__ __forceinline__ floatx16 x3_mfma(half8 a, half8 b, floatx16 c) {
 // One sub-stage out of LDS.  HI: both weight planes against the hi patch (2 products); !HI: hi weights against the lo
 // patch.  Tap order dx-major: the R+KS-1 patch-row fragments of a tap column are fetched once and serve its KS taps;
 // weight fragments are fetched one tap ahead, the next column's patch rows at the column's first tap.
-template <class C, int KS, int R, bool HI>
+// BINHIP_X3_SPREAD (side builds; 0 in the product): the DMA instructions of the next sub-stage go out one per tap BEHIND that tap's
+// MFMAs (`hook(step)`) instead of as a burst at the top of the sub-stage — a wave executes in order and a burst of
+// buffer_load ... lds sits at the head of its stream until the memory pipeline has taken all of it (binhip_wgrad.hip gained 5 %
+// from the same change); measured for this kernel in profiles/r06_experiments.md.
+#ifndef BINHIP_X3_SPREAD
+#define BINHIP_X3_SPREAD 0
+#endif
+struct X3NoHook { __device__ __forceinline__ void operator()(int) const {} };
+
+template <class C, int KS, int R, bool HI, class Hook = X3NoHook>
 __device__ __forceinline__ void x3_compute(const char* pb, const char* wb, int a_lane_off, int b_lane_off,
-                                           floatx16 (&acc)[R]) {
+                                           floatx16 (&acc)[R], Hook hook = Hook{}) {
     constexpr int NTAP = KS * KS;
     half8 B[2][R + KS - 1];
     half8 Ah[2], Al[2];
@@ -150,6 +184,7 @@ __device__ __forceinline__ void x3_compute(const char* pb, const char* wb, int a
 #pragma unroll
         for (int r = 0; r < R; ++r)
             acc[r] = x3_mfma(Ah[s & 1], B[dx & 1][r + dy], acc[r]);
+        hook(s);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -298,8 +333,11 @@ __device__ __forceinline__ void x3_tile(const ConvKArgs& a, const float* __restr
 #if BINHIP_TIMELINE
         if (c == 0) BH_TL_STAMP(1);
 #endif
-        x3_issue_patch<C>(a, smem, c, 1, 1, wave, voff, plane_elems, plane_bytes);
-        if (c + 1 < nchunks) x3_issue_weights<C, KS>(a, smem, c + 1, (c + 1) & 1, wave, lane, z);
+        constexpr bool SPREAD = BINHIP_X3_SPREAD && KS == 3;
+        if constexpr (!SPREAD) {
+            x3_issue_patch<C>(a, smem, c, 1, 1, wave, voff, plane_elems, plane_bytes);
+            if (c + 1 < nchunks) x3_issue_weights<C, KS>(a, smem, c + 1, (c + 1) & 1, wave, lane, z);
+        }
         // GATED: one sub-stage before the first DMA of a gated chunk (the hi plane of chunk c + 1, issued in the lo sub-stage
         // below), lanes 0-8 of wave 0 fetch the flags of the 3 x 3 tile neighbourhood; the loads ride under this sub-stage's MFMAs
         unsigned gate_seen = gate.epoch;
@@ -318,6 +356,13 @@ __device__ __forceinline__ void x3_tile(const ConvKArgs& a, const float* __restr
         if constexpr (KS == 5 && !XTRA) {
             if (pair) x3_compute_pair<C, KS, R, true>(smem, wb, n, kg, wave, acc[0]);
             else x3_compute<C, KS, R, true>(smem, wb, a_lane_off, b_lane_off, acc[0]);
+        } else if constexpr (SPREAD) {
+            // steps 0 .. NPJ-1: the lo patch plane, then NWJ steps: the next chunk's weights (9 taps: 6 of them carry a piece)
+            const bool more = c + 1 < nchunks;
+            x3_compute<C, KS, R, true>(smem, wb, a_lane_off, b_lane_off, acc[0], [&](int s) {
+                if (s < C::NPJ) x3_issue_patch_piece<C>(a, smem, c, 1, 1, wave, s, voff, plane_elems, plane_bytes);
+                else if (s < C::NPJ + C::NWJ && more) x3_issue_weights_piece<C, KS>(a, smem, c + 1, (c + 1) & 1, wave, lane, z, s - C::NPJ);
+            });
         } else {
             x3_compute<C, KS, R, true>(smem, wb, a_lane_off, b_lane_off, acc[0]);
         }
@@ -342,10 +387,17 @@ __device__ __forceinline__ void x3_tile(const ConvKArgs& a, const float* __restr
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (c + 1 < nchunks) x3_issue_patch<C>(a, smem, c + 1, 0, 0, wave, voff, plane_elems, plane_bytes);
+        if constexpr (!SPREAD) {
+            if (c + 1 < nchunks) x3_issue_patch<C>(a, smem, c + 1, 0, 0, wave, voff, plane_elems, plane_bytes);
+        }
         if constexpr (KS == 5 && !XTRA) {
             if (pair) x3_compute_pair<C, KS, R, false>(smem + C::PATCH_BYTES, wb, n, kg, wave, acc[0]);
             else x3_compute<C, KS, R, false>(smem + C::PATCH_BYTES, wb, a_lane_off, b_lane_off, acc[0]);
+        } else if constexpr (SPREAD) {
+            const bool more = c + 1 < nchunks;
+            x3_compute<C, KS, R, false>(smem + C::PATCH_BYTES, wb, a_lane_off, b_lane_off, acc[0], [&](int s) {
+                if (s < C::NPJ && more) x3_issue_patch_piece<C>(a, smem, c + 1, 0, 0, wave, s, voff, plane_elems, plane_bytes);
+            });
         } else {
             x3_compute<C, KS, R, false>(smem + C::PATCH_BYTES, wb, a_lane_off, b_lane_off, acc[0]);
         }

@@ -32,8 +32,15 @@ from bin_amd.utils import util  # noqa: E402
 from bin_amd.weights import reference_state_dict, synthetic_frames  # noqa: E402
 
 
+TRAINED_LIKE = None          # --trained-like SEED: bin_amd.weights.trained_like_weights instead of the initialiser
+
+
 def load_weights(net, checkpoint):
     """Seeded initialisation, or a reference checkpoint with the reference's key clean-up (base_model.py:93-102), strict."""
+    if not checkpoint and TRAINED_LIKE is not None:
+        from bin_amd.weights import state_dict_from_canonical, trained_like_weights
+        net.load_state_dict(state_dict_from_canonical(trained_like_weights(TRAINED_LIKE)), strict=True)
+        return f"trained-like synthetic distribution (bin_amd/weights.py trained_like_weights, seed {TRAINED_LIKE})"
     if not checkpoint:
         net.load_state_dict(reference_state_dict(0), strict=True)
         return "seeded initialisation (bin_amd/weights.py, seed 0)"
@@ -116,10 +123,16 @@ def main():
     ap.add_argument("--out", default="gpurun_out/r03_fp16_headroom")
     ap.add_argument("--skip-720p", action="store_true")
     ap.add_argument("--checkpoint", default=None, help="reference .pth to measure instead of the seeded initialisation")
+    ap.add_argument("--trained-like", type=int, default=None, metavar="SEED",
+                    help="weights with a trained network's value distribution (three decades per layer, 30 %% zeros, one layer x50: "
+                         "bin_amd.weights.trained_like_weights) instead of the initialiser")
     args = ap.parse_args()
+    global TRAINED_LIKE
+    TRAINED_LIKE = args.trained_like
     marks = {int(x) for x in args.marks.split(",") if int(x) <= args.steps}
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
-    src = f"checkpoint {os.path.basename(args.checkpoint)}" if args.checkpoint else "seeded initialisation"
+    src = (f"checkpoint {os.path.basename(args.checkpoint)}" if args.checkpoint else
+           f"trained-like synthetic distribution, seed {args.trained_like}" if args.trained_like is not None else "seeded initialisation")
     result, md = {}, [f"# fp16 headroom of the stored planes, measured (tools/fp16_headroom.py; weights: {src})", ""]
     if not args.skip_720p:
         rows = window_720p(args.checkpoint)
