@@ -266,12 +266,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const float* _
                                     for (int j = 0; j < 4; ++j) v[j] = ((float)xm[g][j] > 0.f) ? v[j] : 0.f;
                                 }
                                 if (ge == kg) o_slot = o - 4 * kg;
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) {
-                                    const _Float16 hj = split_hi(v[j], sat);
-                                    hv[ge].h[j] = hj;
-                                    lv[ge].h[j] = split_lo(v[j], hj);
-                                }
+                                split_pair(v[0], v[1], sat, hv[ge].u[0], lv[ge].u[0]);
+                                split_pair(v[2], v[3], sat, hv[ge].u[1], lv[ge].u[1]);
                             }
 #pragma unroll
                             for (int k = 0; k < 2; ++k) {
@@ -442,9 +438,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const float* _
                                         }
                                     }
                                 }
-                                if (a.relu) {
+                                if constexpr (X) {               // (without extras the ReLU rides on split_pair's clamp)
+                                    if (a.relu) {
 #pragma unroll
-                                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                                    }
                                 }
                                 if constexpr (X) {
                                     if (use_m && och >= a.mask_from && live) {
@@ -456,12 +454,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const float* _
                             // after the swap, lanes 0-31 own slot 0 (g even) and lanes 32-63 slot 1 (g odd) of pixel n:
                             // the slot start is this (g, kg=0) element offset
                             if (ge == kg) o_slot = o - 4 * kg;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const _Float16 hj = split_hi(v[j], sat);
-                                hv[ge].h[j] = hj;
-                                lv[ge].h[j] = split_lo(v[j], hj);
-                            }
+                            const bool fold_relu = !X && a.relu && (EPI != BINHIP_EPI_SHUFFLE);
+                            split_pair(v[0], v[1], sat, hv[ge].u[0], lv[ge].u[0], fold_relu);
+                            split_pair(v[2], v[3], sat, hv[ge].u[1], lv[ge].u[1], fold_relu);
                         }
                         // vdst = even group, src = odd group: upper half of vdst <-> lower half of src
 #pragma unroll

@@ -232,14 +232,11 @@ rdb_tail_kernel(const TailKArgs a, const float* __restrict__ bias_c, const float
                 float b8[8];                              // wave-uniform slot of 8 biases, the lane's half picked by kg
 #pragma unroll
                 for (int j = 0; j < 8; ++j) b8[j] = bias_c[8 * g + j];
-                const float v[4] = {fmaxf(accc[r][4 * g + 0] + (kg ? b8[4] : b8[0]), 0.f), fmaxf(accc[r][4 * g + 1] + (kg ? b8[5] : b8[1]), 0.f),
-                                    fmaxf(accc[r][4 * g + 2] + (kg ? b8[6] : b8[2]), 0.f), fmaxf(accc[r][4 * g + 3] + (kg ? b8[7] : b8[3]), 0.f)};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const _Float16 hj = split_hi(v[j], sat);
-                    hv[ge].h[j] = hj;
-                    lv[ge].h[j] = split_lo(v[j], hj);
-                }
+                // (the ReLU rides on split_pair's clamp)
+                const float v[4] = {accc[r][4 * g + 0] + (kg ? b8[4] : b8[0]), accc[r][4 * g + 1] + (kg ? b8[5] : b8[1]),
+                                    accc[r][4 * g + 2] + (kg ? b8[6] : b8[2]), accc[r][4 * g + 3] + (kg ? b8[7] : b8[3])};
+                split_pair(v[0], v[1], sat, hv[ge].u[0], lv[ge].u[0], true);
+                split_pair(v[2], v[3], sat, hv[ge].u[1], lv[ge].u[1], true);
                 const int off = ((gp * C::R + r) * 32 + n) * 32 + ((ge ^ ((n >> 3) & 1)) << 4) + kg * 8;
                 *reinterpret_cast<half4*>(o3 + off) = hv[ge].h;
                 if constexpr (NT == 3) *reinterpret_cast<half4*>(o3 + O3_PLANE + off) = lv[ge].h;
@@ -317,12 +314,8 @@ rdb_tail_kernel(const TailKArgs a, const float* __restrict__ bias_c, const float
                                   accl[mt][r][4 * g + 2] + (kg ? b8[6] : b8[2]), accl[mt][r][4 * g + 3] + (kg ? b8[7] : b8[3])};
                     const long long o = (long long)(co >> 4) * plane_elems + ((((long long)img * H + gyc) * W + gxc) << 4) + (co & 15);
                     if (ge == kg) o_slot = o - 4 * kg;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const _Float16 hj = split_hi(v[j], sat);
-                        hv[ge].h[j] = hj;
-                        lv[ge].h[j] = split_lo(v[j], hj);
-                    }
+                    split_pair(v[0], v[1], sat, hv[ge].u[0], lv[ge].u[0]);
+                    split_pair(v[2], v[3], sat, hv[ge].u[1], lv[ge].u[1]);
                 }
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {

@@ -341,14 +341,11 @@ rdb_tail_x3_kernel(const TailKArgs a, const float* __restrict__ bias_c, const fl
                 float b8[8];                              // wave-uniform slot of 8 biases, the lane's half picked by kg
 #pragma unroll
                 for (int j = 0; j < 8; ++j) b8[j] = bias_c[8 * g + j];
-                const float v[4] = {fmaxf(accc[r][4 * g + 0] + (kg ? b8[4] : b8[0]), 0.f), fmaxf(accc[r][4 * g + 1] + (kg ? b8[5] : b8[1]), 0.f),
-                                    fmaxf(accc[r][4 * g + 2] + (kg ? b8[6] : b8[2]), 0.f), fmaxf(accc[r][4 * g + 3] + (kg ? b8[7] : b8[3]), 0.f)};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const _Float16 hj = split_hi(v[j], sat);
-                    hv[ge].h[j] = hj;
-                    lv[ge].h[j] = split_lo(v[j], hj);
-                }
+                // (the ReLU rides on split_pair's clamp)
+                const float v[4] = {accc[r][4 * g + 0] + (kg ? b8[4] : b8[0]), accc[r][4 * g + 1] + (kg ? b8[5] : b8[1]),
+                                    accc[r][4 * g + 2] + (kg ? b8[6] : b8[2]), accc[r][4 * g + 3] + (kg ? b8[7] : b8[3])};
+                split_pair(v[0], v[1], sat, hv[ge].u[0], lv[ge].u[0], true);
+                split_pair(v[2], v[3], sat, hv[ge].u[1], lv[ge].u[1], true);
             }
 #pragma unroll
             for (int k = 0; k < 2; ++k) {

@@ -47,6 +47,41 @@ __device__ __forceinline__ _Float16 split_lo(float v, _Float16 hi) {
     return (_Float16)__builtin_amdgcn_fmed3f(v - (float)hi, -BINHIP_F16_MAX, BINHIP_F16_MAX);
 }
 
+// Two values at once, packed (round 6).  The epilogues are VALU-bound — ~12 instructions per stored value, 192 values per lane in the
+// fused tail's LFF epilogue (5.4 us per tile, profiles/r06_wg_timeline.md) — and most of them were this split: clamp, convert, convert
+// back, subtract, clamp, convert, pack.  Here: one v_med3 per value (the clamp of hi ALSO bounds lo: |vc - hi| <= 32), one
+// v_cvt_pk_f16_f32 per pair, and lo = vc - hi as ONE v_fma_mix{lo,hi}_f16 per value — an fp32 fma of (f16 hi) * -1.0 + vc whose exact
+// result is rounded once to f16, straight into its half of the packed dword: the same bits as the subtract-then-convert form for every
+// in-range value (tests/test_gpu_conv.py::test_packed_split_equals_the_scalar_split).  A saturated or NaN value gives lo = 0 instead of a
+// clamped remainder; such outputs raise at the host either way.
+#ifndef BINHIP_SPLIT_ASM
+#define BINHIP_SPLIT_ASM 1
+#endif
+// RELU (wave-uniform): the layer's ReLU rides on the clamp — the lower bound of the v_med3 becomes 0 (fmaxf costs a canonicalising
+// v_max on top of the v_max itself) — and a large NEGATIVE value is then not a saturation: the range test keeps the sign bit and
+// compares signed.
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& sat, unsigned& hi2, unsigned& lo2, bool relu = false) {
+#if BINHIP_SPLIT_ASM
+    const unsigned smask = relu ? 0xffffffffu : 0x7fffffffu;
+    const float lb = relu ? 0.f : -BINHIP_F16_MAX;
+    sat |= ((int)(__float_as_uint(a) & smask) > 0x477fe000) ? 1u : 0u;
+    sat |= ((int)(__float_as_uint(b) & smask) > 0x477fe000) ? 1u : 0u;
+    const float ac = __builtin_amdgcn_fmed3f(a, lb, BINHIP_F16_MAX);
+    const float bc = __builtin_amdgcn_fmed3f(b, lb, BINHIP_F16_MAX);
+    unsigned h, l;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(ac), "v"(bc));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(ac));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(bc));
+    hi2 = h; lo2 = l;
+#else
+    if (relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+    union { _Float16 h[2]; unsigned u; } H, L;
+    H.h[0] = split_hi(a, sat); L.h[0] = split_lo(a, H.h[0]);
+    H.h[1] = split_hi(b, sat); L.h[1] = split_lo(b, H.h[1]);
+    hi2 = H.u; lo2 = L.u;
+#endif
+}
+
 // internal launcher used by both the per-op ABI and the RDN plan
 struct BhConvCall {
     BinConvDesc d;

@@ -508,3 +508,39 @@ def test_sfenet1_tap_pair_path_vs_float64_and_the_plain_path(cin):
     assert float((plain - ref).abs().max()) <= 2e-6 * scale and float((plain - got).abs().max()) <= 2e-6 * scale
     if 1 <= cin % 16 <= 8:
         assert not torch.equal(plain, got)          # (different summation order: the pair path really ran)
+
+
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("ks", [1, 3])
+def test_packed_split_equals_the_scalar_split(ks, relu):
+    """The epilogues' hi / lo split (round 6: one v_med3 + v_cvt_pk_f16_f32 per pair + one v_fma_mix{lo,hi}_f16 per value, the ReLU
+    folded into the clamp; binhip_internal.h split_pair) must store the SAME bits as the definition hi = fp16(v), lo = fp16(v - hi):
+    an identity convolution (centre tap 1.0) plus a bias makes the accumulator an exactly known fp32 value v = fl(x + b) for inputs
+    spanning 1e-7 ... 6e4 of both signs, so the stored planes can be compared bit for bit with torch's roundings."""
+    from bin_amd import ops
+    ops.check_status()
+    g = torch.Generator().manual_seed(11 + ks)
+    n, c, h, w = 1, 32, 16, 64
+    mag = 10.0 ** (torch.rand(n, c, h, w, generator=g) * 11.5 - 7.0)            # 1e-7 .. 3e4
+    x = (mag * (torch.randint(0, 2, mag.shape, generator=g) * 2 - 1)).float()
+    x[0, 0, 0, :8] = torch.tensor([0.0, -0.0, 65504.0, -65504.0, 6.1e-5, -6.0e-8, 2.0 ** -24, 1.0])
+    b = (torch.rand(c, generator=g) - 0.5) * 2e-3
+    wt = torch.zeros(c, c, ks, ks)
+    for i in range(c):
+        wt[i, i, ks // 2, ks // 2] = 1.0
+    xp = ops.nchw_to_planes(x.cuda(), 3)
+    xq = xp.hi.float() + xp.lo.float()                                            # what the planes hold: exact in fp32 (22 bits)
+    cw = ops.ConvWeights(wt.cuda(), b.cuda(), nterms=3)
+    y = ops.conv2d(xp, cw, relu=relu)
+    torch.cuda.synchronize()
+    ops.check_status()
+    # planes [chunk][n][h][w][16] -> the expected accumulator per element
+    bb = b.cuda().view(2, 16)[:, None, None, None, :]
+    v = xq + bb                                                                  # one fp32 add, as acc + bias in the epilogue
+    if relu:
+        v = torch.clamp_min(v, 0.0)
+    hi = v.half()
+    lo = (v - hi.float()).half()
+    same_hi = (y.hi.view(torch.int16) == hi.view(torch.int16)) | ((y.hi == 0) & (hi == 0))      # (+0 / -0 are the same stored value)
+    same_lo = (y.lo.view(torch.int16) == lo.view(torch.int16)) | ((y.lo == 0) & (lo == 0))
+    assert bool(same_hi.all()) and bool(same_lo.all()), (int((~same_hi).sum()), int((~same_lo).sum()))
