@@ -58,6 +58,10 @@ struct X3Cfg {
     static_assert((KS == 3 ? 2 : 1) * LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
+// cache-policy bits of the patch DMA (side builds; 0 = default policy in the product): 2 = nt.  Measured in profiles/r06_experiments.md.
+#ifndef BINHIP_X3_PATCH_AUX
+#define BINHIP_X3_PATCH_AUX 0
+#endif
 template <class C>
 __device__ __forceinline__ void x3_issue_patch(const ConvKArgs& a, char* smem, int c, int pl, int buf, int wave,
                                                const unsigned* voff, long long plane_elems, unsigned plane_bytes) {
@@ -72,7 +76,7 @@ __device__ __forceinline__ void x3_issue_patch(const ConvKArgs& a, char* smem, i
     for (int j = 0; j < C::NPJ; ++j) {
         const int i = wave + C::NW * j;
         if (BINHIP_ABLATE != 4 && ((C::PP % C::NW == 0) || (i < C::PP)))
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(lds + i * 1024), 16, voff[j], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(lds + i * 1024), 16, voff[j], 0, 0, BINHIP_X3_PATCH_AUX);
     }
 }
 

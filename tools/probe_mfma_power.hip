@@ -9,6 +9,8 @@
 //   8  32x32x16, both operands half zeros
 //   9  v_mfma_i32_32x32x32_i8, random int8 operands (ops counted like flops)      10  the same, all-zero operands
 //  11  i8, B half zeros (post-ReLU magnitudes), A = small signed "weight" bytes
+//  12 / 13 / 15  32x32x16, B = lo-plane data whose mantissa keeps only its top 5 / 3 / 0 bits (round 6: does a coarser lo plane cost fewer joules?)
+//  16  both operands U[-1,1) with 5-bit mantissas        17  B = lo-plane data, 7-bit mantissa
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
@@ -32,8 +34,15 @@ __device__ __forceinline__ half8 frag(unsigned seed, int mode, bool is_b) {
         if (mode == 3) r = is_b ? fmaxf(r, 0.f) : r * (1.f / 38.f);
         if (mode == 7) r = is_b ? r * (1.f / 38.f) : fmaxf(r, 0.f);
         if (mode == 8) r = fmaxf(r, 0.f);
-        if (mode == 4 && is_b) r *= (1.f / 2048.f);
+        if ((mode == 4 || mode == 12 || mode == 13 || mode == 15 || mode == 17) && is_b) r *= (1.f / 2048.f);
         v[e] = (_Float16)r;
+        const int keep = mode == 12 ? 5 : mode == 13 ? 3 : mode == 15 ? 0 : mode == 16 ? 5 : mode == 17 ? 7 : 10;
+        if (keep < 10 && (is_b || mode == 16)) {
+            union { _Float16 h; unsigned short u; } c;
+            c.h = v[e];
+            c.u &= (unsigned short)(0xFFFFu << (10 - keep));
+            v[e] = c.h;
+        }
     }
     return v;
 }
@@ -144,6 +153,11 @@ int main(int argc, char** argv) {
             case 9: probe<9><<<blocks, 256>>>(iters, out); break;
             case 10: probe<10><<<blocks, 256>>>(iters, out); break;
             case 11: probe<11><<<blocks, 256>>>(iters, out); break;
+            case 12: probe<12><<<blocks, 256>>>(iters, out); break;
+            case 13: probe<13><<<blocks, 256>>>(iters, out); break;
+            case 15: probe<15><<<blocks, 256>>>(iters, out); break;
+            case 16: probe<16><<<blocks, 256>>>(iters, out); break;
+            case 17: probe<17><<<blocks, 256>>>(iters, out); break;
             default: probe<8><<<blocks, 256>>>(iters, out); break;
         }
     };
