@@ -15,6 +15,9 @@
 #                               <tag>_pmc_traffic.json[KEY] + <tag>_pmc_traffic_<KEY>.md
 #   sq "rdb 3 160"              SQ counters (two 8-counter passes) of one layer class of tools/pmc_one.py
 #   py SCRIPT [args]            python SCRIPT args, output to <tag>_<script>.log (tail printed)
+#   tl NAME [wg_timeline args]  per-workgroup timeline (tools/wg_timeline.py) with the BINHIP_TIMELINE side build -> <tag>_tl_<NAME>.json/.npz
+#   steps MODE N                un-profiled per-step spread (tools/stall_hunt.py steps): MODE = train | infer -> <tag>_steps_<MODE>.json
+#   stalls NAME [bench args]    rocprofv3 --kernel-trace --hip-trace of the bench command + tools/stall_hunt.py trace -> <tag>_stalls_<NAME>.json
 #   env NAME=VALUE              export for the steps that follow (env NAME= unsets)
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.." || exit 1
 mkdir -p gpurun_out; export TMPDIR=/tmp
@@ -43,6 +46,18 @@ for step in "$@"; do
   case $verb in
     tag) TAG=$1 ;;
     env) case "$1" in *=) unset "${1%=}" ;; *) export "$1" ;; esac ;;
+    tl)
+      name=$1; shift
+      BIN_AMD_LIB=tools/_abl/libbinhip_timeline.so timeout 600 python tools/wg_timeline.py --out gpurun_out/${TAG}_tl_$name "$@" > gpurun_out/${TAG}_tl_$name.log 2>&1
+      tail -4 gpurun_out/${TAG}_tl_$name.log ;;
+    steps)
+      timeout 900 python tools/stall_hunt.py steps --mode $1 --steps ${2:-50} > gpurun_out/${TAG}_steps_$1.json 2> gpurun_out/${TAG}_steps_$1.err
+      cut -c1-300 gpurun_out/${TAG}_steps_$1.json ;;
+    stalls)
+      name=$1; shift; rm -rf /tmp/stall_$name
+      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --hip-trace --output-format csv -d /tmp/stall_$name -o st -- python $OLDPWD/bench.py "$@" > $OLDPWD/gpurun_out/${TAG}_stalls_$name.log 2>&1 )
+      python tools/stall_hunt.py trace /tmp/stall_$name > gpurun_out/${TAG}_stalls_$name.json 2> gpurun_out/${TAG}_stalls_$name.err
+      head -c 600 gpurun_out/${TAG}_stalls_$name.json ;;
     test)
       args="$*"; [ -z "$args" ] && args=tests
       ( timeout 2400 python -m pytest -m gpu -q $args 2>&1 | grep -E "passed|failed|rror|^E |^FAILED|^tests/.*(FAIL|ERR)" | tail -25 ) 2>&1 | tee -a gpurun_out/${TAG}_pytest.log ;;
