@@ -41,7 +41,7 @@ struct Ws {
     int64_t P, PF;        // plane elems at half / full res
     int kc0;
     int64_t x0, f1, blk, g0, g1, u, total;   // element offsets of the hi part
-    int64_t sync;                            // element offset of the dense-block sync words (32 counters + 2 T flags, uint32)
+    int64_t sync;                            // element offset of the dense-block sync words (32 reserved + 2 T flags, uint32)
     int tiles;                               // 16x32 tiles of one dense-block conv launch
     int64_t s_x0, s_f1, s_blk, s_g, s_u;     // sizes (elements) of each tensor's hi part
     int nt;
@@ -64,7 +64,7 @@ Ws make_ws(int N, int H, int W, int nin, int nt, const Shp& sh) {
     w.g0 = o; o += mul * w.s_g;
     w.g1 = o; o += mul * w.s_g;
     w.u = o; o += mul * w.s_u;
-    // sync words of the three-phase dense-block launches (binhip_conv_x3.hip): 32 counters (one per block) + two
+    // sync words of the one-launch dense blocks (binhip_conv_x3.hip): 32 reserved words (the round-2 work-queue heads) + two
     // flag words per tile; 4-byte words kept in the fp16-element address space (2 elements each), 256-B aligned
     w.tiles = N * ((h + 15) / 16) * ((ww + 31) / 32);
     o = (o + 127) & ~(int64_t)127;
@@ -155,8 +155,8 @@ int binhip_rdn_forward(const BinRdnPlan* p, const float* const* inputs, float* o
         return bh_launch_conv(mk(layer, ks, cin_chunks, cout, cout_pad, epi, relu, Hc, Wc, x_off, x_size, cpg, gstride,
                                  y_off, y_size, r_off, r_size), s);
     };
-    // three-phase dense-block launches (BINHIP_PLAN_RDB3, opt-in, fp32-class path): one memset per call zeroes the 12
-    // work-queue heads and the per-tile flags (block d publishes the value d + 1, so the blocks of one call never confuse
+    // one-launch dense blocks (BINHIP_PLAN_RDB3, opt-in, fp32-class path): one memset per call zeroes the per-tile flags
+    // (block d publishes the value d + 1, so the blocks of one call never confuse
     // each other's flags; the memset only removes what an earlier call or uninitialised memory left behind)
     const bool rdb3 = (p->reserved & BINHIP_PLAN_RDB3) && nt == 3 && sh.stage4;
     unsigned* sync_words = (unsigned*)(base + w.sync);
@@ -177,7 +177,7 @@ int binhip_rdn_forward(const BinRdnPlan* p, const float* const* inputs, float* o
         const bool fuse = sh.stage4 && !(p->reserved & BINHIP_PLAN_NO_FUSE);
         bool done3 = false;
         if (rdb3 && fuse) {
-            // convs 0-2 as three phases of one launch (work queue + neighbour flags instead of two kernel boundaries)
+            // convs 0-2 as three phases of one launch (static tile ownership + neighbour flags instead of two kernel boundaries)
             ConvKArgs ka[3];
             bool ok3 = true;
             for (int c = 0; c < 3 && ok3; ++c) {

@@ -321,9 +321,9 @@ def test_concurrent_host_threads_share_the_library():
 
 
 def test_three_phase_dense_block_launch_is_bit_identical(canon_gpu):
-    """BINHIP_PLAN_RDB3 (opt-in): convs 0-2 of every dense block as three phases of ONE launch — (phase, tile) items from an
-    atomic work queue, per-tile neighbour flags instead of kernel boundaries, write-through stores + drained flag for
-    cross-XCD visibility.  Must return the per-launch path's bits on ragged and multi-image shapes, repeatedly and while
+    """BINHIP_PLAN_RDB3 (opt-in): convs 0-2 of every dense block as three phases of ONE launch — static tile ownership (round 6;
+    shapes with more tiles than co-resident workgroups give a workgroup several tiles per phase: the 3 x 130 x 190 case), per-tile
+    neighbour flags checked only before a conv's last two input chunks, write-through stores + drained flag for cross-XCD visibility.  Must return the per-launch path's bits on ragged and multi-image shapes, repeatedly and while
     another stream loads the chip unevenly, and must never trip the bounded-spin status bit."""
     from bin_amd import _lib as L, ops
     from bin_amd.rdn_plan import RdnWeights, rdn_forward
