@@ -279,7 +279,8 @@ BINHIP_API int binhip_rdb_tail_fwd(int N, int H, int W, int nterms, const void* 
 #define BINHIP_PLAN_KEEP_ACTS 1   /* training: keep every activation binhip_rdn_backward needs      */
 #define BINHIP_PLAN_NO_FUSE   2   /* run conv #3 and LFF of each RDB as two kernels (A/B + tests)   */
 #define BINHIP_PLAN_RDB3      4   /* nterms = 3: convs 0-2 of each RDB as three phases of ONE launch */
-                                  /* (work queue + per-tile neighbour flags, no grid barrier)        */
+                                  /* (static tile ownership + per-tile neighbour flags, no grid       */
+                                  /* barrier; per-conv launches when the grid cannot be co-resident)  */
 typedef struct BinRdnPlan {
     int32_t N, H, W;          /* full-resolution frame size (H, W even)                          */
     int32_t n_inputs;         /* 2, 3 or 5 input frames                                          */
