@@ -38,6 +38,11 @@
 #ifndef BINHIP_X3_PRIO
 #define BINHIP_X3_PRIO 0
 #endif
+// 1 (product, round 6) = waves run their K loop at priority 2 and their epilogue at 0, so that a workgroup's epilogue VALU work does not
+// take issue slots from its CU partner's MFMAs: window -0.46 % (6 of 6 alternating pairs), training step -0.15 % (5 of 6); 0 = side builds
+#ifndef BINHIP_EPI_PRIO
+#define BINHIP_EPI_PRIO 1
+#endif
 
 template <int KS, int R, int WN>
 struct X3Cfg {
@@ -297,6 +302,9 @@ __device__ __forceinline__ void x3_tile(const ConvKArgs& a, const float* __restr
     const int a_lane_off = n * 32 + ((kg ^ ((n >> 3) & 1)) << 4);
     const int b_lane_off = (kg * (C::PH * C::PW) + wave * R * C::PW + n) * 16;
 
+#if BINHIP_EPI_PRIO
+    __builtin_amdgcn_s_setprio(2);       // K loop above the CU partner's epilogue (profiles/r06_experiments.md)
+#endif
     x3_issue_weights<C, KS>(a, smem, 0, 0, wave, lane, z);
     if constexpr (GATED) {
         if (gate.chunk <= 0 && gate.flags) {              // every input chunk is gated: wait before the first patch DMA
@@ -407,6 +415,9 @@ __device__ __forceinline__ void x3_tile(const ConvKArgs& a, const float* __restr
         }
     }
     BH_TL_STAMP(2);
+#if BINHIP_EPI_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     conv_epilogue<1, R, 3, EPI, XTRA>(a, bias, acc, img, ty0 + wave * R, tx0, z * 32, z == 0, n, kg, plane_elems);
     BH_TL_FINISH(a, (((img * a.tiles_y + ty) * a.tiles_x + tx) * a.ncol + z));
 }

@@ -21,6 +21,9 @@
 #ifndef BINHIP_X3_PRIO
 #define BINHIP_X3_PRIO 0      // bit 1: progress-ordered wave priority in this kernel (binhip_conv_x3.hip explains)
 #endif
+#ifndef BINHIP_EPI_PRIO
+#define BINHIP_EPI_PRIO 1        // K loop at wave priority 2, epilogues at 0: see binhip_conv_x3.hip
+#endif
 #ifndef BINHIP_TAIL_RES_MFMA
 #define BINHIP_TAIL_RES_MFMA 0   // side builds: 1 = the residual as an identity MFMA (rounds 1-3), for A/B runs
 #endif
@@ -257,6 +260,9 @@ rdb_tail_x3_kernel(const TailKArgs a, const float* __restrict__ bias_c, const fl
     const int a_lane_off = n * 32 + ((kg ^ ((n >> 3) & 1)) << 4);
     const int b_lane_off = (kg * (TX::PH * TX::PW) + wave * TX::R * TX::PW + n) * 16;
 
+#if BINHIP_EPI_PRIO
+    __builtin_amdgcn_s_setprio(2);
+#endif
     tx_issue_weights(a, smem, 0, 0, wave, lane);
     tx_issue_patch(a, smem, 0, 0, wave, voff, plane_elems, plane_bytes);
     // one 16-channel chunk = a hi and a lo sub-stage.  Chunks 0-5 (the block input) also carry the residual, with their index
@@ -318,6 +324,9 @@ rdb_tail_x3_kernel(const TailKArgs a, const float* __restrict__ bias_c, const fl
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
+#if BINHIP_EPI_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     // ---- conv #3 epilogue: bias + ReLU + hi/lo split; o3 never leaves the registers -------------------------------------
     // The accumulator tile gives lane (n, kg) channels 8g + 4kg + j; after the store epilogue's v_permlane32_swap of a
     // (g even, g odd) pair lane (n, kg) owns the full 16-byte slot kg of 16-channel group gp — channels 16gp + 8kg .. +7 of
