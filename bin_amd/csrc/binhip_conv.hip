@@ -413,6 +413,7 @@ int bh_prepare_conv(const BhConvCall& c, ConvKArgs* out) {
     a.xcd_remap = 1;
     a.dbg = 0;
     a.wt = 0;
+    a.prog_prio = 0;
 #if BINHIP_TIMELINE
     a.tl = nullptr; a.tl_launch = 0; a.tl_base = 0;
 #endif

@@ -46,6 +46,7 @@ struct ConvKArgs {
     int y_cpg;                // output chunk grouping (<=0: one group)
     unsigned y_cpg_inv;       // ceil(2^20 / y_cpg): och / y_cpg == (och * y_cpg_inv) >> 20 for och < 4096, y_cpg <= 128 (no SALU division per slot)
     long long y_group_stride;
+    int prog_prio;            // plane-split kernel: progress-ordered wave priority (launches that fit the chip in one round)
     int half_last;            // the last input chunk carries 8 real channels at most (BINHIP_CONV_HALF_LAST_CHUNK): 5x5 plane-split kernel
 #if BINHIP_TIMELINE
     void* tl;                 // BINHIP_TIMELINE side builds: per-workgroup time-stamp records (BhTlBuf) or null

@@ -40,6 +40,9 @@
 #endif
 // 1 (product, round 6) = waves run their K loop at priority 2 and their epilogue at 0, so that a workgroup's epilogue VALU work does not
 // take issue slots from its CU partner's MFMAs: window -0.46 % (6 of 6 alternating pairs), training step -0.15 % (5 of 6); 0 = side builds
+#ifndef BINHIP_PROG_PRIO
+#define BINHIP_PROG_PRIO 1     // 0 = side builds without the progress-ordered priority of one-round launches
+#endif
 #ifndef BINHIP_EPI_PRIO
 #define BINHIP_EPI_PRIO 1
 #endif
@@ -329,15 +332,18 @@ __device__ __forceinline__ void x3_tile(const ConvKArgs& a, const float* __restr
     x3_issue_patch<C>(a, smem, 0, 0, 0, wave, voff, plane_elems, plane_bytes);
     for (int c = 0; c < nchunks; ++c) {
         const char* wb = smem + 2 * C::PATCH_BYTES + (c & 1) * C::WBUF_BYTES;
-#if BINHIP_X3_PRIO & 1
-        {
+        // Progress-ordered priority (round 3 side build, round 6 product for ONE-ROUND grids): of the two workgroups sharing a CU the
+        // one that lags issues first, so the pair finishes together instead of the younger one running alone at the end of the launch
+        // (profiles/r06_wg_timeline.md).  Only when every workgroup of the launch is resident at once (`a.prog_prio`, set by the
+        // launcher): in a multi-round grid a freshly started workgroup would outrank the ones about to free their slot — the
+        // training step loses 0.6 % with it, the 720p window gains 0.7 %.
+        if ((BINHIP_X3_PRIO & 1) || a.prog_prio) {
             const int q = (4 * c) / nchunks;
             if (q == 0) __builtin_amdgcn_s_setprio(3);
             else if (q == 1) __builtin_amdgcn_s_setprio(2);
             else if (q == 2) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
         }
-#endif
         // ---- hi sub-stage (the long one: 2 products): meanwhile the lo patch plane and the NEXT chunk's weights land
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
@@ -525,6 +531,8 @@ static int launch_x3_x(const ConvKArgs& ka, int cout_pad, hipStream_t s) {
     a.tiles_y = (a.H + C::TH - 1) / C::TH;
     a.ncol = cout_pad / 32;
     dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.N * a.ncol));
+    // progress-ordered wave priority: only for launches whose workgroups are all resident at once (two per CU), forward layers only
+    a.prog_prio = (BINHIP_PROG_PRIO && KS == 3 && !XTRA && (long long)grid.x <= 2ll * binhip_device_cus()) ? 1 : 0;
 #if BINHIP_TIMELINE
     // kind: 1 = the dense-block conv (3x3, one 32-row column, plane epilogue, no extras), 3 = every other instantiation
     a.tl = bh_tl_reserve(grid.x, &a.tl_base);
