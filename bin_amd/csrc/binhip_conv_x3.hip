@@ -587,6 +587,7 @@ int bh_launch_rdb3_x3(const ConvKArgs* convs, unsigned* flags, unsigned epoch, i
     a.flags = flags; a.epoch = epoch;
     const long long slots = (long long)occ * (cus > 0 ? cus : 256);
     const unsigned grid = (unsigned)(a.T < slots ? a.T : slots);
+    for (int p = 0; p < 3; ++p) a.conv[p].prog_prio = (BINHIP_PROG_PRIO && a.T <= slots) ? 1 : 0;     // one tile per workgroup and phase
     conv_x3_rdbs_kernel<BINHIP_X3_R, BINHIP_X3_WN><<<dim3(grid), dim3(64 * C::NW), C::LDS_BYTES, s>>>(a, a.conv[0].bias, a.conv[1].bias,
                                                                                                    a.conv[2].bias);
     BH_CHECK_LAUNCH();
