@@ -137,7 +137,7 @@ def main():
     if not args.skip_720p:
         rows = window_720p(args.checkpoint)
         result["window_720p"] = rows
-        md.append(md_table("720p window (768x1344), seeded init, forward activations of all 17 call-equivalents (4 batched calls)", rows))
+        md.append(md_table(f"720p window (768x1344), {src}, forward activations of all 17 call-equivalents (4 batched calls)", rows))
     tr, losses = training(args.steps, marks, checkpoint=args.checkpoint) if args.steps > 0 else ({}, {})
     for step in sorted(tr):
         rows = tr[step]
