@@ -484,3 +484,25 @@ def test_striped_png_writer_decodes_to_the_same_pixels(tmp_path):
     with pytest.raises(ValueError):
         util.png_bytes_striped(np.zeros((4, 4), dtype=np.uint8))
     pool.shutdown()
+
+
+def test_synthetic_moving_texture_clips_have_the_dataset_structure():
+    """bin_amd.data.synthetic: the dict feed_data takes (BIN_dataset.py:170-183 shapes), deterministic in (seed, index), values in
+    [0, 1], a blurry frame = the exposure mean of its sharp neighbourhood (smoother than, and close to, the sharp frame at its instant),
+    and the in-between sharp frame lies between its neighbours in time (uniform motion)."""
+    import torch
+    from bin_amd.data.synthetic import moving_texture_batch, moving_texture_clip
+    d = moving_texture_batch(3, 10, 2, 48)
+    assert d["LQs"].shape == (2, 6, 3, 48, 48) and d["GTenh"].shape == (2, 6, 3, 48, 48) and d["GTinp"].shape == (2, 5, 3, 48, 48)
+    assert all(v.dtype == torch.float32 and 0.0 <= float(v.min()) and float(v.max()) <= 1.0 for v in d.values())
+    again = moving_texture_clip(3, 11, 48)
+    assert torch.equal(again[0], d["LQs"][1]) and torch.equal(again[2], d["GTinp"][1])
+    assert not torch.equal(d["LQs"][0], d["LQs"][1])
+
+    def roughness(x):
+        return float((x[..., 1:, :] - x[..., :-1, :]).abs().mean() + (x[..., :, 1:] - x[..., :, :-1]).abs().mean())
+    lq, enh, inp = moving_texture_clip(3, 10, 48, max_speed=3.0)
+    assert roughness(lq) < roughness(enh)                                   # motion blur removes detail
+    assert float((lq - enh).abs().mean()) < 0.5 * float((enh[0] - enh[5]).abs().mean())      # ... but stays at its instant
+    mid = 0.5 * (enh[2] + enh[3])
+    assert float((inp[2] - mid).abs().mean()) < float((inp[2] - enh[2]).abs().mean())       # I6 is nearer the mean of I5, I7 than I5
