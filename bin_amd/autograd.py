@@ -78,7 +78,8 @@ def train_precision(module):
             "bin_amd: training with precision 'f16' (one fp16 product in forward and backward) is not a supported mode — its "
             "parameter gradients are only verified to 25 %.  Train in 'f16x3' (the default; set network_G.precision: f16x3 or "
             "leave it unset), optionally with network_G.backward_precision: f16 for the faster mixed mode; 'f16' is the "
-            "inference mode (wrap inference in torch.no_grad()).  Diagnostics may set module.allow_f16_training = True.")
+            "inference mode (wrap inference in torch.no_grad()).  To train in it regardless (it converged like f16x3 on the synthetic "
+            "task of profiles/r06_training_modes.md) set network_G.allow_f16_training: true, or module.allow_f16_training = True.")
     return PRECISIONS[p]
 
 

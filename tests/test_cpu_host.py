@@ -295,6 +295,9 @@ def test_define_G_and_create_model_errors():
         create_model({"model": "sr"})
     net = networks.define_G({"network_G": {"which_model_G": "bin_stage4", "precision": "f16"}})
     assert net.precision == "f16" and net.model.model2_1.precision == "f16"
+    assert not any(m.allow_f16_training for m in net.rdn_modules())                 # f16 TRAINING stays gated by default ...
+    net = networks.define_G({"network_G": {"which_model_G": "bin_stage4", "precision": "f16", "allow_f16_training": True}})
+    assert all(m.allow_f16_training for m in net.rdn_modules())                     # ... and opens only on an explicit option
 
 
 # ------------------------------------------------------------------ wrapper
