@@ -669,6 +669,21 @@ def train_bench(args, rank, world, dev, steps=None, warmup=None, standalone=True
                    "backward_precision": bwd_prec or prec}}
     del m
     torch.cuda.empty_cache()
+    if prec == "f16x3" and not bwd_prec and not args.zero_data and world == 1 and not args.no_extras:
+        # the supported reduced-precision training mode beside the headline (never instead of it): f16x3 forward, single-product
+        # backward — the counterpart of BASELINE config 4's "bf16" wording with a stated parity (profiles/r06_training_modes.md)
+        m2, _ = make_train_model("f16x3", "f16", world, rank, args.batch)
+        for i in range(2):
+            m2.optimize_parameters(i + 1)
+        torch.cuda.synchronize()
+        dt2, ms2 = timed_steps(lambda i: m2.optimize_parameters(3 + i), 4, torch.cuda.synchronize)
+        ops.check_status()
+        line["mixed_mode"] = {"value": round(B * 4 / dt2, 4), "unit": "samples/s", "ms_per_step": round(dt2 / 4 * 1e3, 2),
+                              "step_ms": step_spread(ms2), "config": {"precision": "f16x3", "backward_precision": "f16"},
+                              "parity": "loss and ReLU masks exact (f16x3 forward); parameter gradients ~2e-3 relative vs torch autograd of the "
+                                        "oracle (tests/test_gpu_train.py); converges like f16x3 (profiles/r06_training_modes.md)"}
+        del m2
+        torch.cuda.empty_cache()
     if not standalone:
         return line
     if rank == 0:
