@@ -31,7 +31,8 @@ def create_dataloader(dataset, dataset_opt, opt=None, sampler=None, vscode_debug
 
 
 def create_dataset(dataset_opt):
-    kinds = {"BIN": ("BIN_dataset", "BINDataset")}
+    # "synthetic_texture" is a bin_amd extension: clips rendered on the fly with the structure of the reference's windows
+    kinds = {"BIN": ("BIN_dataset", "BINDataset"), "synthetic_texture": ("synthetic", "SyntheticTextureDataset")}
     mode = dataset_opt["mode"]
     if mode not in kinds:
         raise NotImplementedError("Dataset [{:s}] is not recognized.".format(mode))

@@ -67,3 +67,28 @@ def moving_texture_batch(seed, first_index, batch, size, **kw):
     clips = [moving_texture_clip(seed, first_index + b, size, **kw) for b in range(batch)]
     return {"LQs": torch.stack([c[0] for c in clips]), "GTenh": torch.stack([c[1] for c in clips]),
             "GTinp": torch.stack([c[2] for c in clips])}
+
+
+class SyntheticTextureDataset(torch.utils.data.Dataset):
+    """`datasets.<phase>.mode: synthetic_texture` — the moving-texture clips behind the `BINDataset` item contract
+    (BIN_dataset.py:170-183: LQs / GTenh / GTinp / key), so that `python -m bin_amd.train -opt options/bin_stage4_synthetic.yml` trains
+    and validates with no frames on disk.  Options: `LQ_size: [3, S, S]` (crop), `num_windows` (default 1000), `seed` (default 0; the val
+    phase draws from a different stream), `max_speed` (pixels per instant, default 3)."""
+
+    def __init__(self, opt):
+        size = opt["LQ_size"] or [3, 256, 256]
+        if size[-1] != size[-2]:
+            raise ValueError("synthetic_texture renders square crops: LQ_size must be [3, S, S]")
+        self.size = int(size[-1])
+        self.n = int(opt["num_windows"] or 1000)
+        self.seed = int(opt["seed"] or 0) + (100003 if opt["phase"] != "train" else 0)
+        self.max_speed = float(opt["max_speed"] or 3.0)
+        # (the trainer's probe reads `all_paths[i][3]`, the window key, as it does for BINDataset)
+        self.all_paths = [(None, None, None, "synthetic/%06d" % i) for i in range(self.n)]
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, index):
+        lq, enh, inp = moving_texture_clip(self.seed, index, self.size, max_speed=self.max_speed)
+        return {"LQs": lq, "GTenh": enh, "GTinp": inp, "key": self.all_paths[index][3]}

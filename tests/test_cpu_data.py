@@ -506,3 +506,31 @@ def test_synthetic_moving_texture_clips_have_the_dataset_structure():
     assert float((lq - enh).abs().mean()) < 0.5 * float((enh[0] - enh[5]).abs().mean())      # ... but stays at its instant
     mid = 0.5 * (enh[2] + enh[3])
     assert float((inp[2] - mid).abs().mean()) < float((inp[2] - enh[2]).abs().mean())       # I6 is nearer the mean of I5, I7 than I5
+
+
+def test_train_script_on_the_synthetic_dataset_option_file(tmp_path, monkeypatch):
+    """`mode: synthetic_texture` (bin_amd extension): the shipped options/bin_stage4_synthetic.yml — shrunk to a few tiny windows — goes
+    through option parsing, create_dataset / create_dataloader, the training loop, validation and checkpointing with nothing on disk."""
+    from bin_amd import train
+    from bin_amd.data import create_dataset
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setenv("CUDA_VISIBLE_DEVICES", "")
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    y = open(os.path.join(here, "bin_amd", "options", "bin_stage4_synthetic.yml")).read()
+    y = y.replace("name: synthetic_stage4", "name: debug_synthetic").replace("save_path: ./runs", f"save_path: {tmp_path}")
+    y = y.replace("LQ_size: [3, 128, 128]", "LQ_size: [3, 32, 32]").replace("num_windows: 4000", "num_windows: 12")
+    y = y.replace("batch_size: 8", "batch_size: 2").replace("n_workers: 3", "n_workers: 0").replace("niter: 2000", "niter: 4")
+    y = y.replace("val_freq: 500", "val_freq: 2\n  val_max_batches: 2")
+    p = str(tmp_path / "syn.yml")
+    open(p, "w").write(y)
+    assert train.main(["-opt", p], model_factory=_tiny_factory) == 0
+    exp = tmp_path / "experiments" / "debug_synthetic"
+    assert (exp / "models" / "latest_G.pth").exists()
+    text = open(exp / [f for f in os.listdir(exp) if f.endswith(".log")][0]).read()
+    assert "SyntheticTextureDataset" in text and "<val iter:" in text and "End of training." in text
+    ds = create_dataset({"mode": "synthetic_texture", "name": "v", "phase": "val", "LQ_size": [3, 32, 32], "num_windows": 3, "seed": None, "max_speed": None})
+    tr = create_dataset({"mode": "synthetic_texture", "name": "t", "phase": "train", "LQ_size": [3, 32, 32], "num_windows": 3, "seed": None, "max_speed": None})
+    assert len(ds) == 3 and ds[1]["key"] == "synthetic/000001" and ds[1]["LQs"].shape == (6, 3, 32, 32)
+    assert not torch.equal(ds[0]["LQs"], tr[0]["LQs"])                          # validation draws from its own stream
+    with pytest.raises(ValueError):
+        create_dataset({"mode": "synthetic_texture", "name": "x", "phase": "train", "LQ_size": [3, 32, 48], "num_windows": 3, "seed": None, "max_speed": None})
