@@ -32,6 +32,14 @@
 #ifndef BINHIP_WG3_SPREAD_DMA
 #define BINHIP_WG3_SPREAD_DMA 1
 #endif
+// ... the multiply steps (of 18) behind which the four (plane, chunk) groups go out: FIRST + k * STRIDE.  A group is needed at the
+// next tile's step 0, so a later step leaves its round trip less cover (steps 1 / 5 / 9 / 13: 17 / 13 / 9 / 5 steps)
+#ifndef BINHIP_WG3_DMA_FIRST
+#define BINHIP_WG3_DMA_FIRST 1
+#endif
+#ifndef BINHIP_WG3_DMA_STRIDE
+#define BINHIP_WG3_DMA_STRIDE 4
+#endif
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef short short4_ __attribute__((ext_vector_type(4)));
@@ -604,8 +612,9 @@ wgrad3x3_xrow_kernel(const WgradKArgs a) {
                 }
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
 #if BINHIP_WG3_SPREAD_DMA
-                if constexpr (s % 4 == 1 && s / 4 < (NT == 3 ? 4 : 2)) {
-                    constexpr int grp = s / 4;           // (plane, chunk) = (0,0) (0,1) (1,0) (1,1)
+                if constexpr (s >= BINHIP_WG3_DMA_FIRST && (s - BINHIP_WG3_DMA_FIRST) % BINHIP_WG3_DMA_STRIDE == 0 &&
+                              (s - BINHIP_WG3_DMA_FIRST) / BINHIP_WG3_DMA_STRIDE < (NT == 3 ? 4 : 2)) {
+                    constexpr int grp = (s - BINHIP_WG3_DMA_FIRST) / BINHIP_WG3_DMA_STRIDE;           // (plane, chunk) = (0,0) (0,1) (1,0) (1,1)
                     if (pre) wg3x_issue_part<NT>(a, stage_nxt, grp / 2, grp % 2, cp, cot, wave, to, plane_elems, plane_bytes);
                 }
 #endif
