@@ -28,6 +28,7 @@ Extra objects on the JSON line:
 import argparse
 import ctypes
 import json
+import math
 import os
 import sys
 import time
@@ -191,16 +192,47 @@ def cpu_baseline_worker(full=True):
         if full:
             padded = [util.replicate_pad(f, util.pad_sizes(H, W)) for f in synthetic_frames(1234, 1, H, W, 6)]
             t0 = time.time()
-            O.bin_stage4_forward(padded, canon)
+            ref = O.bin_stage4_forward(padded, canon)
             t_full = time.time() - t0
             res["value"] = round(1.0 / t_full, 6)
+            hip_path = os.environ.get("BIN_AMD_BENCH_HIP_OUT")
+            if hip_path and os.path.exists(hip_path):
+                # the oracle as the CHECKER of the very window the headline timed (same seeded frames, same seeded weights): BASELINE's
+                # metric reads "... ; PSNR vs ref" — this is that figure, live, at full size, beside the tests' fixtures
+                res["hip_vs_oracle"] = compare_with_oracle(torch.load(hip_path), ref, O, util)
             res["sample"] = (f"oracle (PyTorch-CPU restatement of the reference, literal 20-call schedule): ONE full-size "
                              f"6-frame forward at 768x1344 = {t_full:.1f} s on {cores} threads of {res['cpu']} "
                              f"(no extrapolation)")
     return res
 
 
-def cpu_baseline(timeout_s=420):
+def compare_with_oracle(hip, ref, O, util):
+    """(cpu_baseline leg only) the 14 outputs of the timed window against the oracle's, on the 720 x 1280 crop test.py writes."""
+    pads = util.pad_sizes(H, W)
+    worst, mse, diff_px, npx = 0.0, 0.0, 0, 0
+    psnr_u8 = []
+    for a, b in zip(hip, ref):
+        a, b = a.float(), b.float()
+        worst = max(worst, float((a - b).abs().max()))
+        ac = a[..., pads[2]:pads[2] + H, pads[0]:pads[0] + W].clamp(0, 1)
+        bc = b[..., pads[2]:pads[2] + H, pads[0]:pads[0] + W].clamp(0, 1)
+        mse += float(((ac - bc).double() ** 2).mean())
+        ia, ib = O.tensor2img(ac[0]), O.tensor2img(bc[0])
+        diff_px += int((ia != ib).sum())
+        npx += ia.size
+        p = O.calculate_psnr(ia, ib)
+        psnr_u8.append(None if p == float("inf") else round(float(p), 2))
+    mse /= len(ref)
+    return {"outputs": len(ref), "max_abs": worst,
+            "psnr_db_float": (None if mse == 0 else round(10.0 * math.log10(1.0 / mse), 2)),
+            "u8_values_differing": diff_px, "u8_values": npx,
+            "psnr_db_u8_worst": (None if all(v is None for v in psnr_u8) else min(v for v in psnr_u8 if v is not None)),
+            "note": "the 14 outputs of the timed 720p window (HIP, headline precision) against the oracle's outputs on the same seeded frames and "
+                    "weights; psnr_db_float = 10 log10(1 / mean squared difference) over the cropped, clamped outputs; u8 = after the "
+                    "reference's tensor2img (round to uint8): values that differ, worst per-image PSNR (null = every image identical)"}
+
+
+def cpu_baseline(timeout_s=420, hip_outputs=None):
     """Run the CPU baseline in a child process with a hard timeout so it can never stall the bench; if the full-size
     forward does not finish, the crop extrapolation it printed first is reported (and labelled as such)."""
     import subprocess
@@ -208,6 +240,8 @@ def cpu_baseline(timeout_s=420):
             "print('CPU_BASELINE ' + json.dumps(bench.cpu_baseline_worker()), flush=True)" % REPO)
     env = dict(os.environ)
     env["HIP_VISIBLE_DEVICES"] = ""
+    if hip_outputs:
+        env["BIN_AMD_BENCH_HIP_OUT"] = hip_outputs
     out_txt, err_txt = "", ""
     try:
         out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout_s, env=env)
@@ -935,6 +969,13 @@ def main():
             outs[0] = net(*frames, **kw_in)
         dt, step_ms = timed_steps(one_window, args.steps, sync_all)
         out = outs[0]
+        hip_out_path = None
+        if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.zero_data:
+            # the timed window's outputs, kept for the cpu_baseline leg: the oracle it times there also checks them (hip_vs_oracle)
+            import tempfile
+            fd, hip_out_path = tempfile.mkstemp(suffix=".pt", prefix="bin_amd_bench_out_")
+            os.close(fd)
+            torch.save([o.detach().float().cpu() for o in out], hip_out_path)
         # shader clock / package power of the same forwards, in a pass of its own right after the timed region
         do_power = rank == 0 and not args.no_power
         power = power_pass(lambda: net(*frames, **kw_in), dev, min_seconds=1.0, sync=torch.cuda.synchronize) if do_power else None
@@ -1091,7 +1132,9 @@ def main():
             "train": train,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = cpu_baseline(hip_outputs=hip_out_path)
+            if hip_out_path and os.path.exists(hip_out_path):
+                os.remove(hip_out_path)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -654,3 +654,23 @@ def test_smi_device_index_accepts_every_device_spelling():
         smi.device_index("cpu")
     s = smi.Sampler("cuda:0")                    # no GPU in the build container: reports the error, never raises
     assert "samples" in s.summary()
+
+
+def test_bench_live_parity_object():
+    """bench.py's cpu_baseline leg also CHECKS the timed window against the oracle it times there (`cpu_baseline.hip_vs_oracle`): identical
+    outputs read as max_abs 0 / PSNR null, a perturbed output shows up in every field; the object is JSON-serialisable."""
+    import json
+    import bench
+    from bin_amd.utils import util
+    from oracle import rdn_oracle as O
+    g = torch.Generator().manual_seed(0)
+    ref = [torch.rand(1, 3, 768, 1344, generator=g) for _ in range(2)]
+    same = bench.compare_with_oracle([r.clone() for r in ref], ref, O, util)
+    assert same["max_abs"] == 0.0 and same["psnr_db_float"] is None and same["u8_values_differing"] == 0 and same["psnr_db_u8_worst"] is None
+    assert same["u8_values"] == 2 * 3 * 720 * 1280                                   # the crop test.py writes, not the padded frame
+    hip = [r.clone() for r in ref]
+    hip[1][0, 0, 24 + 100, 32 + 100] += 0.25                                         # inside the crop (pads: 24 rows, 32 columns)
+    hip[0][0, 0, 0, 0] += 0.5                                                        # in the padding: counts for max_abs only
+    d = bench.compare_with_oracle(hip, ref, O, util)
+    assert abs(d["max_abs"] - 0.5) < 1e-6 and d["u8_values_differing"] == 1 and d["psnr_db_u8_worst"] is not None and d["psnr_db_float"] > 60
+    json.dumps(d)
