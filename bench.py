@@ -200,6 +200,10 @@ def cpu_baseline_worker(full=True):
                 # the oracle as the CHECKER of the very window the headline timed (same seeded frames, same seeded weights): BASELINE's
                 # metric reads "... ; PSNR vs ref" — this is that figure, live, at full size, beside the tests' fixtures
                 res["hip_vs_oracle"] = compare_with_oracle(torch.load(hip_path), ref, O, util)
+            alt_path = os.environ.get("BIN_AMD_BENCH_ALT_OUT")
+            if alt_path and os.path.exists(alt_path):          # the line's `tolerance_mode` (or `fp32_class`) run of the same window
+                res["other_mode_vs_oracle"] = compare_with_oracle(torch.load(alt_path), ref, O, util)
+                res["other_mode_vs_oracle"]["note"] = "the same check for the precision mode reported beside the headline (tolerance_mode / fp32_class)"
             res["sample"] = (f"oracle (PyTorch-CPU restatement of the reference, literal 20-call schedule): ONE full-size "
                              f"6-frame forward at 768x1344 = {t_full:.1f} s on {cores} threads of {res['cpu']} "
                              f"(no extrapolation)")
@@ -232,7 +236,7 @@ def compare_with_oracle(hip, ref, O, util):
                     "reference's tensor2img (round to uint8): values that differ, worst per-image PSNR (null = every image identical)"}
 
 
-def cpu_baseline(timeout_s=420, hip_outputs=None):
+def cpu_baseline(timeout_s=420, hip_outputs=None, alt_outputs=None):
     """Run the CPU baseline in a child process with a hard timeout so it can never stall the bench; if the full-size
     forward does not finish, the crop extrapolation it printed first is reported (and labelled as such)."""
     import subprocess
@@ -242,6 +246,8 @@ def cpu_baseline(timeout_s=420, hip_outputs=None):
     env["HIP_VISIBLE_DEVICES"] = ""
     if hip_outputs:
         env["BIN_AMD_BENCH_HIP_OUT"] = hip_outputs
+    if alt_outputs:
+        env["BIN_AMD_BENCH_ALT_OUT"] = alt_outputs
     out_txt, err_txt = "", ""
     try:
         out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout_s, env=env)
@@ -969,7 +975,7 @@ def main():
             outs[0] = net(*frames, **kw_in)
         dt, step_ms = timed_steps(one_window, args.steps, sync_all)
         out = outs[0]
-        hip_out_path = None
+        hip_out_path = alt_out_path = None
         if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.zero_data:
             # the timed window's outputs, kept for the cpu_baseline leg: the oracle it times there also checks them (hip_vs_oracle)
             import tempfile
@@ -1044,6 +1050,9 @@ def main():
                 net(*frames)
             torch.cuda.synchronize()
             t_alt = (time.perf_counter() - ta) / n_alt
+            if hip_out_path:                 # the other mode's outputs of the same window, for the same live check
+                alt_out_path = hip_out_path[:-3] + "_alt.pt"
+                torch.save([o.detach().float().cpu() for o in net(*frames)], alt_out_path)
             alt_power = power_pass(lambda: net(*frames), dev, min_seconds=0.6, sync=torch.cuda.synchronize) if do_power else None
             alt_ms, alt_n = dominant_kernel_pass() if prof else (0.0, 0)
             alt = {"precision": other, "dtype": DTYPE[other], "value": round(1.0 / t_alt, 4),
@@ -1132,9 +1141,10 @@ def main():
             "train": train,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(hip_outputs=hip_out_path)
-            if hip_out_path and os.path.exists(hip_out_path):
-                os.remove(hip_out_path)
+            line["cpu_baseline"] = cpu_baseline(hip_outputs=hip_out_path, alt_outputs=alt_out_path)
+            for pth in (hip_out_path, alt_out_path):
+                if pth and os.path.exists(pth):
+                    os.remove(pth)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
