@@ -655,3 +655,19 @@ def test_weights_after_real_optimisation_keep_fp32_class_parity(tmp_path):
             assert err <= bar * mag, (prec, err, mag)
     print(f"(c) done at {time.time() - t0:.1f} s")
     torch.set_num_threads(threads)
+
+
+def test_train_convergence_tool_runs_every_mode(tmp_path):
+    """tools/train_convergence.py (profiles/r06_training_modes.md) at toy size: every mode trains, the loss falls, the status word stays
+    clean, the report files are written."""
+    out = str(tmp_path / "conv")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "train_convergence.py"), "--steps", "24", "--batch", "2", "--size", "32",
+                        "--pool", "8", "--out", out], capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.load(open(out + ".json"))
+    assert set(d["modes"]) == {"f16x3", "f16x3eps", "mixed", "f16"}
+    for mode, row in d["modes"].items():
+        assert row["finite"] and row["status"] == "clean", (mode, row)
+        assert row["loss_last50"] < row["loss_first10"], (mode, row)
+        assert row["heldout_loss_f16x3_eval"] < d["initialiser"]["heldout_loss"], (mode, row)
+    assert "| mixed |" in open(out + ".md").read()

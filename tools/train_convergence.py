@@ -106,7 +106,9 @@ def main():
         sd = {k: v.detach().clone() for k, v in m.netG.module.state_dict().items()}
         hl, hp = evaluate(sd, held_out)
         n = a.steps
-        win = lambda lo, hi: sum(losses[lo:hi]) / max(1, hi - lo)      # noqa: E731
+        def win(lo, hi):
+            lo, hi = max(0, lo), min(n, hi)
+            return sum(losses[lo:hi]) / max(1, hi - lo)
         row = {"ms_per_step": dt / n * 1e3, "status": status,
                "loss_first10": win(0, 10), "loss_at_10pct": win(n // 10 - 5, n // 10 + 5), "loss_at_50pct": win(n // 2 - 10, n // 2 + 10),
                "loss_last50": win(n - 50, n), "heldout_loss_f16x3_eval": hl, "heldout_psnr_db": hp,
