@@ -12,6 +12,13 @@
 // (numbers for bin_stage4's shape G0 = 96, D = 12, C = 4, G = 32; in general c0 = G0/16 planes per feature map, cg = G/16
 //  per conv output, BLK [D + 1][c0 + C cg], layer index 2 + d (C + 1) + c — include/binhip.h, BinRdnShape)
 #include "binhip_conv_common.h"
+// 1 (default since round 6) = the forward's 1x1 layers (GFF.0, an unfused LFF) run on the pixel grid reshaped to 32-pixel rows (see
+// mk()): bit-identical, 720p window -0.3 % (GFF.0 reads 1152 channel planes: 8 KiB contiguous per plane and tile instead of 8 runs of
+// 1 KiB at a 21 KiB pitch).  The same reshape in the BACKWARD plan (1x1 backward-data and weight gradients at 128-pixel rows) measured
+// +0.2 / +0.3 / -0.05 % on the training step and is not there (profiles/r06_experiments.md).  0 = side builds, the old geometry.
+#ifndef BINHIP_PLAN_LINEAR_1X1
+#define BINHIP_PLAN_LINEAR_1X1 1
+#endif
 
 namespace {
 
@@ -130,6 +137,11 @@ int binhip_rdn_forward(const BinRdnPlan* p, const float* const* inputs, float* o
         c.d.N = N; c.d.H = Hc; c.d.W = Wc; c.d.ksize = ks; c.d.cin_chunks = cin_chunks; c.d.cout = cout;
         c.d.cout_pad = cout_pad; c.d.nterms = nt; c.d.epilogue = epi; c.d.relu = relu;
         c.d.x_cpg = cpg; c.d.x_group_stride = gstride; c.d.n_images = 0; c.d.reserved = 0; c.d.status = p->status;
+#if BINHIP_PLAN_LINEAR_1X1
+        // a 1x1 convolution is pointwise: any reshape of the pixel grid computes the same values.  [H][W] -> [H * W / 32][32] makes a
+        // workgroup's TH x 32 tile TH KiB of CONTIGUOUS bytes per plane instead of TH runs of 1 KiB at a row pitch of W * 32 B
+        if (ks == 1 && epi == BINHIP_EPI_PLANES && Wc > 32 && Wc % 32 == 0) { c.d.H = Hc * (Wc / 32); c.d.W = 32; }
+#endif
         // SFENet1 on 2 / 3 input frames: 24 / 36 channels = the last chunk's upper half is zero padding (packer and relayout)
         if (layer == 0 && ks == 5 && (12 * nin) % 16 >= 1 && (12 * nin) % 16 <= 8) c.d.reserved = BINHIP_CONV_HALF_LAST_CHUNK;
         c.x_hi = HI(x_off); c.x_lo = LO(x_off, x_size);
