@@ -478,6 +478,13 @@ static int g_xcd_remap = 1, g_dbg = 0, g_wt = 1;
 #endif
 
 // waves (= tile rows) of the wide backward-data 1x1 tiles (LFF: 224 rows, GFF.0: 192): 8 = one workgroup per CU, 4 = two
+// GFF.0 in the fp32-class mode (1x1, 1152 -> 96): rows per wave and waves of its tile (side builds; the product's 2 x 4 = 8 x 32 pixels)
+#ifndef BINHIP_GFF0_R
+#define BINHIP_GFF0_R 2
+#endif
+#ifndef BINHIP_GFF0_WN
+#define BINHIP_GFF0_WN 4
+#endif
 #ifndef BINHIP_K1_DGRAD_WN
 #define BINHIP_K1_DGRAD_WN 8
 #endif
@@ -553,7 +560,7 @@ static int bh_dispatch_conv(const ConvKArgs& a0, int k, int cp, int nt, int e, h
         if (e == P && k == 1 && cb == 192) return launch_cfg<1, 6, 1, 1, BINHIP_K1_DGRAD_WN, 1, 3, 2, P>(a, cp, s);   // GFF.0 dgrad
         if (e == P && k == 1 && cb == 32)  return launch_cfg<1, 1, 1, 4, 4, 2, 3, 2, P>(a, cp, s);
         if (e == P && k == 1 && cb == 96) {
-            if (a.nchunks >= 32) return launch_cfg<1, 3, 1, 2, 4, 1, 3, 2, P>(a, cp, s);
+            if (a.nchunks >= 32) return launch_cfg<1, 3, 1, BINHIP_GFF0_R, BINHIP_GFF0_WN, 1, 3, 2, P>(a, cp, s);   // GFF.0
             return launch_cfg<1, 3, 1, 1, 8, 1, 3, 2, P>(a, cp, s);    // LFF 90 vs 108 us
         }
         if (e == P && k == 5 && cb == 32 && BINHIP_K5_X3) return bh_launch_conv_x3_k5(a, cp, s);   // plane-split stages, double-buffered
