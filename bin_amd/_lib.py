@@ -7,10 +7,10 @@ from .build import LIB_PATH
 
 RDN_LAYERS = 66              # bin_stage4's layer count; BinRdnPlan arrays hold RDN_MAX_LAYERS
 RDN_MAX_LAYERS, RDN_MAX_CONVS = 192, 7
-PLAN_KEEP_ACTS, PLAN_NO_FUSE, PLAN_RDB3 = 1, 2, 4
+PLAN_KEEP_ACTS, PLAN_NO_FUSE, PLAN_RDB3, PLAN_FUSED_UPNET = 1, 2, 4, 8
 BWD_ACCUMULATE = 1          # BinRdnBwdPlan.reserved flag (BINHIP_BWD_ACCUMULATE)
 BWD_SAVED_X3 = 2            # BINHIP_BWD_SAVED_X3
-EPI_PLANES, EPI_SHUFFLE, EPI_FINAL = 0, 1, 2
+EPI_PLANES, EPI_SHUFFLE, EPI_FINAL, EPI_FINAL_SUBPIX = 0, 1, 2, 4
 PROF_WGRAD = 16             # BINHIP_PROF_WGRAD
 LOSS_CHARBONNIER, LOSS_L1_SUM, LOSS_L2_SUM = 0, 1, 2
 RDN_LAYOUT_WORDS, RDN_BWD_LAYOUT_WORDS = 16, 24

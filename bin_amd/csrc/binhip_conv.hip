@@ -358,6 +358,7 @@ static int bh_dispatch_conv(const ConvKArgs& a, int k, int cp, int nt, int e, hi
 int bh_launch_conv_x3(const ConvKArgs& a, int cout_pad, int epilogue, hipStream_t s);   // binhip_conv_x3.hip
 int bh_launch_final_dot2(const ConvKArgs& a, int nterms, hipStream_t s);                 // binhip_conv_x3.hip
 int bh_launch_conv_x3_k5(const ConvKArgs& a, int cout_pad, hipStream_t s);               // binhip_conv_x3.hip
+int bh_launch_conv_x3_k5_subpix(const ConvKArgs& a, hipStream_t s);                      // binhip_conv_x3.hip
 int bh_launch_final_m16(const ConvKArgs& a, hipStream_t s);                              // binhip_conv_x3.hip
 #ifndef BINHIP_LFFD_EPI
 #define BINHIP_LFFD_EPI 1     // 0 (side builds): the LFF backward-data tile on the generic extras grouping (rounds 2-3)
@@ -426,6 +427,9 @@ int bh_prepare_conv(const BhConvCall& c, ConvKArgs* out) {
         if (d.cout % 4) return BINHIP_E_SHAPE;
     } else if (d.epilogue == F) {
         if (!c.y_f32 || d.cout > 4 || d.n_images < 0 || d.n_images > 5) return BINHIP_E_ARG;
+    } else if (d.epilogue == BINHIP_EPI_FINAL_SUBPIX) {      // the fused UPNet: 4 sub-pixel channels per colour, fp32-class 5x5 only
+        if (!c.y_f32 || d.cout <= 0 || (d.cout & 3) || d.cout > 12 || d.n_images < 0 || d.n_images > 5) return BINHIP_E_ARG;
+        if (d.ksize != 5 || d.nterms != 3 || d.cout_pad != 32) return BINHIP_E_SHAPE;
     } else {
         return BINHIP_E_ARG;
     }
@@ -498,6 +502,7 @@ static int bh_dispatch_conv(const ConvKArgs& a0, int k, int cp, int nt, int e, h
     a.dbg = g_dbg;
     if (!g_wt) a.wt = 0;
 #endif
+    if (e == BINHIP_EPI_FINAL_SUBPIX) return bh_launch_conv_x3_k5_subpix(a, s);      // the fused UPNet (shape checked in bh_prepare_conv)
     // UPNet.2 (64 -> 3 + mean of the frames) in the single-product mode: three output channels as VALU dot products instead of
     // a 32-row MFMA tile (f16 720p window 33.02 -> 32.71 ms).  In the fp32-class mode the same kernel needs 648 dot2 per lane
     // and chunk behind 112 scalar weight loads and measured 224 us against the MFMA kernel's 110 (profiles/r03_experiments.md):

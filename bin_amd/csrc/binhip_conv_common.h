@@ -14,6 +14,8 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+int bh_launch_upnet_ring(const void* x_hi, const void* x_lo, const float* wvar, const float* bvar, float* out, const float* const* images,
+                         int nimg, int N, int H, int W, int cin, hipStream_t s);      // binhip_conv_x3.hip (BINHIP_PLAN_FUSED_UPNET)
 struct ConvKArgs {
     const _Float16* x_hi;
     const _Float16* x_lo;
@@ -177,7 +179,54 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const float* _
 #pragma unroll
         for (int j = 0; j < 4; ++j) bv[j] = kg ? b8[4 + j] : b8[j];
     };
-    if constexpr (EPI == BINHIP_EPI_FINAL) {
+    if constexpr (EPI == BINHIP_EPI_FINAL_SUBPIX) {
+        // The fused UPNet (BINHIP_PLAN_FUSED_UPNET): this convolution runs at HALF resolution and its output channel c * 4 + i * 2 + j is
+        // colour c at sub-pixel (i, j) of the full-resolution pixel block (2 gy + i, 2 gx + j).  In the MFMA's C layout lane (n, kg)
+        // holds channels 8 g + 4 kg + 0..3 in acc[..][4 g + 0..3]: slot g = 0 is colour kg's 2 x 2 block, slot g = 1 colour 2 + kg's
+        // (colour 2 for kg = 0; nothing for kg = 1) — two 2-float row pieces per block, 32 lanes = 256 contiguous bytes per row.
+        // + bias + mean of the input frames (RDN.py:221/279/333) -> fp32 NCHW [N, cout / 4, 2 H, 2 W].  Loads first, then stores.
+        const int ncolour = a.cout >> 2;
+        const int H2 = 2 * H, W2 = 2 * W;
+        float bv[2][4];
+        bias4(co0, bv[0]);
+        bias4(co0 + 8, bv[1]);
+        const bool col_ok = first_col && (gx < W);
+        float sum[R][2][4];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int gy = row0 + r;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int c = 2 * g + kg;
+                const bool ok = col_ok && gy < H && c < ncolour;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float sj = 0.f;
+                    if (ok && a.nimg > 0) {
+                        const long long idx = (((long long)img * ncolour + c) * H2 + 2 * gy + (q >> 1)) * W2 + 2 * gx + (q & 1);
+                        sj = a.img[0][idx];
+                        for (int t = 1; t < a.nimg; ++t) sj += a.img[t][idx];
+                        sj = sj / (float)a.nimg;
+                    }
+                    sum[r][g][q] = sj;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int gy = row0 + r;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int c = 2 * g + kg;
+                if (!(col_ok && gy < H && c < ncolour)) continue;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const long long idx = (((long long)img * ncolour + c) * H2 + 2 * gy + (q >> 1)) * W2 + 2 * gx + (q & 1);
+                    a.out_f32[idx] = (acc[0][r][4 * g + q] + bv[g][q]) + sum[r][g][q];
+                }
+            }
+        }
+    } else if constexpr (EPI == BINHIP_EPI_FINAL) {
         float bv[4];
         bias4(co0, bv);
         // every frame load of the wave's R rows first, then the stores (a load behind a store would wait for the store)

@@ -957,6 +957,88 @@ int bh_launch_conv_x3_k5(const ConvKArgs& a, int cout_pad, hipStream_t s) {
     return launch_x3<5, BINHIP_X3_R, BINHIP_X3_WN, BINHIP_EPI_PLANES, 1>(a, cout_pad, s);
 }
 
+// the fused UPNet (BINHIP_PLAN_FUSED_UPNET): 5x5, G0 -> 12 sub-pixel channels at half resolution, fp32 NCHW full-resolution output
+int bh_launch_conv_x3_k5_subpix(const ConvKArgs& a, hipStream_t s) {
+    return launch_x3<5, BINHIP_X3_R, BINHIP_X3_WN, BINHIP_EPI_FINAL_SUBPIX, 0>(a, 32, s);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The border ring of the fused UPNet.  UPNet.2 (RDN.py:207) zero-pads the 64-channel full-resolution tensor it reads, i.e. where
+// its 3x3 window leaves the image a tap contributes nothing — the one-convolution form (W_eff over a zero-padded INPUT) instead
+// sees "UPNet.0 of the padded input" there.  The two differ on the outermost full-resolution pixel ring only; for those
+// 4 H + 4 W - 4 pixels (H, W: half resolution) the host supplies the exact operators (fp32 [9][12][25][cin], variant = 3 vy + vx,
+// bin_amd/rdn_plan.py fused_upnet_weights) and this kernel recomputes them: one wave per ring pixel, the 25 * cin products of
+// the pixel's three colours spread over the lanes (fp32 FMA on hi + lo), a butterfly sum, lane 0 stores.  ~30 MFLOP per call.
+struct RingArgs {
+    const _Float16* x_hi;
+    const _Float16* x_lo;
+    const float* wvar;
+    const float* bvar;
+    float* out;
+    const float* img[5];
+    int N, H, W, cin, nimg;
+};
+__global__ void __launch_bounds__(64) upnet_ring_kernel(const RingArgs a) {
+    const int lane = threadIdx.x;
+    const int H = a.H, W = a.W, H2 = 2 * H, W2 = 2 * W;
+    const int ring = 2 * W2 + 2 * (H2 - 2);
+    int id = blockIdx.x;
+    const int img = id / ring;
+    id -= img * ring;
+    int Y, X;
+    if (id < W2) { Y = 0; X = id; }
+    else if (id < 2 * W2) { Y = H2 - 1; X = id - W2; }
+    else { const int k = id - 2 * W2; Y = 1 + (k >> 1); X = (k & 1) ? W2 - 1 : 0; }
+    const int y = Y >> 1, i = Y & 1, x = X >> 1, j = X & 1;
+    const int vy = (Y == 0) ? 0 : (Y == H2 - 1 ? 2 : 1), vx = (X == 0) ? 0 : (X == W2 - 1 ? 2 : 1);
+    const int var = 3 * vy + vx, sub = 2 * i + j;
+    const int cin = a.cin, terms = 25 * cin;
+    const long long wstride = (long long)25 * cin;                       // one output channel
+    const float* w = a.wvar + ((long long)var * 12 + sub) * wstride;       // colour c at + 4 c * wstride
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int q = lane; q < terms; q += 64) {
+        const int tap = q / cin, ci = q - tap * cin;
+        const int yy = y + tap / 5 - 2, xx = x + tap % 5 - 2;
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+        const long long o = (((((long long)(ci >> 4) * a.N + img) * H + yy) * W + xx) << 4) + (ci & 15);
+        float xv = (float)a.x_hi[o];
+        if (a.x_lo) xv += (float)a.x_lo[o];
+        s0 = fmaf(w[q], xv, s0);
+        s1 = fmaf(w[q + 4 * wstride], xv, s1);
+        s2 = fmaf(w[q + 8 * wstride], xv, s2);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s0 += __shfl_xor(s0, off);
+        s1 += __shfl_xor(s1, off);
+        s2 += __shfl_xor(s2, off);
+    }
+    if (lane < 3) {
+        const int c = lane;
+        const float s = c == 0 ? s0 : (c == 1 ? s1 : s2);
+        const long long idx = (((long long)img * 3 + c) * H2 + Y) * W2 + X;
+        float m = 0.f;
+        if (a.nimg > 0) {
+            m = a.img[0][idx];
+            for (int t = 1; t < a.nimg; ++t) m += a.img[t][idx];
+            m = m / (float)a.nimg;
+        }
+        a.out[idx] = (s + a.bvar[var * 12 + 4 * c + sub]) + m;
+    }
+}
+int bh_launch_upnet_ring(const void* x_hi, const void* x_lo, const float* wvar, const float* bvar, float* out, const float* const* images,
+                         int nimg, int N, int H, int W, int cin, hipStream_t s) {
+    if (!x_hi || !wvar || !bvar || !out || N <= 0 || H <= 0 || W <= 0 || cin <= 0 || (cin & 15) || nimg < 0 || nimg > 5) return BINHIP_E_ARG;
+    RingArgs a;
+    a.x_hi = (const _Float16*)x_hi; a.x_lo = (const _Float16*)x_lo; a.wvar = wvar; a.bvar = bvar; a.out = out;
+    for (int t = 0; t < 5; ++t) a.img[t] = (t < nimg) ? images[t] : nullptr;
+    a.N = N; a.H = H; a.W = W; a.cin = cin; a.nimg = nimg;
+    const long long ring = 4ll * W + 4ll * H - 4;
+    upnet_ring_kernel<<<dim3((unsigned)(ring * N)), dim3(64), 0, s>>>(a);
+    BH_CHECK_LAUNCH();
+    return 0;
+}
+
 int bh_launch_conv_x3(const ConvKArgs& a, int cout_pad, int epilogue, hipStream_t s) {
     if (epilogue == BINHIP_EPI_PLANES)
         return cout_pad == 32 ? launch_x3<3, BINHIP_X3_R, BINHIP_X3_WN, BINHIP_EPI_PLANES, 0>(a, cout_pad, s)

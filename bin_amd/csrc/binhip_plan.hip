@@ -154,7 +154,7 @@ int binhip_rdn_forward(const BinRdnPlan* p, const float* const* inputs, float* o
         c.status = p->status;
         c.prof = p->profiler;
         for (int i = 0; i < 5; ++i) c.images[i] = nullptr;
-        if (epi == BINHIP_EPI_FINAL) {
+        if (epi == BINHIP_EPI_FINAL || epi == BINHIP_EPI_FINAL_SUBPIX) {
             c.y_f32 = out;
             c.d.n_images = nin;
             for (int i = 0; i < nin; ++i) c.images[i] = inputs[i];
@@ -223,6 +223,17 @@ int binhip_rdn_forward(const BinRdnPlan* p, const float* const* inputs, float* o
     if ((rc = conv(LG, 1, D * c0, G0, G0, P_, 0, h, ww, w.blk + (int64_t)cb * P, w.s_blk, c0, (int64_t)cb * P, w.g0, w.s_g, -1, 0))) return rc;
     // GFF.1 3x3, x += f__1 (RDN.py:200, 219)
     if ((rc = conv(LG + 1, 3, c0, G0, G0, P_, 0, h, ww, w.g0, w.s_g, 0, 0, w.g1, w.s_g, w.f1, w.s_f1))) return rc;
+    // UPNet as ONE 5x5 convolution G0 -> 12 sub-pixel channels (BINHIP_PLAN_FUSED_UPNET, include/binhip.h): inference only — training keeps
+    // the two layers, whose activations and separate weight gradients its backward needs
+    const bool fused_up = (p->reserved & BINHIP_PLAN_FUSED_UPNET) && !(p->reserved & BINHIP_PLAN_KEEP_ACTS) && nt == 3 &&
+                          sh.L + 1 < BINHIP_RDN_MAX_LAYERS && p->w_hi[sh.L] && p->w_lo[sh.L] && p->bias[sh.L] && p->w_hi[sh.L + 1] &&
+                          p->bias[sh.L + 1];
+    if (fused_up) {
+        if ((rc = bh_launch_conv(mk(sh.L, 5, c0, 12, 32, BINHIP_EPI_FINAL_SUBPIX, 0, h, ww, w.g1, w.s_g, 0, 0, -1, 0, -1, 0), s))) return rc;
+        // ... and the one-pixel full-resolution border ring from its own operators (UPNet.2 pads the intermediate, not the input)
+        return bh_launch_upnet_ring(HI(w.g1), LO(w.g1, w.s_g), (const float*)p->w_hi[sh.L + 1], p->bias[sh.L + 1], out, inputs, nin, N, h, ww,
+                                    G0, s);
+    }
     // UPNet.0 3x3 G0->256 + PixelShuffle(2) (RDN.py:205-206)
     if ((rc = conv(LG + 2, 3, c0, 256, 256, BINHIP_EPI_SHUFFLE, 0, h, ww, w.g1, w.s_g, 0, 0, w.u, w.s_u, -1, 0))) return rc;
     // UPNet.2 3x3 64->3 + mean(inputs) (RDN.py:207, 221/279/333)

@@ -38,6 +38,71 @@ def layer_names(shape=STAGE4_SHAPE):
     return names
 
 
+def fused_upnet_weights(w0, b0, w2, b2):
+    """UPNet (RDN.py:203-207) = conv3x3(G0 -> 256) -> PixelShuffle(2) -> conv3x3(64 -> 3) has no activation between its layers, so it is
+    ONE linear map: a 5x5 convolution G0 -> 12 at half resolution whose output channel c * 4 + i * 2 + j is colour c at sub-pixel (i, j):
+        O[c, 2y+i, 2x+j] = b2[c] + sum_{k,dy,dx} W2[c,k,dy,dx] * U[k, 2y+i+dy-1, 2x+j+dx-1],   U[k, 2y'+i', 2x'+j'] = (W0 * x + b0)[4k+2i'+j', y', x']
+    with y' = y + floor((i+dy-1)/2), i' = (i+dy-1) mod 2: the 3x3 of W0 lands at offset (oy, ox) = (floor((i+dy-1)/2), floor((j+dx-1)/2))
+    inside the 5x5.  UPNet.2 zero-pads U, not x: where its window leaves the full-resolution image the tap contributes NOTHING (not even b0), so
+    the outermost full-resolution pixel ring has its own operators.  Returns (W [9, 12, G0, 5, 5], b [9, 12]) in float64; variant 3 vy + vx,
+    v = 0 first row (column), 1 interior, 2 last row (column); only the sub-pixels that lie ON the ring differ from the interior form.
+    3.4 x fewer multiply-adds than the two layers (25 * 12 * G0 against 9 * 256 * G0 + 4 * 9 * 64 * 3 per half-resolution pixel)."""
+    w0, b0, w2, b2 = (t.detach().double() for t in (w0, b0, w2, b2))
+    g0 = w0.shape[1]
+    assert w0.shape == (256, g0, 3, 3) and w2.shape == (3, 64, 3, 3) and b0.shape == (256,) and b2.shape == (3,)
+    k4 = torch.arange(64, device=w0.device) * 4
+    # contribution of UPNet.2's tap (dy, dx) to sub-pixel (i, j): [3, g0, 3, 3] weights at offset (oy + 1, ox + 1) of the 5x5, [3] bias
+    contrib = {}
+    for i in range(2):
+        for j in range(2):
+            for dy in range(3):
+                for dx in range(3):
+                    oy, ip = divmod(i + dy - 1, 2)
+                    ox, jp = divmod(j + dx - 1, 2)
+                    ch = k4 + 2 * ip + jp
+                    wc = torch.einsum("ck,kgab->cgab", w2[:, :, dy, dx], w0[ch])
+                    bc = w2[:, :, dy, dx] @ b0[ch]
+                    contrib[(i, j, dy, dx)] = (oy + 1, ox + 1, wc, bc)
+    W = torch.zeros(9, 12, g0, 5, 5, dtype=torch.float64, device=w0.device)
+    B = torch.zeros(9, 12, dtype=torch.float64, device=w0.device)
+    for vy in range(3):
+        for vx in range(3):
+            v = 3 * vy + vx
+            for i in range(2):
+                for j in range(2):
+                    rows = torch.arange(3, device=w0.device) * 4 + 2 * i + j
+                    B[v, rows] += b2
+                    for dy in range(3):
+                        # the source row 2y + i + dy - 1 is outside the image: first row (i = 0) looking up, last row (i = 1) looking down
+                        if (vy == 0 and i == 0 and dy == 0) or (vy == 2 and i == 1 and dy == 2):
+                            continue
+                        for dx in range(3):
+                            if (vx == 0 and j == 0 and dx == 0) or (vx == 2 and j == 1 and dx == 2):
+                                continue
+                            oy, ox, wc, bc = contrib[(i, j, dy, dx)]
+                            W[v, rows, :, oy:oy + 3, ox:ox + 3] += wc
+                            B[v, rows] += bc
+    return W, B
+
+
+def fused_upnet_reference(x, W, B):
+    """Plain-torch statement of what the fused UPNet computes from `fused_upnet_weights` (tests; the device path is
+    BINHIP_PLAN_FUSED_UPNET): the interior operator everywhere, then the full-resolution border ring from its own variants."""
+    import torch.nn.functional as F
+    x = x.double()
+    out = F.pixel_shuffle(F.conv2d(x, W[4], B[4], padding=2), 2)
+    h2, w2 = out.shape[-2:]
+    for vy in range(3):
+        for vx in range(3):
+            if vy == 1 and vx == 1:
+                continue
+            full = F.pixel_shuffle(F.conv2d(x, W[3 * vy + vx], B[3 * vy + vx], padding=2), 2)
+            ys = {0: slice(0, 1), 1: slice(1, h2 - 1), 2: slice(h2 - 1, h2)}[vy]
+            xs = {0: slice(0, 1), 1: slice(1, w2 - 1), 2: slice(w2 - 1, w2)}[vx]
+            out[..., ys, xs] = full[..., ys, xs]
+    return out
+
+
 class RdnWeights:
     """Kernel-layout weights of one RDN weight set + the BinRdnPlan pointer table."""
 
@@ -56,6 +121,24 @@ class RdnWeights:
         relayout_batch(items)
 
         self._dgrad = None
+        # the fused UPNet's operands (BINHIP_PLAN_FUSED_UPNET) are built on the first INFERENCE call of this weight version
+        # (ensure_fused_upnet): a training step rebuilds its RdnWeights every step and never needs them
+        self._up_src = tuple(params[f"{prefix}UPNet.{k}.{t}"] for k in (0, 2) for t in ("weight", "bias"))
+        self.fused_up = None
+
+    def ensure_fused_upnet(self):
+        """(ConvWeights of the [12][G0][5][5] interior operator, fp32 [9][12][25][G0] ring operators, fp32 [9][12] ring biases) or None when
+        this weight set has no such form (single-product mode: the plan ignores the flag)."""
+        if self.fused_up is None and self.nterms == 3 and self._up_src is not None:
+            with torch.no_grad():
+                w0, b0, w2, b2 = self._up_src
+                if tuple(w0.shape[2:]) == (3, 3) and w0.shape[0] == 256 and tuple(w2.shape) == (3, 64, 3, 3):
+                    W, B = fused_upnet_weights(w0, b0, w2, b2)
+                    main = ConvWeights(W[4].float().contiguous(), B[4].float().contiguous(), nterms=3)
+                    ring_w = W.permute(0, 1, 3, 4, 2).reshape(9, 12, 25, W.shape[2]).float().contiguous()
+                    self.fused_up = (main, ring_w, B.float().contiguous())
+            self._up_src = None
+        return self.fused_up
 
     def fill_plan(self, plan):
         plan.shape = c_shape(self.shape)
@@ -63,6 +146,11 @@ class RdnWeights:
             plan.w_hi[i] = cw.w_hi.data_ptr()
             plan.w_lo[i] = cw.w_lo.data_ptr() if cw.w_lo is not None else None
             plan.bias[i] = cw.bias.data_ptr()
+        n = len(self.layers)
+        if self.fused_up is not None:
+            main, ring_w, ring_b = self.fused_up
+            plan.w_hi[n], plan.w_lo[n], plan.bias[n] = main.w_hi.data_ptr(), main.w_lo.data_ptr(), main.bias.data_ptr()
+            plan.w_hi[n + 1], plan.w_lo[n + 1], plan.bias[n + 1] = ring_w.data_ptr(), None, ring_b.data_ptr()
 
     def dgrad(self, module, nterms=None):
         """Backward-data weights (transposed + flipped), built on first use for the same parameter version; `nterms`
@@ -179,7 +267,12 @@ import os as _os
 def default_plan_flags():
     """Plan flags a freshly built RDN module starts with (its `plan_flags` attribute; tests pass BINHIP_PLAN_NO_FUSE /
     BINHIP_PLAN_RDB3 per call).  BIN_AMD_RDB3=1: convs 0-2 of every dense block as three phases of one launch."""
-    return L.PLAN_RDB3 if _os.environ.get("BIN_AMD_RDB3", "0") == "1" else 0
+    flags = L.PLAN_RDB3 if _os.environ.get("BIN_AMD_RDB3", "0") == "1" else 0
+    # round 6: UPNet (conv3x3 -> PixelShuffle -> conv3x3, no activation in between) as ONE 5x5 convolution in inference (fp32-class
+    # mode; same function up to fp32 summation order, 3.4 x fewer multiply-adds).  BIN_AMD_FUSED_UPNET=0: the two layers, as in training
+    if _os.environ.get("BIN_AMD_FUSED_UPNET", "1") != "0":
+        flags |= L.PLAN_FUSED_UPNET
+    return flags
 
 
 def rdn_forward(weights, inputs, out=None, ws=None, flags=0, profiler=None):
@@ -201,6 +294,8 @@ def _rdn_forward(weights, inputs, out, ws, flags, profiler):
     plan.reserved = int(flags or 0)
     plan.status = status_word(inputs[0].device).data_ptr()
     plan.profiler = profiler if profiler else None
+    if (plan.reserved & L.PLAN_FUSED_UPNET) and not (plan.reserved & L.PLAN_KEEP_ACTS):
+        weights.ensure_fused_upnet()
     weights.fill_plan(plan)
     nbytes = lib.binhip_rdn_workspace_bytes(n, h, w, weights.n_inputs, weights.nterms, C.byref(plan.shape))
     if nbytes == 0:

@@ -49,7 +49,7 @@ extern "C" {
 /* Interface version = what binhip_version() of a matching library returns (100 x round + revision); a binder checks
  * `binhip_version() == BINHIP_VERSION` after dlopen.  BINHIP_ABI_EXPORTS = number of BINHIP_API entry points below
  * (tests/test_cpu_host.py keeps it equal to the declarations and to `nm -D`). */
-#define BINHIP_VERSION 600
+#define BINHIP_VERSION 610
 #define BINHIP_ABI_EXPORTS 45
 
 #define BINHIP_E_ARG      (-1)   /* null pointer / bad enum */
@@ -63,6 +63,9 @@ extern "C" {
 #define BINHIP_EPI_PLANES  0     /* y = [relu](conv + b [+ residual]) -> chunk planes            */
 #define BINHIP_EPI_SHUFFLE 1     /* conv + b -> PixelShuffle(2) -> chunk planes at 2H x 2W       */
 #define BINHIP_EPI_FINAL   2     /* conv + b + mean(images) -> fp32 NCHW [N,cout,H,W]            */
+#define BINHIP_EPI_FINAL_SUBPIX 4 /* a half-resolution conv whose cout = 4 c' channels are the 2 x 2 sub-pixels of c' <= 3 colour
+                                     channels (order c' * 4 + i * 2 + j): conv + b + mean(images) -> fp32 NCHW [N,c',2H,2W].  The
+                                     epilogue of the FUSED UPNet (BINHIP_PLAN_FUSED_UPNET below); fp32-class mode, 5x5, cout_pad 32 */
 
 #define BINHIP_RDN_LAYERS 66     /* bin_stage4: SFE1, SFE2, 12 x (4 conv + LFF), GFF.0, GFF.1, UP.0, UP.2 */
 /* Shape of an RDN sub-network (constructor arguments of RDN.py:168-186): G0 feature channels, D residual dense blocks of
@@ -281,6 +284,16 @@ BINHIP_API int binhip_rdb_tail_fwd(int N, int H, int W, int nterms, const void* 
 #define BINHIP_PLAN_RDB3      4   /* nterms = 3: convs 0-2 of each RDB as three phases of ONE launch */
                                   /* (static tile ownership + per-tile neighbour flags, no grid       */
                                   /* barrier; per-conv launches when the grid cannot be co-resident)  */
+#define BINHIP_PLAN_FUSED_UPNET 8 /* inference (not with KEEP_ACTS), nterms = 3: UPNet = conv3x3(G0 -> 256) -> PixelShuffle(2) ->   */
+                                  /* conv3x3(64 -> 3) (RDN.py:203-207) has no activation in between, so it IS one linear map:     */
+                                  /* a 5x5 convolution G0 -> 12 at half resolution (W_eff = W2 * shuffle * W0, 3.4 x fewer MACs,  */
+                                  /* no 256-channel intermediate).  The caller supplies it: slot L = 2 + D (C + 1) + 4 of         */
+                                  /* w_hi / w_lo / bias = the relayouted [12][G0][5][5] weights + 12 biases (interior form), slot  */
+                                  /* L + 1: w_hi = fp32 [9][12][25][G0] border variants, bias = fp32 [9][12] (variant 3 vy + vx,   */
+                                  /* v = 0 first row / column, 1 interior, 2 last): the one-pixel full-resolution border ring,     */
+                                  /* where UPNet.2's zero padding of the INTERMEDIATE differs from padding the input, is           */
+                                  /* recomputed exactly by a second small launch.  Same function as the two-layer form up to fp32  */
+                                  /* summation order; bin_amd/rdn_plan.py builds the operands (fused_upnet_weights).               */
 typedef struct BinRdnPlan {
     int32_t N, H, W;          /* full-resolution frame size (H, W even)                          */
     int32_t n_inputs;         /* 2, 3 or 5 input frames                                          */

@@ -674,3 +674,26 @@ def test_bench_live_parity_object():
     d = bench.compare_with_oracle(hip, ref, O, util)
     assert abs(d["max_abs"] - 0.5) < 1e-6 and d["u8_values_differing"] == 1 and d["psnr_db_u8_worst"] is not None and d["psnr_db_float"] > 60
     json.dumps(d)
+
+
+def test_fused_upnet_weights_reproduce_the_two_layers():
+    """rdn_plan.fused_upnet_weights: UPNet's two convolutions around the PixelShuffle (RDN.py:203-207, no activation) as one 5x5
+    operator on 12 sub-pixel channels + the nine border variants — in float64 the composition equals F.conv2d / F.pixel_shuffle /
+    F.conv2d to rounding on every pixel, including 1 x 1 and 2 x 3 inputs where everything is border; the interior operator alone
+    is right everywhere but on the one-pixel full-resolution ring."""
+    import torch.nn.functional as F
+    from bin_amd.rdn_plan import fused_upnet_reference, fused_upnet_weights
+    g = torch.Generator().manual_seed(0)
+    g0 = 32
+    w0, b0 = torch.randn(256, g0, 3, 3, generator=g).double() * 0.1, torch.randn(256, generator=g).double() * 0.1
+    w2, b2 = torch.randn(3, 64, 3, 3, generator=g).double() * 0.1, torch.randn(3, generator=g).double()
+    W, B = fused_upnet_weights(w0, b0, w2, b2)
+    assert W.shape == (9, 12, g0, 5, 5) and B.shape == (9, 12)
+    for h, w in ((7, 9), (1, 1), (2, 3), (16, 5)):
+        x = torch.randn(2, g0, h, w, generator=g).double()
+        ref = F.conv2d(F.pixel_shuffle(F.conv2d(x, w0, b0, padding=1), 2), w2, b2, padding=1)
+        assert float((fused_upnet_reference(x, W, B) - ref).abs().max()) <= 1e-12
+        if h > 1 and w > 1:
+            inter = F.pixel_shuffle(F.conv2d(x, W[4], B[4], padding=2), 2)
+            d = (inter - ref).abs()
+            assert float(d[..., 1:-1, 1:-1].max()) <= 1e-12 and float(d.max()) > 1e-3      # only the ring needs its own operators

@@ -672,3 +672,63 @@ def test_streaming_cache_misses_after_a_weight_or_precision_change():
         c = net(*frames, stage1_cache=cache)
         fresh16 = net(*frames)
         assert all(torch.equal(x, y) for x, y in zip(c, fresh16)) and not torch.equal(b[0], c[0])
+
+
+# ------------------------------------------------------------------------------------------------ the fused UPNet
+@pytest.mark.parametrize("k,nhw", [(2, (1, 64, 96)), (3, (2, 36, 70)), (5, (1, 6, 6)), (2, (1, 2, 2)), (5, (1, 132, 260))])
+def test_fused_upnet_equals_the_two_layer_form(k, nhw, canon_cpu):
+    """BINHIP_PLAN_FUSED_UPNET (round 6): UPNet = conv3x3(96 -> 256) -> PixelShuffle(2) -> conv3x3(64 -> 3) has no activation in between
+    (RDN.py:203-207), so inference runs it as ONE 5x5 convolution 96 -> 12 sub-pixel channels at half resolution plus an exact recomputation
+    of the one-pixel border ring (where UPNet.2's zero padding of the intermediate differs from padding the input).  Against the two-layer
+    launches (themselves pinned to the reference's fixtures): the whole output, and the ring by itself, within fp32 summation-order noise —
+    on ragged widths, a 2 x 2 frame (every pixel is ring), batches, 2 / 3 / 5 input frames.  The formula is pinned on the CPU
+    (tests/test_cpu_host.py::test_fused_upnet_weights_reproduce_the_two_layers)."""
+    from bin_amd import _lib as L
+    from bin_amd.models.archs import RDN as A
+    from bin_amd.weights import rdn_param_shapes
+    set_name = {2: "model1", 3: "model2", 5: "model3"}[k]
+    cls = {2: A.RDN_residual_interp_2_input, 3: A.RDN_residual_interp_2_1_input, 5: A.RDN_residual_interp_4_1_input}[k]
+    mod = cls(G0=96, D=12)
+    mod.load_state_dict({n: canon_cpu[f"{set_name}.{n}"] for n in rdn_param_shapes(k)})
+    mod = mod.cuda().eval()
+    mod.precision = "f16x3"
+    n, h, w = nhw
+    gen = torch.Generator().manual_seed(5)
+    ins = [torch.rand(n, 3, h, w, generator=gen).cuda() for _ in range(k)]
+    assert mod.plan_flags & L.PLAN_FUSED_UPNET                      # the default
+    with torch.no_grad():
+        fused = mod(*ins).clone()
+        mod.plan_flags &= ~L.PLAN_FUSED_UPNET
+        two = mod(*ins).clone()
+    d = (fused - two).abs()
+    ring = torch.ones_like(d, dtype=torch.bool)
+    ring[..., 1:-1, 1:-1] = False
+    print(f"k {k} {nhw}: fused vs two-layer max-abs {float(d.max()):.2e} (ring {float(d[ring].max()):.2e}), |out| {float(two.abs().max()):.2f}")
+    assert float(d.max()) <= 2e-6 * max(1.0, float(two.abs().max()))
+
+
+def test_fused_upnet_is_inference_only_and_fp32_class_only(canon_cpu):
+    """A differentiable call keeps the two layers (their activations and separate weight gradients are what the backward needs), and the
+    single-product mode ignores the flag: both give what they gave before."""
+    from bin_amd import _lib as L
+    from bin_amd.models.archs import RDN as A
+    from bin_amd.weights import rdn_param_shapes
+    mod = A.RDN_residual_interp_2_input(G0=96, D=12)
+    mod.load_state_dict({n: canon_cpu[f"model1.{n}"] for n in rdn_param_shapes(2)})
+    mod = mod.cuda()
+    gen = torch.Generator().manual_seed(6)
+    ins = [torch.rand(1, 3, 32, 48, generator=gen).cuda() for _ in range(2)]
+    mod.precision = "f16x3"
+    out = mod(*ins)                                                  # grad mode: KEEP_ACTS
+    out.sum().backward()
+    assert mod.UPNet[0].weight.grad is not None and mod.UPNet[2].weight.grad is not None
+    with torch.no_grad():
+        mod.plan_flags &= ~L.PLAN_FUSED_UPNET
+        two = mod(*ins)
+    assert torch.equal(out.detach(), two)                            # the training forward IS the two-layer forward
+    mod.precision = "f16"
+    with torch.no_grad():
+        a = mod(*ins)
+        mod.plan_flags |= L.PLAN_FUSED_UPNET
+        b = mod(*ins)
+    assert torch.equal(a, b)
