@@ -427,9 +427,9 @@ int bh_prepare_conv(const BhConvCall& c, ConvKArgs* out) {
         if (d.cout % 4) return BINHIP_E_SHAPE;
     } else if (d.epilogue == F) {
         if (!c.y_f32 || d.cout > 4 || d.n_images < 0 || d.n_images > 5) return BINHIP_E_ARG;
-    } else if (d.epilogue == BINHIP_EPI_FINAL_SUBPIX) {      // the fused UPNet: 4 sub-pixel channels per colour, fp32-class 5x5 only
+    } else if (d.epilogue == BINHIP_EPI_FINAL_SUBPIX) {      // the fused UPNet: 4 sub-pixel channels per colour, 5x5, one 32-row block
         if (!c.y_f32 || d.cout <= 0 || (d.cout & 3) || d.cout > 12 || d.n_images < 0 || d.n_images > 5) return BINHIP_E_ARG;
-        if (d.ksize != 5 || d.nterms != 3 || d.cout_pad != 32) return BINHIP_E_SHAPE;
+        if (d.ksize != 5 || d.cout_pad != 32) return BINHIP_E_SHAPE;
     } else {
         return BINHIP_E_ARG;
     }
@@ -502,7 +502,8 @@ static int bh_dispatch_conv(const ConvKArgs& a0, int k, int cp, int nt, int e, h
     a.dbg = g_dbg;
     if (!g_wt) a.wt = 0;
 #endif
-    if (e == BINHIP_EPI_FINAL_SUBPIX) return bh_launch_conv_x3_k5_subpix(a, s);      // the fused UPNet (shape checked in bh_prepare_conv)
+    if (e == BINHIP_EPI_FINAL_SUBPIX)                                                // the fused UPNet (shape checked in bh_prepare_conv)
+        return nt == 3 ? bh_launch_conv_x3_k5_subpix(a, s) : launch_cfg<5, 1, 1, 2, 8, 1, 1, 2, BINHIP_EPI_FINAL_SUBPIX>(a, cp, s);
     // UPNet.2 (64 -> 3 + mean of the frames) in the single-product mode: three output channels as VALU dot products instead of
     // a 32-row MFMA tile (f16 720p window 33.02 -> 32.71 ms).  In the fp32-class mode the same kernel needs 648 dot2 per lane
     // and chunk behind 112 scalar weight loads and measured 224 us against the MFMA kernel's 110 (profiles/r03_experiments.md):

@@ -225,9 +225,9 @@ int binhip_rdn_forward(const BinRdnPlan* p, const float* const* inputs, float* o
     if ((rc = conv(LG + 1, 3, c0, G0, G0, P_, 0, h, ww, w.g0, w.s_g, 0, 0, w.g1, w.s_g, w.f1, w.s_f1))) return rc;
     // UPNet as ONE 5x5 convolution G0 -> 12 sub-pixel channels (BINHIP_PLAN_FUSED_UPNET, include/binhip.h): inference only — training keeps
     // the two layers, whose activations and separate weight gradients its backward needs
-    const bool fused_up = (p->reserved & BINHIP_PLAN_FUSED_UPNET) && !(p->reserved & BINHIP_PLAN_KEEP_ACTS) && nt == 3 &&
-                          sh.L + 1 < BINHIP_RDN_MAX_LAYERS && p->w_hi[sh.L] && p->w_lo[sh.L] && p->bias[sh.L] && p->w_hi[sh.L + 1] &&
-                          p->bias[sh.L + 1];
+    const bool fused_up = (p->reserved & BINHIP_PLAN_FUSED_UPNET) && !(p->reserved & BINHIP_PLAN_KEEP_ACTS) &&
+                          sh.L + 1 < BINHIP_RDN_MAX_LAYERS && p->w_hi[sh.L] && (nt == 1 || p->w_lo[sh.L]) && p->bias[sh.L] &&
+                          p->w_hi[sh.L + 1] && p->bias[sh.L + 1];
     if (fused_up) {
         if ((rc = bh_launch_conv(mk(sh.L, 5, c0, 12, 32, BINHIP_EPI_FINAL_SUBPIX, 0, h, ww, w.g1, w.s_g, 0, 0, -1, 0, -1, 0), s))) return rc;
         // ... and the one-pixel full-resolution border ring from its own operators (UPNet.2 pads the intermediate, not the input)

@@ -128,13 +128,13 @@ class RdnWeights:
 
     def ensure_fused_upnet(self):
         """(ConvWeights of the [12][G0][5][5] interior operator, fp32 [9][12][25][G0] ring operators, fp32 [9][12] ring biases) or None when
-        this weight set has no such form (single-product mode: the plan ignores the flag)."""
-        if self.fused_up is None and self.nterms == 3 and self._up_src is not None:
+        this weight set's UPNet is not the 256 -> shuffle -> 3 one."""
+        if self.fused_up is None and self._up_src is not None:
             with torch.no_grad():
                 w0, b0, w2, b2 = self._up_src
                 if tuple(w0.shape[2:]) == (3, 3) and w0.shape[0] == 256 and tuple(w2.shape) == (3, 64, 3, 3):
                     W, B = fused_upnet_weights(w0, b0, w2, b2)
-                    main = ConvWeights(W[4].float().contiguous(), B[4].float().contiguous(), nterms=3)
+                    main = ConvWeights(W[4].float().contiguous(), B[4].float().contiguous(), nterms=self.nterms)
                     ring_w = W.permute(0, 1, 3, 4, 2).reshape(9, 12, 25, W.shape[2]).float().contiguous()
                     self.fused_up = (main, ring_w, B.float().contiguous())
             self._up_src = None
@@ -149,7 +149,8 @@ class RdnWeights:
         n = len(self.layers)
         if self.fused_up is not None:
             main, ring_w, ring_b = self.fused_up
-            plan.w_hi[n], plan.w_lo[n], plan.bias[n] = main.w_hi.data_ptr(), main.w_lo.data_ptr(), main.bias.data_ptr()
+            plan.w_hi[n], plan.bias[n] = main.w_hi.data_ptr(), main.bias.data_ptr()
+            plan.w_lo[n] = main.w_lo.data_ptr() if main.w_lo is not None else None
             plan.w_hi[n + 1], plan.w_lo[n + 1], plan.bias[n + 1] = ring_w.data_ptr(), None, ring_b.data_ptr()
 
     def dgrad(self, module, nterms=None):

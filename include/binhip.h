@@ -65,7 +65,7 @@ extern "C" {
 #define BINHIP_EPI_FINAL   2     /* conv + b + mean(images) -> fp32 NCHW [N,cout,H,W]            */
 #define BINHIP_EPI_FINAL_SUBPIX 4 /* a half-resolution conv whose cout = 4 c' channels are the 2 x 2 sub-pixels of c' <= 3 colour
                                      channels (order c' * 4 + i * 2 + j): conv + b + mean(images) -> fp32 NCHW [N,c',2H,2W].  The
-                                     epilogue of the FUSED UPNet (BINHIP_PLAN_FUSED_UPNET below); fp32-class mode, 5x5, cout_pad 32 */
+                                     epilogue of the FUSED UPNet (BINHIP_PLAN_FUSED_UPNET below); 5x5, cout_pad 32, both precision modes */
 
 #define BINHIP_RDN_LAYERS 66     /* bin_stage4: SFE1, SFE2, 12 x (4 conv + LFF), GFF.0, GFF.1, UP.0, UP.2 */
 /* Shape of an RDN sub-network (constructor arguments of RDN.py:168-186): G0 feature channels, D residual dense blocks of
@@ -284,7 +284,7 @@ BINHIP_API int binhip_rdb_tail_fwd(int N, int H, int W, int nterms, const void* 
 #define BINHIP_PLAN_RDB3      4   /* nterms = 3: convs 0-2 of each RDB as three phases of ONE launch */
                                   /* (static tile ownership + per-tile neighbour flags, no grid       */
                                   /* barrier; per-conv launches when the grid cannot be co-resident)  */
-#define BINHIP_PLAN_FUSED_UPNET 8 /* inference (not with KEEP_ACTS), nterms = 3: UPNet = conv3x3(G0 -> 256) -> PixelShuffle(2) ->   */
+#define BINHIP_PLAN_FUSED_UPNET 8 /* inference (not with KEEP_ACTS), both modes:  UPNet = conv3x3(G0 -> 256) -> PixelShuffle(2) ->   */
                                   /* conv3x3(64 -> 3) (RDN.py:203-207) has no activation in between, so it IS one linear map:     */
                                   /* a 5x5 convolution G0 -> 12 at half resolution (W_eff = W2 * shuffle * W0, 3.4 x fewer MACs,  */
                                   /* no 256-channel intermediate).  The caller supplies it: slot L = 2 + D (C + 1) + 4 of         */

@@ -707,9 +707,9 @@ def test_fused_upnet_equals_the_two_layer_form(k, nhw, canon_cpu):
     assert float(d.max()) <= 2e-6 * max(1.0, float(two.abs().max()))
 
 
-def test_fused_upnet_is_inference_only_and_fp32_class_only(canon_cpu):
-    """A differentiable call keeps the two layers (their activations and separate weight gradients are what the backward needs), and the
-    single-product mode ignores the flag: both give what they gave before."""
+def test_fused_upnet_is_inference_only(canon_cpu):
+    """A differentiable call keeps the two layers (their activations and separate weight gradients are what the backward needs): the training
+    forward gives what it gave before.  The single-product mode fuses too; there the two forms differ by the mode's own fp16 rounding."""
     from bin_amd import _lib as L
     from bin_amd.models.archs import RDN as A
     from bin_amd.weights import rdn_param_shapes
@@ -731,4 +731,7 @@ def test_fused_upnet_is_inference_only_and_fp32_class_only(canon_cpu):
         a = mod(*ins)
         mod.plan_flags |= L.PLAN_FUSED_UPNET
         b = mod(*ins)
-    assert torch.equal(a, b)
+    d = float((a - b).abs().max())
+    print(f"f16: fused vs two-layer max-abs {d:.2e}; each against the fp32-class output: {float((a - two).abs().max()):.2e} (two layers), "
+          f"{float((b - two).abs().max()):.2e} (fused)")
+    assert 0.0 < d <= 1e-3 and float((b - two).abs().max()) <= 1e-3
