@@ -733,6 +733,13 @@ def train_bench(args, rank, world, dev, steps=None, warmup=None, standalone=True
         dist.destroy_process_group()
 
 
+def fused_upnet_active():
+    """Is the inference path running UPNet as one 5x5 convolution (BINHIP_PLAN_FUSED_UPNET, the default since round 6)?"""
+    from bin_amd import _lib as L_
+    from bin_amd.rdn_plan import default_plan_flags
+    return bool(default_plan_flags() & L_.PLAN_FUSED_UPNET)
+
+
 def kernel_roofline(prec, kern_ms, kern_n, hp, wp, ms, reuse_schedule):
     """`roofline` object of the inference window in precision `prec`: the dominant kernel (dense-block 3x3 conv,
     Cin -> 32) from its event-timed mean duration, plus the whole forward's algorithmic rates.  Every `frac` can be
@@ -782,11 +789,28 @@ def kernel_roofline(prec, kern_ms, kern_n, hp, wp, ms, reuse_schedule):
             "algorithmic_bytes_per_launch": int(ab), "bytes_per_element": BYTES_PER_ELEM[prec],
             "algorithmic_flop_per_launch": int(rdb_conv_flops(1, hp // 2, wp // 2)),
             "hbm": hbm, "mfma": mfma,
-            "whole_forward": {"algorithmic_GB": round(abytes / 1e9, 1), "achieved_GBs": round(whole_gbs, 1),
-                              "frac_hbm": round(whole_gbs / HBM_PEAK_GBS, 4),
-                              "algorithmic_TFLOP": round(flops / 1e12, 3),
-                              "achieved_TFLOPs": round(flops / (ms * 1e-3) / 1e12, 1),
-                              "mfma_frac": round(flops * PRODUCTS[prec] / (ms * 1e-3) / 1e12 / MFMA_PEAK_TF, 4)}}
+            "whole_forward": whole_forward_rates(prec, flops, abytes, ms, hp, wp, reuse_schedule)}
+
+
+def whole_forward_rates(prec, flops, abytes, ms, hp, wp, reuse_schedule):
+    """Whole-window rates.  `algorithmic_*` = SURVEY 8(d)'s layer-wise count of the REFERENCE's layer list; with the fused UPNet the
+    window executes less than that (one 5x5 convolution 96 -> 12 at half resolution instead of conv3x3 96 -> 256 + conv3x3 64 -> 3 at full
+    resolution, and no 64-channel full-resolution intermediate), so the fractions are computed from what is EXECUTED."""
+    calls = 17 if reuse_schedule else 20
+    px = (hp // 2) * (wp // 2)
+    ex_flops, ex_bytes, fused = flops, abytes, fused_upnet_active()
+    if fused:
+        ex_flops -= calls * px * 2.0 * (9 * 96 * 256 + 4 * 9 * 64 * 3 - 25 * 96 * 12)
+        ex_bytes -= calls * px * 4 * 64 * BYTES_PER_ELEM[prec] * 2.0              # the intermediate's write and read
+    gbs = ex_bytes / (ms * 1e-3) / 1e9
+    assert gbs <= HBM_PEAK_GBS
+    return {"algorithmic_GB": round(abytes / 1e9, 1), "algorithmic_TFLOP": round(flops / 1e12, 3),
+            "executed_GB": round(ex_bytes / 1e9, 1), "executed_TFLOP": round(ex_flops / 1e12, 3), "fused_upnet": fused,
+            "achieved_GBs": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4),
+            "achieved_TFLOPs": round(ex_flops / (ms * 1e-3) / 1e12, 1),
+            "mfma_frac": round(ex_flops * PRODUCTS[prec] / (ms * 1e-3) / 1e12 / MFMA_PEAK_TF, 4),
+            "note": "rates and fractions from the EXECUTED work (UPNet = conv3x3 -> PixelShuffle -> conv3x3 without an activation runs as one "
+                    "5x5 convolution on 12 sub-pixel channels: same function, 3.4 x fewer multiply-adds); algorithmic_* = the reference's layer list"}
 
 
 def train_roofline(batch, size, step_s, prec, bwd_prec, kern, kern_overlapped=None):
@@ -1120,7 +1144,7 @@ def main():
             "data": ("all-zero operands (diagnostic, INVALID as a result)" if args.zero_data else "synthetic"),
             "config": {"workload": "Adobe240 test_blur 1280x720 inference, batch=1 per GPU "
                                    "(6-frame window padded to 768x1344 by the test.py rule), window-sharded",
-                       "schedule": "17 RDN calls + 6 ConvLSTM cells (exact reuse)" if net.reuse_schedule
+                       "schedule": ("17 RDN calls + 6 ConvLSTM cells (exact reuse)" + ("; UPNet of every call as one fused 5x5 convolution" if fused_upnet_active() else "")) if net.reuse_schedule
                                    else "20 RDN calls + 12 ConvLSTM cells (reference literal)",
                        "precision": prec, "streams": net.resolved_streams(), "pipelined_steps": bool(kw_in),
                        "four_call_schedule": bool(args.four_calls),
