@@ -967,8 +967,7 @@ int bh_launch_conv_x3_k5_subpix(const ConvKArgs& a, hipStream_t s) {
 // its 3x3 window leaves the image a tap contributes nothing — the one-convolution form (W_eff over a zero-padded INPUT) instead
 // sees "UPNet.0 of the padded input" there.  The two differ on the outermost full-resolution pixel ring only; for those
 // 4 H + 4 W - 4 pixels (H, W: half resolution) the host supplies the exact operators (fp32 [9][12][25][cin], variant = 3 vy + vx,
-// bin_amd/rdn_plan.py fused_upnet_weights) and this kernel recomputes them: one wave per ring pixel, the 25 * cin products of
-// the pixel's three colours spread over the lanes (fp32 FMA on hi + lo), a butterfly sum, lane 0 stores.  ~30 MFLOP per call.
+// bin_amd/rdn_plan.py fused_upnet_weights) and this kernel recomputes them (fp32 FMA on hi + lo; ~30 MFLOP per call).
 struct RingArgs {
     const _Float16* x_hi;
     const _Float16* x_lo;
@@ -978,8 +977,14 @@ struct RingArgs {
     const float* img[5];
     int N, H, W, cin, nimg;
 };
-__global__ void __launch_bounds__(64) upnet_ring_kernel(const RingArgs a) {
-    const int lane = threadIdx.x;
+constexpr int RING_THREADS = 128;
+// One workgroup per ring pixel.  Work item = (tap, group of 8 input channels): two 16-byte plane loads (hi, lo) and six float4
+// weight loads feed 24 FMAs — 25 * cin / 8 items per pixel (300 at 96 channels) over 128 threads.  (Measured on the way, 720p call:
+// one 2-byte load per product 26-30 us; eight pixels per workgroup sharing their weights 50 us — it is the number of load
+// instructions, not the 29 KB of L2-resident weights per pixel, that this small kernel pays for.)
+__global__ void __launch_bounds__(RING_THREADS) upnet_ring_kernel(const RingArgs a) {
+    __shared__ float red[3][RING_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = a.H, W = a.W, H2 = 2 * H, W2 = 2 * W;
     const int ring = 2 * W2 + 2 * (H2 - 2);
     int id = blockIdx.x;
@@ -992,20 +997,33 @@ __global__ void __launch_bounds__(64) upnet_ring_kernel(const RingArgs a) {
     const int y = Y >> 1, i = Y & 1, x = X >> 1, j = X & 1;
     const int vy = (Y == 0) ? 0 : (Y == H2 - 1 ? 2 : 1), vx = (X == 0) ? 0 : (X == W2 - 1 ? 2 : 1);
     const int var = 3 * vy + vx, sub = 2 * i + j;
-    const int cin = a.cin, terms = 25 * cin;
+    const int cin = a.cin, ng = cin >> 3, items = 25 * ng;
     const long long wstride = (long long)25 * cin;                       // one output channel
     const float* w = a.wvar + ((long long)var * 12 + sub) * wstride;       // colour c at + 4 c * wstride
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (int q = lane; q < terms; q += 64) {
-        const int tap = q / cin, ci = q - tap * cin;
+    for (int it = tid; it < items; it += RING_THREADS) {
+        const int tap = it / ng, ci = (it - tap * ng) << 3;
         const int yy = y + tap / 5 - 2, xx = x + tap % 5 - 2;
         if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
         const long long o = (((((long long)(ci >> 4) * a.N + img) * H + yy) * W + xx) << 4) + (ci & 15);
-        float xv = (float)a.x_hi[o];
-        if (a.x_lo) xv += (float)a.x_lo[o];
-        s0 = fmaf(w[q], xv, s0);
-        s1 = fmaf(w[q + 4 * wstride], xv, s1);
-        s2 = fmaf(w[q + 8 * wstride], xv, s2);
+        const half8 xh = *reinterpret_cast<const half8*>(a.x_hi + o);
+        half8 xl;
+        if (a.x_lo) xl = *reinterpret_cast<const half8*>(a.x_lo + o);
+        const float* wq = w + (long long)tap * cin + ci;
+        floatx4 wa[3][2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            wa[c][0] = *reinterpret_cast<const floatx4*>(wq + 4 * c * wstride);
+            wa[c][1] = *reinterpret_cast<const floatx4*>(wq + 4 * c * wstride + 4);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = (float)xh[e];
+            if (a.x_lo) v += (float)xl[e];
+            s0 = fmaf(wa[0][e >> 2][e & 3], v, s0);
+            s1 = fmaf(wa[1][e >> 2][e & 3], v, s1);
+            s2 = fmaf(wa[2][e >> 2][e & 3], v, s2);
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -1013,9 +1031,11 @@ __global__ void __launch_bounds__(64) upnet_ring_kernel(const RingArgs a) {
         s1 += __shfl_xor(s1, off);
         s2 += __shfl_xor(s2, off);
     }
-    if (lane < 3) {
-        const int c = lane;
-        const float s = c == 0 ? s0 : (c == 1 ? s1 : s2);
+    if (lane == 0) { red[0][wave] = s0; red[1][wave] = s1; red[2][wave] = s2; }
+    __syncthreads();
+    if (tid < 3) {
+        const int c = tid;
+        const float v = red[c][0] + red[c][1];
         const long long idx = (((long long)img * 3 + c) * H2 + Y) * W2 + X;
         float m = 0.f;
         if (a.nimg > 0) {
@@ -1023,7 +1043,7 @@ __global__ void __launch_bounds__(64) upnet_ring_kernel(const RingArgs a) {
             for (int t = 1; t < a.nimg; ++t) m += a.img[t][idx];
             m = m / (float)a.nimg;
         }
-        a.out[idx] = (s + a.bvar[var * 12 + 4 * c + sub]) + m;
+        a.out[idx] = (v + a.bvar[var * 12 + 4 * c + sub]) + m;
     }
 }
 int bh_launch_upnet_ring(const void* x_hi, const void* x_lo, const float* wvar, const float* bvar, float* out, const float* const* images,
@@ -1034,7 +1054,7 @@ int bh_launch_upnet_ring(const void* x_hi, const void* x_lo, const float* wvar, 
     for (int t = 0; t < 5; ++t) a.img[t] = (t < nimg) ? images[t] : nullptr;
     a.N = N; a.H = H; a.W = W; a.cin = cin; a.nimg = nimg;
     const long long ring = 4ll * W + 4ll * H - 4;
-    upnet_ring_kernel<<<dim3((unsigned)(ring * N)), dim3(64), 0, s>>>(a);
+    upnet_ring_kernel<<<dim3((unsigned)(ring * N)), dim3(RING_THREADS), 0, s>>>(a);
     BH_CHECK_LAUNCH();
     return 0;
 }

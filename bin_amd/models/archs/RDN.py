@@ -433,6 +433,12 @@ def _forward_streams(self, B, stage1_cache=None, input_events=None):
     stale = [v._wcache is None or v._wcache[0] != wkeys[k] for k, v in mods.items()]
     relayout_pending = any(stale)
     kw = {k: v.kernel_weights(nterms[k]) for k, v in mods.items()}       # relayouts (if any) on the main stream
+    for k, v in mods.items():
+        # ... and the fused UPNet's operands (BINHIP_PLAN_FUSED_UPNET): built HERE, on the main stream, which the side streams wait for
+        # below — rdn_forward would otherwise build them lazily on whichever side stream calls first, unordered against the others
+        if (v.plan_flags & L.PLAN_FUSED_UPNET) and kw[k].fused_up is None and kw[k]._up_src is not None:
+            kw[k].ensure_fused_upnet()
+            relayout_pending = True
     lib = L.lib()
     n, _, h, w = B[0].shape
     ready = {}                                                          # id(tensor) -> (event recorded after its call, stream)

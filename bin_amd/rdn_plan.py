@@ -47,41 +47,30 @@ def fused_upnet_weights(w0, b0, w2, b2):
     the outermost full-resolution pixel ring has its own operators.  Returns (W [9, 12, G0, 5, 5], b [9, 12]) in float64; variant 3 vy + vx,
     v = 0 first row (column), 1 interior, 2 last row (column); only the sub-pixels that lie ON the ring differ from the interior form.
     3.4 x fewer multiply-adds than the two layers (25 * 12 * G0 against 9 * 256 * G0 + 4 * 9 * 64 * 3 per half-resolution pixel)."""
-    w0, b0, w2, b2 = (t.detach().double() for t in (w0, b0, w2, b2))
-    g0 = w0.shape[1]
+    w0, b0, w2, b2 = (t.double() for t in (w0, b0, w2, b2))          # differentiable: a caller may backpropagate dW_eff -> dW0, dW2
+    dev, g0 = w0.device, w0.shape[1]
     assert w0.shape == (256, g0, 3, 3) and w2.shape == (3, 64, 3, 3) and b0.shape == (256,) and b2.shape == (3,)
-    k4 = torch.arange(64, device=w0.device) * 4
-    # contribution of UPNet.2's tap (dy, dx) to sub-pixel (i, j): [3, g0, 3, 3] weights at offset (oy + 1, ox + 1) of the 5x5, [3] bias
-    contrib = {}
+    # (i, dy) -> (oy, i'): s = i + dy - 1 in {-1, 0, 1, 2}, oy = floor(s / 2), i' = s mod 2 — the same table serves (j, dx)
+    sub = torch.tensor([[1, 0, 1], [0, 1, 0]], device=dev)              # i'[i][dy]
+    off = torch.tensor([[-1, 0, 0], [0, 0, 1]], device=dev)             # oy[i][dy]
+    w0r = w0.view(64, 2, 2, g0, 3, 3)                                   # [k, i', j', g, a, b]  (channel 4 k + 2 i' + j')
+    w0g = w0r[:, sub.reshape(-1)].view(64, 2, 3, 2, g0, 3, 3)           # [k, i, dy, j', g, a, b]
+    w0g = w0g[:, :, :, sub.reshape(-1)].view(64, 2, 3, 2, 3, g0, 3, 3)  # [k, i, dy, j, dx, g, a, b]
+    b0g = b0.view(64, 2, 2)[:, sub.reshape(-1)].view(64, 2, 3, 2)[:, :, :, sub.reshape(-1)].view(64, 2, 3, 2, 3)
+    T = torch.einsum("ckyx,kiyjxgab->ciyjxgab", w2, w0g)                # UPNet.2's tap (dy, dx) through UPNet.0, per sub-pixel (i, j)
+    Tb = torch.einsum("ckyx,kiyjx->ciyjx", w2, b0g)
+    # where a tap's 3x3 lands inside the 5x5: row oy + 1 + a
+    place = torch.zeros(2, 3, 3, 5, dtype=torch.float64, device=dev)    # [i, dy, a, t]
     for i in range(2):
-        for j in range(2):
-            for dy in range(3):
-                for dx in range(3):
-                    oy, ip = divmod(i + dy - 1, 2)
-                    ox, jp = divmod(j + dx - 1, 2)
-                    ch = k4 + 2 * ip + jp
-                    wc = torch.einsum("ck,kgab->cgab", w2[:, :, dy, dx], w0[ch])
-                    bc = w2[:, :, dy, dx] @ b0[ch]
-                    contrib[(i, j, dy, dx)] = (oy + 1, ox + 1, wc, bc)
-    W = torch.zeros(9, 12, g0, 5, 5, dtype=torch.float64, device=w0.device)
-    B = torch.zeros(9, 12, dtype=torch.float64, device=w0.device)
-    for vy in range(3):
-        for vx in range(3):
-            v = 3 * vy + vx
-            for i in range(2):
-                for j in range(2):
-                    rows = torch.arange(3, device=w0.device) * 4 + 2 * i + j
-                    B[v, rows] += b2
-                    for dy in range(3):
-                        # the source row 2y + i + dy - 1 is outside the image: first row (i = 0) looking up, last row (i = 1) looking down
-                        if (vy == 0 and i == 0 and dy == 0) or (vy == 2 and i == 1 and dy == 2):
-                            continue
-                        for dx in range(3):
-                            if (vx == 0 and j == 0 and dx == 0) or (vx == 2 and j == 1 and dx == 2):
-                                continue
-                            oy, ox, wc, bc = contrib[(i, j, dy, dx)]
-                            W[v, rows, :, oy:oy + 3, ox:ox + 3] += wc
-                            B[v, rows] += bc
+        for dy in range(3):
+            for a in range(3):
+                place[i, dy, a, int(off[i, dy]) + 1 + a] = 1.0
+    # which taps exist: the first row's upper sub-pixel cannot look up, the last row's lower sub-pixel cannot look down
+    keep = torch.ones(3, 2, 3, dtype=torch.float64, device=dev)         # [v, i, dy]
+    keep[0, 0, 0] = 0.0
+    keep[2, 1, 2] = 0.0
+    W = torch.einsum("ciyjxgab,viy,wjx,iyat,jxbu->vwcijgtu", T, keep, keep, place, place).reshape(9, 12, g0, 5, 5)
+    B = (b2.view(1, 1, 3, 1, 1) + torch.einsum("ciyjx,viy,wjx->vwcij", Tb, keep, keep)).reshape(9, 12)
     return W, B
 
 
