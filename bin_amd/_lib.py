@@ -7,9 +7,10 @@ from .build import LIB_PATH
 
 RDN_LAYERS = 66              # bin_stage4's layer count; BinRdnPlan arrays hold RDN_MAX_LAYERS
 RDN_MAX_LAYERS, RDN_MAX_CONVS = 192, 7
-PLAN_KEEP_ACTS, PLAN_NO_FUSE, PLAN_RDB3, PLAN_FUSED_UPNET = 1, 2, 4, 8
+PLAN_KEEP_ACTS, PLAN_NO_FUSE, PLAN_RDB3, PLAN_FUSED_UPNET, PLAN_FUSED_UPNET_TRAIN = 1, 2, 4, 8, 16
 BWD_ACCUMULATE = 1          # BinRdnBwdPlan.reserved flag (BINHIP_BWD_ACCUMULATE)
 BWD_SAVED_X3 = 2            # BINHIP_BWD_SAVED_X3
+BWD_FUSED_UPNET = 4         # BINHIP_BWD_FUSED_UPNET
 EPI_PLANES, EPI_SHUFFLE, EPI_FINAL, EPI_FINAL_SUBPIX = 0, 1, 2, 4
 PROF_WGRAD = 16             # BINHIP_PROF_WGRAD
 LOSS_CHARBONNIER, LOSS_L1_SUM, LOSS_L2_SUM = 0, 1, 2

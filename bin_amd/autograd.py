@@ -56,6 +56,11 @@ def _aux_stream(device):
     return s
 
 
+def train_fused_upnet():
+    """BIN_AMD_FUSED_UPNET_TRAIN=0: training keeps UPNet's two layers (forward and backward as in rounds 1-5)."""
+    return os.environ.get("BIN_AMD_FUSED_UPNET_TRAIN", "1") != "0"
+
+
 def default_backward_precision():
     return os.environ.get("BIN_AMD_BACKWARD_PRECISION") or None
 
@@ -94,7 +99,12 @@ class _RdnFn(torch.autograd.Function):
         if nbytes == 0:
             raise RuntimeError(f"bin_amd: unsupported RDN shape N={n} H={h} W={w}")
         saved = torch.empty(nbytes, dtype=torch.uint8, device=frames[0].device)
-        out = rdn_forward(weights, frames, ws=saved, flags=module.plan_flags | L.PLAN_KEEP_ACTS, profiler=module.profiler)
+        # the fused UPNet in training (round 6): forward = one 5x5 convolution + border ring, backward = BINHIP_BWD_FUSED_UPNET + the
+        # chain rule from the operator's gradient to UPNet.0 / UPNet.2 (rdn_plan.fused_upnet_weights under autograd)
+        fused = bool(module.plan_flags & L.PLAN_FUSED_UPNET) and train_fused_upnet() and weights.ensure_fused_upnet() is not None
+        flags = module.plan_flags | L.PLAN_KEEP_ACTS | (L.PLAN_FUSED_UPNET_TRAIN if fused else 0)
+        out = rdn_forward(weights, frames, ws=saved, flags=flags, profiler=module.profiler)
+        ctx.fused_up = fused
         if module.debug_hook is not None:
             module.debug_hook("forward", module, (n, h, w, n_frames, nterms), saved, {"shape": module.shape})
         ctx.module, ctx.nterms, ctx.n_frames = module, nterms, n_frames
@@ -152,6 +162,16 @@ class _RdnFn(torch.autograd.Function):
         for i in range(len(grads) // 2):
             plan.dw[i] = grads[2 * i].data_ptr()
             plan.db[i] = grads[2 * i + 1].data_ptr()
+        fused = getattr(ctx, "fused_up", False)
+        if fused:
+            nl, g0 = len(grads) // 2, module.shape[0]
+            plan.reserved |= L.BWD_FUSED_UPNET
+            up_dw4 = torch.empty((12, g0, 5, 5), dtype=torch.float32, device=dev)
+            up_db4 = torch.empty((12,), dtype=torch.float32, device=dev)
+            up_dwr = torch.empty((n, 9, 12, 25, g0), dtype=torch.float32, device=dev)
+            up_dbr = torch.empty((n, 9, 12), dtype=torch.float32, device=dev)
+            plan.dw[nl], plan.db[nl], plan.dw[nl + 1], plan.db[nl + 1] = (up_dw4.data_ptr(), up_db4.data_ptr(), up_dwr.data_ptr(),
+                                                                        up_dbr.data_ptr())
         gins = []
         for i in range(k):
             if ctx.needs_input_grad[3 + i]:
@@ -170,6 +190,23 @@ class _RdnFn(torch.autograd.Function):
             module.debug_hook("backward", module, (n, h, w, k, nt_bwd), ws, {"input_grads": any(g is not None for g in gins),
                                                                               "shape": module.shape})
         ctx.saved_ws = None
+        if fused:
+            # dL/dW_eff -> dL/dW0, dL/db0, dL/dW2, dL/db2: the operators are a bilinear function of the two layers' parameters
+            from .rdn_plan import fused_upnet_weights
+            nl = len(grads) // 2
+            dW = up_dwr.sum(0).permute(0, 1, 3, 2).reshape(9, 12, g0, 5, 5)
+            dB = up_dbr.sum(0)
+            dW[4], dB[4] = up_dw4, up_db4
+            src = [params[2 * (nl - 2)], params[2 * (nl - 2) + 1], params[2 * (nl - 1)], params[2 * (nl - 1) + 1]]
+            with torch.enable_grad():
+                leaves = [t.detach().requires_grad_() for t in src]
+                Wv, Bv = fused_upnet_weights(*leaves)
+                gup = torch.autograd.grad([Wv, Bv], leaves, [dW.double(), dB.double()])
+            for slot, g in zip((2 * (nl - 2), 2 * (nl - 2) + 1, 2 * (nl - 1), 2 * (nl - 1) + 1), gup):
+                if plan.reserved & L.BWD_ACCUMULATE:
+                    grads[slot].add_(g.float())
+                else:
+                    grads[slot].copy_(g.float())
         module._bwd_pending = getattr(module, "_bwd_pending", 1) - 1
         if module._bwd_pending == 0 and direct:
             cb = getattr(module, "_grads_ready_cb", None)

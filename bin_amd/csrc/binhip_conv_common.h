@@ -16,6 +16,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 int bh_launch_upnet_ring(const void* x_hi, const void* x_lo, const float* wvar, const float* bvar, float* out, const float* const* images,
                          int nimg, int N, int H, int W, int cin, hipStream_t s);      // binhip_conv_x3.hip (BINHIP_PLAN_FUSED_UPNET)
+// backward of the fused UPNet (binhip_misc.hip)
+int bh_upnet_gsub(const float* g, int N, int H, int W, const float* scale, void* y_hi, void* y_lo, void* status, hipStream_t s);
+int bh_upnet_ring_dgrad(const float* g, const float* wvar, const float* scale, void* gx_hi, void* gx_lo, void* status, int N, int H, int W,
+                        int cin, hipStream_t s);
+int bh_upnet_ring_wgrad(const float* g, const void* x_hi, const void* x_lo, float* dwvar, float* dbvar, int N, int H, int W, int cin,
+                        int accumulate, hipStream_t s);
 struct ConvKArgs {
     const _Float16* x_hi;
     const _Float16* x_lo;

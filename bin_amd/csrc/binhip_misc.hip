@@ -744,7 +744,224 @@ convlstm_bwd_weight_final_kernel(const float* __restrict__ partials, int nb, flo
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Backward of the FUSED UPNet (BINHIP_BWD_FUSED_UPNET; forward: BINHIP_PLAN_FUSED_UPNET, binhip_conv_x3.hip).  The forward is
+//   O = Main(x; W[4]) on every full-resolution pixel, then the outermost pixel ring overwritten by Ring(x; W[v]), v = border variant,
+// so with g = dL/dO split into g_int (ring zeroed) and g_ring:
+//   dL/dx = Main^T(g_int; W[4]) + Ring^T(g_ring; W[v]),   dW[4] = wgrad5x5(x, g_int),   dW[v] = sum over the ring pixels of variant v.
+// Main^T and wgrad5x5 are the ordinary 5x5 kernels on `gsub`, the pixel-unshuffled (12 sub-pixel channels, one chunk), scaled,
+// ring-zeroed gradient that upnet_gsub_kernel packs; the two ring kernels below add the rest (fp32, ~30 MFLOP each).  dW[*] -> dW0, dW2
+// is the host's job (torch autograd through rdn_plan.fused_upnet_weights).
+
+// one thread = one 16-byte slot (8 of the 16 plane channels) of one half-resolution pixel: channels c * 4 + i * 2 + j = g[c][2y+i][2x+j]
+__global__ void upnet_gsub_kernel(const float* __restrict__ g, int N, int H, int W, const float* __restrict__ scale,
+                                  _Float16* __restrict__ y_hi, _Float16* __restrict__ y_lo, unsigned* __restrict__ flags) {
+    const float sc = scale ? scale[0] : 1.f;
+    const long long HW = (long long)H * W, total = (long long)N * HW * 2;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int s = (int)(t & 1);
+    long long u = t >> 1;
+    const int x = (int)(u % W); u /= W;
+    const int y = (int)(u % H);
+    const int n = (int)(u / H);
+    const int H2 = 2 * H, W2 = 2 * W;
+    half8 hv, lv;
+    unsigned sat = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ch = s * 8 + e, c = ch >> 2, Y = 2 * y + ((ch >> 1) & 1), X = 2 * x + (ch & 1);
+        const bool ring = (Y == 0) || (Y == H2 - 1) || (X == 0) || (X == W2 - 1);
+        const float v = (c < 3 && !ring) ? g[(((long long)n * 3 + c) * H2 + Y) * W2 + X] * sc : 0.f;
+        hv[e] = split_hi(v, sat);
+        lv[e] = split_lo(v, hv[e]);
+    }
+    *reinterpret_cast<half8*>(y_hi + t * 8) = hv;
+    if (y_lo) *reinterpret_cast<half8*>(y_lo + t * 8) = lv;
+    if (sat != 0 && flags) atomicOr(flags, BINHIP_FLAG_SATURATED);
+}
+
+struct RingBwdArgs {
+    const float* g;            // dL/dO, fp32 [N, 3, 2H, 2W]
+    const float* wvar;         // forward ring operators, fp32 [9][12][25][cin]
+    const float* scale;        // scale[0]: the gradient planes carry dL/dx * scale
+    const _Float16* x_hi;      // saved input of UPNet (G1), planes [cin / 16][N][H][W][16]
+    const _Float16* x_lo;
+    _Float16* gx_hi;           // dL/dx planes (same layout): read-modify-write by ring_dgrad
+    _Float16* gx_lo;
+    float* dwvar;              // [N][9][12][25][cin]: per-image partial sums
+    float* dbvar;              // [N][9][12]
+    unsigned* flags;
+    int N, H, W, cin, accumulate;
+};
+
+// Ring^T: one thread = (band pixel, 8 input channels).  A half-resolution pixel (y, x) receives from ring output pixels (Y, X) with
+// |Y / 2 - y| <= 2 and |X / 2 - x| <= 2, so only pixels within two of the border are touched: the band is enumerated as the rows
+// {0, 1, 2, H-3, H-2, H-1} in full and the columns {0, 1, 2, W-3, W-2, W-1} of the remaining rows (all rows / columns when there are
+// six or fewer).  Single writer per slot: plain read-modify-write of the hi / lo planes, no atomics.
+__global__ void __launch_bounds__(256) upnet_ring_dgrad_kernel(const RingBwdArgs a) {
+    const int H = a.H, W = a.W, H2 = 2 * H, W2 = 2 * W, cin = a.cin, ng = cin >> 3;
+    const int nrow = H < 6 ? H : 6, ncolx = W < 6 ? W : 6;              // band rows / band columns
+    const int mid = H > 6 ? H - 6 : 0;                                  // rows that only contribute their border columns
+    const long long per_img = (long long)nrow * W + (long long)mid * ncolx;
+    const long long total = per_img * a.N * ng;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int grp = (int)(t % ng);
+    long long u = t / ng;
+    const int n = (int)(u / per_img);
+    long long q = u - (long long)n * per_img;
+    int y, x;
+    if (q < (long long)nrow * W) {
+        const int r = (int)(q / W);
+        x = (int)(q - (long long)r * W);
+        y = (H <= 6) ? r : (r < 3 ? r : H - 6 + r);
+    } else {
+        q -= (long long)nrow * W;
+        const int r = (int)(q / ncolx), k = (int)(q - (long long)r * ncolx);
+        y = 3 + r;
+        x = (W <= 6) ? k : (k < 3 ? k : W - 6 + k);
+    }
+    const float sc = a.scale ? a.scale[0] : 1.f;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int ci = grp << 3;
+    // ring output pixels whose 5x5 window covers (y, x): half-resolution position (py, px) = (y - ty + 2, x - tx + 2), tap (ty, tx)
+    for (int ty = 0; ty < 5; ++ty) {
+        const int py = y - ty + 2;
+        if (py < 0 || py >= H) continue;
+        for (int tx = 0; tx < 5; ++tx) {
+            const int px = x - tx + 2;
+            if (px < 0 || px >= W) continue;
+            const int tap = ty * 5 + tx;
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub) {
+                const int Y = 2 * py + (sub >> 1), X = 2 * px + (sub & 1);
+                const bool ring = (Y == 0) || (Y == H2 - 1) || (X == 0) || (X == W2 - 1);
+                if (!ring) continue;
+                const int vy = (Y == 0) ? 0 : (Y == H2 - 1 ? 2 : 1), vx = (X == 0) ? 0 : (X == W2 - 1 ? 2 : 1);
+                const float* w = a.wvar + ((((long long)(3 * vy + vx) * 12 + sub) * 25 + tap) * cin) + ci;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float gv = a.g[(((long long)n * 3 + c) * H2 + Y) * W2 + X];
+                    const float* wc = w + (long long)4 * c * 25 * cin;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] = fmaf(wc[e], gv, acc[e]);
+                }
+            }
+        }
+    }
+    const long long o = (((((long long)(ci >> 4) * a.N + n) * H + y) * W + x) << 4) + (ci & 15);
+    half8 hv = *reinterpret_cast<const half8*>(a.gx_hi + o), lv;
+    if (a.gx_lo) lv = *reinterpret_cast<const half8*>(a.gx_lo + o);
+    unsigned sat = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float v = (float)hv[e] + acc[e] * sc;
+        if (a.gx_lo) v += (float)lv[e];
+        hv[e] = split_hi(v, sat);
+        lv[e] = split_lo(v, hv[e]);
+    }
+    *reinterpret_cast<half8*>(a.gx_hi + o) = hv;
+    if (a.gx_lo) *reinterpret_cast<half8*>(a.gx_lo + o) = lv;
+    if (sat != 0 && a.flags) atomicOr(a.flags, BINHIP_FLAG_SATURATED);
+}
+
+// dW[n][v][o][tap][ci], dB[n][v][o] of the eight border variants, per image: one workgroup = (image, variant, sub-pixel, tap), thread =
+// input channel; the ring pixels of the variant with that sub-pixel (an edge's every second pixel, or one corner) are walked in a fixed
+// order and the caller sums the images (deterministic).  Variant 4 (interior) is written as zeros: its gradient is the 5x5
+// weight-gradient kernel's.
+__global__ void __launch_bounds__(256) upnet_ring_wgrad_kernel(const RingBwdArgs a) {
+    const int H = a.H, W = a.W, H2 = 2 * H, W2 = 2 * W, cin = a.cin;
+    int id = blockIdx.x;
+    const int n = id / (9 * 4 * 25);                   // one image per workgroup: per-image partials, summed by the caller (deterministic)
+    id -= n * (9 * 4 * 25);
+    const int tap = id % 25; id /= 25;
+    const int sub = id & 3, var = id >> 2;
+    const int vy = var / 3, vx = var - 3 * vy, i = sub >> 1, j = sub & 1;
+    const int ty = tap / 5 - 2, tx = tap % 5 - 2;
+    const int ci = threadIdx.x;
+    // the pixels (Y, X) of this variant with parity (i, j): a border row / column has ONE parity (row 0: i = 0, row 2H - 1: i = 1), the
+    // free coordinate of an edge runs over [1, L - 2] in steps of two
+    int Y0, Y1, X0, X1;      // inclusive ranges, step 2; an empty range has Y0 > Y1 (X0 > X1)
+    if (vy == 0) { Y0 = 0; Y1 = (i == 0) ? 0 : -1; }
+    else if (vy == 2) { Y0 = H2 - 1; Y1 = (i == 1) ? H2 - 1 : -1; }
+    else { Y0 = i ? 1 : 2; Y1 = H2 - 2; }
+    if (vx == 0) { X0 = 0; X1 = (j == 0) ? 0 : -1; }
+    else if (vx == 2) { X0 = W2 - 1; X1 = (j == 1) ? W2 - 1 : -1; }
+    else { X0 = j ? 1 : 2; X1 = W2 - 2; }
+    const bool none = (var == 4);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+    if (!none && ci < cin) {
+            for (int Y = Y0; Y <= Y1; Y += 2)
+                for (int X = X0; X <= X1; X += 2) {
+                    const float g0 = a.g[(((long long)n * 3 + 0) * H2 + Y) * W2 + X];
+                    const float g1 = a.g[(((long long)n * 3 + 1) * H2 + Y) * W2 + X];
+                    const float g2 = a.g[(((long long)n * 3 + 2) * H2 + Y) * W2 + X];
+                    b0 += g0; b1 += g1; b2 += g2;
+                    const int yy = (Y >> 1) + ty, xx = (X >> 1) + tx;
+                    if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+                    const long long o = (((((long long)(ci >> 4) * a.N + n) * H + yy) * W + xx) << 4) + (ci & 15);
+                    float xv = (float)a.x_hi[o];
+                    if (a.x_lo) xv += (float)a.x_lo[o];
+                    s0 = fmaf(g0, xv, s0); s1 = fmaf(g1, xv, s1); s2 = fmaf(g2, xv, s2);
+                }
+    }
+    if (ci < cin) {
+        const float sv[3] = {s0, s1, s2};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            a.dwvar[(((((long long)n * 9 + var) * 12 + 4 * c + sub) * 25 + tap) * cin) + ci] = sv[c];
+        }
+    }
+    if (tap == 0 && ci == 0) {
+        const float bv[3] = {b0, b1, b2};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            a.dbvar[((long long)n * 9 + var) * 12 + 4 * c + sub] = bv[c];
+        }
+    }
+}
+
+int bh_upnet_gsub(const float* g, int N, int H, int W, const float* scale, void* y_hi, void* y_lo, void* status, hipStream_t s) {
+    if (!g || !y_hi || N <= 0 || H <= 0 || W <= 0) return BINHIP_E_ARG;
+    const long long total = (long long)N * H * W * 2;
+    upnet_gsub_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(g, N, H, W, scale, (_Float16*)y_hi, (_Float16*)y_lo,
+                                                                             (unsigned*)status);
+    BH_CHECK_LAUNCH();
+    return 0;
+}
+static int ring_bwd_args(RingBwdArgs& a, const float* g, const float* wvar, const float* scale, const void* x_hi, const void* x_lo,
+                         void* gx_hi, void* gx_lo, float* dwvar, float* dbvar, void* status, int N, int H, int W, int cin, int accumulate) {
+    if (!g || N <= 0 || H <= 0 || W <= 0 || cin <= 0 || (cin & 15) || cin > 256) return BINHIP_E_ARG;
+    a.g = g; a.wvar = wvar; a.scale = scale; a.x_hi = (const _Float16*)x_hi; a.x_lo = (const _Float16*)x_lo;
+    a.gx_hi = (_Float16*)gx_hi; a.gx_lo = (_Float16*)gx_lo; a.dwvar = dwvar; a.dbvar = dbvar; a.flags = (unsigned*)status;
+    a.N = N; a.H = H; a.W = W; a.cin = cin; a.accumulate = accumulate;
+    return 0;
+}
+int bh_upnet_ring_dgrad(const float* g, const float* wvar, const float* scale, void* gx_hi, void* gx_lo, void* status, int N, int H, int W,
+                        int cin, hipStream_t s) {
+    RingBwdArgs a;
+    if (!wvar || !gx_hi) return BINHIP_E_ARG;
+    if (int rc = ring_bwd_args(a, g, wvar, scale, nullptr, nullptr, gx_hi, gx_lo, nullptr, nullptr, status, N, H, W, cin, 0)) return rc;
+    const int nrow = H < 6 ? H : 6, ncolx = W < 6 ? W : 6, mid = H > 6 ? H - 6 : 0;
+    const long long total = ((long long)nrow * W + (long long)mid * ncolx) * N * (cin >> 3);
+    upnet_ring_dgrad_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(a);
+    BH_CHECK_LAUNCH();
+    return 0;
+}
+int bh_upnet_ring_wgrad(const float* g, const void* x_hi, const void* x_lo, float* dwvar, float* dbvar, int N, int H, int W, int cin,
+                        int accumulate, hipStream_t s) {
+    RingBwdArgs a;
+    if (!x_hi || !dwvar || !dbvar) return BINHIP_E_ARG;
+    if (int rc = ring_bwd_args(a, g, nullptr, nullptr, x_hi, x_lo, nullptr, nullptr, dwvar, dbvar, nullptr, N, H, W, cin, accumulate)) return rc;
+    upnet_ring_wgrad_kernel<<<dim3((unsigned)(9 * 4 * 25 * N)), dim3(256), 0, s>>>(a);
+    BH_CHECK_LAUNCH();
+    return 0;
+}
+
+
 extern "C" {
+
 
 int binhip_version(void) { return BINHIP_VERSION; }
 

@@ -225,7 +225,8 @@ int binhip_rdn_forward(const BinRdnPlan* p, const float* const* inputs, float* o
     if ((rc = conv(LG + 1, 3, c0, G0, G0, P_, 0, h, ww, w.g0, w.s_g, 0, 0, w.g1, w.s_g, w.f1, w.s_f1))) return rc;
     // UPNet as ONE 5x5 convolution G0 -> 12 sub-pixel channels (BINHIP_PLAN_FUSED_UPNET, include/binhip.h): inference only — training keeps
     // the two layers, whose activations and separate weight gradients its backward needs
-    const bool fused_up = (p->reserved & BINHIP_PLAN_FUSED_UPNET) && !(p->reserved & BINHIP_PLAN_KEEP_ACTS) &&
+    const bool fused_up = (p->reserved & BINHIP_PLAN_FUSED_UPNET) &&
+                          (!(p->reserved & BINHIP_PLAN_KEEP_ACTS) || (p->reserved & BINHIP_PLAN_FUSED_UPNET_TRAIN)) &&
                           sh.L + 1 < BINHIP_RDN_MAX_LAYERS && p->w_hi[sh.L] && (nt == 1 || p->w_lo[sh.L]) && p->bias[sh.L] &&
                           p->w_hi[sh.L + 1] && p->bias[sh.L + 1];
     if (fused_up) {
@@ -387,6 +388,14 @@ int binhip_rdn_backward(const BinRdnBwdPlan* p, const void* saved, size_t saved_
     const int accumulate = (p->reserved & BINHIP_BWD_ACCUMULATE) ? 1 : 0;   // dw/db += instead of =
     int rc;
     if ((rc = binhip_grad_scale(gout, (int64_t)N * 3 * H * W, 16.f, amax_part, sc, stream))) return rc;
+    // BINHIP_BWD_FUSED_UPNET: the forward ran UPNet as one 5x5 convolution on 12 sub-pixel channels (+ the border ring)
+    const bool fused_up = (p->reserved & BINHIP_BWD_FUSED_UPNET) != 0;
+    if (fused_up) {
+        if (sh.L + 1 >= BINHIP_RDN_MAX_LAYERS || !p->wt_hi[sh.L] || (nt == 3 && !p->wt_lo[sh.L]) || !p->wt_hi[sh.L + 1] || !p->dw[sh.L] ||
+            !p->db[sh.L] || !p->dw[sh.L + 1] || !p->db[sh.L + 1]) return BINHIP_E_ARG;
+        // gsub: the pixel-unshuffled, scaled gradient with the ring zeroed — ONE half-resolution chunk, hi at b.gout, lo one plane further
+        if ((rc = bh_upnet_gsub(gout, N, H / 2, W / 2, sc, GH(b.gout), GL(b.gout, (int64_t)N * (H / 2) * (W / 2) * 16), p->status, s))) return rc;
+    } else
     if ((rc = binhip_nchw_to_planes_scaled(gout, N, 3, H, W, sc, GH(b.gout), GL(b.gout, b.s_gout), p->status, stream))) return rc;
 
     // weight gradient of forward layer `layer`: X = saved activations, gY = gradient planes.  slot < 0: reduce at once;
@@ -407,7 +416,7 @@ int binhip_rdn_backward(const BinRdnBwdPlan* p, const void* saved, size_t saved_
                                          p->dw[layer], p->db[layer], cin, shuffle, &r, (void*)sb);
         if (timed) bh_prof_end(p->profiler, sb);
         if (rw) return rw;
-        if (slot < 0) return bh_wgrad_reduce_batch(&r, 1, inv, accumulate, (void*)sb);
+        if (slot < 0) return bh_wgrad_reduce_batch(&r, 1, inv, layer >= sh.L ? 0 : accumulate, (void*)sb);   // (fused UPNet: written)
         pending[npending++] = r;
         return 0;
     };
@@ -444,6 +453,16 @@ int binhip_rdn_backward(const BinRdnBwdPlan* p, const void* saved, size_t saved_
     // `workspace` / frees `saved` in main-stream order, also after a failed call).
     hipEvent_t b_done[20] = {};
     auto chain = [&]() -> int {
+        if (fused_up) {
+            // ---- the fused UPNet (G0 -> 12 sub-pixel channels, 5x5): X = G1, gY = gsub; then the ring's share of both gradients
+            const int64_t s_sub = (int64_t)N * h * ww * 16;
+            if ((rc = wgrad(sh.L, 5, h, ww, c0, G0, 12, w.g1, w.s_g, 0, 0, b.gout, s_sub, 0))) return rc;
+            if ((rc = order(s, sb))) return rc;
+            if ((rc = bh_upnet_ring_wgrad(gout, SH(w.g1), SL(w.g1, w.s_g), p->dw[sh.L + 1], p->db[sh.L + 1], N, h, ww, G0, 0, sb))) return rc;
+            if ((rc = dgrad(sh.L, 5, h, ww, 1, G0, b.gout, s_sub, b.gg1, b.s_g, -1, 0, 0, false, -1, 0, 0, 0))) return rc;
+            if ((rc = bh_upnet_ring_dgrad(gout, (const float*)p->wt_hi[sh.L + 1], sc, GH(b.gg1), GL(b.gg1, b.s_g), p->status, N, h, ww, G0, s)))
+                return rc;
+        } else {
         // ---- UPNet.2 (64 -> 3 at full res): X = U
         if ((rc = wgrad(LG + 3, 3, H, W, 4, 64, 3, w.u, w.s_u, 0, 0, b.gout, b.s_gout, 0))) return rc;
         // its backward-data writes straight through the inverse PixelShuffle (round 4: y_unshuf; before, a 64-channel
@@ -453,6 +472,7 @@ int binhip_rdn_backward(const BinRdnBwdPlan* p, const void* saved, size_t saved_
         // ---- UPNet.0 (G0 -> 256): X = G1
         if ((rc = wgrad(LG + 2, 3, h, ww, c0, G0, 256, w.g1, w.s_g, 0, 0, b.guu, b.s_guu, 1))) return rc;
         if ((rc = dgrad(LG + 2, 3, h, ww, 16, G0, b.guu, b.s_guu, b.gg1, b.s_g, -1, 0, 0, false, -1, 0, 0, 0))) return rc;
+        }
         // ---- GFF.1 (+ f__1 skip): X = G0
         if ((rc = wgrad(LG + 1, 3, h, ww, c0, G0, G0, w.g0, w.s_g, 0, 0, b.gg1, b.s_g, 0))) return rc;
         if ((rc = dgrad(LG + 1, 3, h, ww, c0, G0, b.gg1, b.s_g, b.gg0, b.s_g, -1, 0, 0, false, -1, 0, 0, 0))) return rc;

@@ -114,6 +114,7 @@ class RdnWeights:
         # (ensure_fused_upnet): a training step rebuilds its RdnWeights every step and never needs them
         self._up_src = tuple(params[f"{prefix}UPNet.{k}.{t}"] for k in (0, 2) for t in ("weight", "bias"))
         self.fused_up = None
+        self.fused_w4 = None
 
     def ensure_fused_upnet(self):
         """(ConvWeights of the [12][G0][5][5] interior operator, fp32 [9][12][25][G0] ring operators, fp32 [9][12] ring biases) or None when
@@ -123,7 +124,8 @@ class RdnWeights:
                 w0, b0, w2, b2 = self._up_src
                 if tuple(w0.shape[2:]) == (3, 3) and w0.shape[0] == 256 and tuple(w2.shape) == (3, 64, 3, 3):
                     W, B = fused_upnet_weights(w0, b0, w2, b2)
-                    main = ConvWeights(W[4].float().contiguous(), B[4].float().contiguous(), nterms=self.nterms)
+                    self.fused_w4 = W[4].float().contiguous()               # (RdnDgradWeights relayouts its transpose for the backward)
+                    main = ConvWeights(self.fused_w4, B[4].float().contiguous(), nterms=self.nterms)
                     ring_w = W.permute(0, 1, 3, 4, 2).reshape(9, 12, 25, W.shape[2]).float().contiguous()
                     self.fused_up = (main, ring_w, B.float().contiguous())
             self._up_src = None
@@ -151,7 +153,8 @@ class RdnWeights:
         if nterms not in self._dgrad:
             with torch.no_grad():
                 self._dgrad[nterms] = RdnDgradWeights(dict(module.named_parameters()), self.n_inputs, nterms,
-                                                      shape=self.shape)
+                                                      shape=self.shape,
+                                                      fused=(self.fused_w4, self.fused_up[1]) if self.fused_up is not None else None)
         return self._dgrad[nterms]
 
 
@@ -163,10 +166,11 @@ class RdnDgradWeights:
     slot `RDBs.d.convs.g` holds the weights that produce concat-group g of the block from the stacked output
     gradients of convs g..3 - what binhip_rdn_backward expects (include/binhip.h, BinRdnBwdPlan)."""
 
-    def __init__(self, params, n_inputs, nterms, prefix="", shape=STAGE4_SHAPE):
+    def __init__(self, params, n_inputs, nterms, prefix="", shape=STAGE4_SHAPE, fused=None):
         lib = L.lib()
         self.shape = G0, D, C, G = check_shape(shape)
         self.w_hi, self.w_lo = [], []
+        self.fused_ring_w = None
         dev = None
         names = layer_names(self.shape)
         fp32 = {nm: params[f"{prefix}{nm}.weight"].detach().contiguous().float() for nm in names}
@@ -201,6 +205,17 @@ class RdnDgradWeights:
             self.w_hi.append(hi)
             self.w_lo.append(lo)
             scratch.append(zb)
+        if fused is not None:
+            # BINHIP_BWD_FUSED_UPNET: slot L = the transposed interior operator of the fused UPNet ([12][G0][5][5] -> 5x5, 12 -> G0),
+            # slot L + 1 = its fp32 ring operators as the forward uses them
+            w4, self.fused_ring_w = fused
+            rows_pad = lib.binhip_dgrad_rows_pad(5, G0)
+            cb = lib.binhip_conv_cout_block(5, rows_pad, nterms)
+            hi, lo, zb = alloc(rows_pad, 1, 5)
+            items.append(relayout_item(L.RELAYOUT_DGRAD, [w4], None, hi, lo, zb, 12, G0, 5, rows_pad, 1, cb, 0))
+            self.w_hi.append(hi)
+            self.w_lo.append(lo)
+            scratch.append(zb)
         relayout_batch(items)
         del scratch
         self.zero_bias = torch.zeros(max(D * G0, G0 + C * G, 256, 1152), dtype=torch.float32, device=dev)
@@ -210,6 +225,8 @@ class RdnDgradWeights:
         for i in range(len(self.w_hi)):
             plan.wt_hi[i] = self.w_hi[i].data_ptr()
             plan.wt_lo[i] = self.w_lo[i].data_ptr() if self.w_lo[i] is not None else None
+        if self.fused_ring_w is not None:
+            plan.wt_hi[len(self.w_hi)] = self.fused_ring_w.data_ptr()
         plan.zero_bias = self.zero_bias.data_ptr()
 
 
@@ -284,7 +301,7 @@ def _rdn_forward(weights, inputs, out, ws, flags, profiler):
     plan.reserved = int(flags or 0)
     plan.status = status_word(inputs[0].device).data_ptr()
     plan.profiler = profiler if profiler else None
-    if (plan.reserved & L.PLAN_FUSED_UPNET) and not (plan.reserved & L.PLAN_KEEP_ACTS):
+    if (plan.reserved & L.PLAN_FUSED_UPNET) and (not (plan.reserved & L.PLAN_KEEP_ACTS) or (plan.reserved & L.PLAN_FUSED_UPNET_TRAIN)):
         weights.ensure_fused_upnet()
     weights.fill_plan(plan)
     nbytes = lib.binhip_rdn_workspace_bytes(n, h, w, weights.n_inputs, weights.nterms, C.byref(plan.shape))

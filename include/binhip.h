@@ -294,6 +294,8 @@ BINHIP_API int binhip_rdb_tail_fwd(int N, int H, int W, int nterms, const void* 
                                   /* where UPNet.2's zero padding of the INTERMEDIATE differs from padding the input, is           */
                                   /* recomputed exactly by a second small launch.  Same function as the two-layer form up to fp32  */
                                   /* summation order; bin_amd/rdn_plan.py builds the operands (fused_upnet_weights).               */
+#define BINHIP_PLAN_FUSED_UPNET_TRAIN 16 /* with KEEP_ACTS: the fused UPNet in the TRAINING forward too (needs the slots of          */
+                                        /* BINHIP_PLAN_FUSED_UPNET); its backward is BINHIP_BWD_FUSED_UPNET                          */
 typedef struct BinRdnPlan {
     int32_t N, H, W;          /* full-resolution frame size (H, W even)                          */
     int32_t n_inputs;         /* 2, 3 or 5 input frames                                          */
@@ -368,6 +370,12 @@ BINHIP_API int binhip_convlstm_bwd(const float* x, const float* c_prev, const fl
  * parameters' .grad buffers when a weight set is shared by several calls) when `reserved` has
  * BINHIP_BWD_ACCUMULATE.  gin[i]: fp32 [N,3,H,W] or NULL.                                                */
 #define BINHIP_BWD_ACCUMULATE 1
+#define BINHIP_BWD_FUSED_UPNET 4  /* the forward ran UPNet as one 5x5 convolution (BINHIP_PLAN_FUSED_UPNET_TRAIN): with L = 2 + D (C + 1) + 4,
+                                   * wt_hi / wt_lo[L] = binhip_weights_relayout_dgrad of the [12][G0][5][5] interior operator, wt_hi[L + 1] = the fp32
+                                   * [9][12][25][G0] ring operators; results: dw[L] / db[L] = fp32 [12][G0][5][5] / [12] gradient of the interior
+                                   * operator (always WRITTEN, never accumulated), dw[L + 1] / db[L + 1] = fp32 [N][9][12][25][G0] / [N][9][12]
+                                   * per-image gradients of the ring operators (variant 4 zero).  dw / db of UPNet.0 and UPNet.2 are NOT written:
+                                   * the caller maps the operator gradients to them (autograd of rdn_plan.fused_upnet_weights).               */
 #define BINHIP_BWD_SAVED_X3   2   /* `saved` has the nterms = 3 layout while this plan's nterms is 1: a single-product
                                    * backward behind the fp32-class forward (exact loss and ReLU masks, ~1e-3 relative
                                    * gradient error); wt_* are then the nterms = 1 backward-data weights              */
