@@ -101,7 +101,8 @@ class _RdnFn(torch.autograd.Function):
         saved = torch.empty(nbytes, dtype=torch.uint8, device=frames[0].device)
         # the fused UPNet in training (round 6): forward = one 5x5 convolution + border ring, backward = BINHIP_BWD_FUSED_UPNET + the
         # chain rule from the operator's gradient to UPNet.0 / UPNet.2 (rdn_plan.fused_upnet_weights under autograd)
-        fused = bool(module.plan_flags & L.PLAN_FUSED_UPNET) and train_fused_upnet() and weights.ensure_fused_upnet() is not None
+        fused = (bool(module.plan_flags & L.PLAN_FUSED_UPNET) and train_fused_upnet() and
+                 weights.ensure_fused_upnet(train=True) is not None and weights.fused_graph is not None)
         flags = module.plan_flags | L.PLAN_KEEP_ACTS | (L.PLAN_FUSED_UPNET_TRAIN if fused else 0)
         out = rdn_forward(weights, frames, ws=saved, flags=flags, profiler=module.profiler)
         ctx.fused_up = fused
@@ -192,16 +193,12 @@ class _RdnFn(torch.autograd.Function):
         ctx.saved_ws = None
         if fused:
             # dL/dW_eff -> dL/dW0, dL/db0, dL/dW2, dL/db2: the operators are a bilinear function of the two layers' parameters
-            from .rdn_plan import fused_upnet_weights
             nl = len(grads) // 2
-            dW = up_dwr.sum(0).permute(0, 1, 3, 2).reshape(9, 12, g0, 5, 5)
+            dW = up_dwr.sum(0)                                                  # ring layout [9, 12, 25, G0]
             dB = up_dbr.sum(0)
-            dW[4], dB[4] = up_dw4, up_db4
-            src = [params[2 * (nl - 2)], params[2 * (nl - 2) + 1], params[2 * (nl - 1)], params[2 * (nl - 1) + 1]]
-            with torch.enable_grad():
-                leaves = [t.detach().requires_grad_() for t in src]
-                Wv, Bv = fused_upnet_weights(*leaves)
-                gup = torch.autograd.grad([Wv, Bv], leaves, [dW.double(), dB.double()])
+            dW[4], dB[4] = up_dw4.reshape(12, g0, 25).permute(0, 2, 1), up_db4
+            leaves, Wr, Br = module.kernel_weights(nterms).fused_graph          # built by this weight version's forward
+            gup = torch.autograd.grad([Wr, Br], leaves, [dW, dB], retain_graph=True)
             for slot, g in zip((2 * (nl - 2), 2 * (nl - 2) + 1, 2 * (nl - 1), 2 * (nl - 1) + 1), gup):
                 if plan.reserved & L.BWD_ACCUMULATE:
                     grads[slot].add_(g.float())

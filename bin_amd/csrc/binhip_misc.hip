@@ -879,7 +879,7 @@ __global__ void __launch_bounds__(256) upnet_ring_wgrad_kernel(const RingBwdArgs
     const int sub = id & 3, var = id >> 2;
     const int vy = var / 3, vx = var - 3 * vy, i = sub >> 1, j = sub & 1;
     const int ty = tap / 5 - 2, tx = tap % 5 - 2;
-    const int ci = threadIdx.x;
+    const int ci = threadIdx.x, sl = threadIdx.y, S = blockDim.y;      // S slices of the pixel walk per channel (256 / cin of them)
     // the pixels (Y, X) of this variant with parity (i, j): a border row / column has ONE parity (row 0: i = 0, row 2H - 1: i = 1), the
     // free coordinate of an edge runs over [1, L - 2] in steps of two
     int Y0, Y1, X0, X1;      // inclusive ranges, step 2; an empty range has Y0 > Y1 (X0 > X1)
@@ -892,8 +892,10 @@ __global__ void __launch_bounds__(256) upnet_ring_wgrad_kernel(const RingBwdArgs
     const bool none = (var == 4);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
     if (!none && ci < cin) {
+            int pix = 0;
             for (int Y = Y0; Y <= Y1; Y += 2)
-                for (int X = X0; X <= X1; X += 2) {
+                for (int X = X0; X <= X1; X += 2, ++pix) {
+                    if (pix % S != sl) continue;
                     const float g0 = a.g[(((long long)n * 3 + 0) * H2 + Y) * W2 + X];
                     const float g1 = a.g[(((long long)n * 3 + 1) * H2 + Y) * W2 + X];
                     const float g2 = a.g[(((long long)n * 3 + 2) * H2 + Y) * W2 + X];
@@ -905,6 +907,17 @@ __global__ void __launch_bounds__(256) upnet_ring_wgrad_kernel(const RingBwdArgs
                     if (a.x_lo) xv += (float)a.x_lo[o];
                     s0 = fmaf(g0, xv, s0); s1 = fmaf(g1, xv, s1); s2 = fmaf(g2, xv, s2);
                 }
+    }
+    __shared__ float red[6][256];
+    {
+        const int t = sl * blockDim.x + ci;
+        red[0][t] = s0; red[1][t] = s1; red[2][t] = s2; red[3][t] = b0; red[4][t] = b1; red[5][t] = b2;
+    }
+    __syncthreads();
+    if (sl != 0) return;
+    for (int q = 1; q < S; ++q) {                       // fixed order: deterministic
+        const int t = q * blockDim.x + ci;
+        s0 += red[0][t]; s1 += red[1][t]; s2 += red[2][t]; b0 += red[3][t]; b1 += red[4][t]; b2 += red[5][t];
     }
     if (ci < cin) {
         const float sv[3] = {s0, s1, s2};
@@ -954,7 +967,8 @@ int bh_upnet_ring_wgrad(const float* g, const void* x_hi, const void* x_lo, floa
     RingBwdArgs a;
     if (!x_hi || !dwvar || !dbvar) return BINHIP_E_ARG;
     if (int rc = ring_bwd_args(a, g, nullptr, nullptr, x_hi, x_lo, nullptr, nullptr, dwvar, dbvar, nullptr, N, H, W, cin, accumulate)) return rc;
-    upnet_ring_wgrad_kernel<<<dim3((unsigned)(9 * 4 * 25 * N)), dim3(256), 0, s>>>(a);
+    const int S = 256 / cin > 0 ? 256 / cin : 1;
+    upnet_ring_wgrad_kernel<<<dim3((unsigned)(9 * 4 * 25 * N)), dim3((unsigned)cin, (unsigned)S), 0, s>>>(a);
     BH_CHECK_LAUNCH();
     return 0;
 }

@@ -74,6 +74,105 @@ def fused_upnet_weights(w0, b0, w2, b2):
     return W, B
 
 
+_FUSED_MAPS = {}
+
+
+def _fused_upnet_maps(device):
+    """Constant index maps of `fused_upnet_operator` (cached per device): the operator is BILINEAR in (W2, W0), so for fixed W2 it is the
+    matrix product A(W2) @ W0 with A[(vy,vx,c,i,j,t,u), (k,i',j',a,b)] = W2[c,k,dy,dx] for the ONE tap (dy, dx) that sends UPNet.0's 3x3
+    entry (a, b) of channel 4k+2i'+j' to entry (t, u) of the 5x5 of sub-pixel (i, j) — or 0 (no such tap, or the tap is cut by the border
+    variant).  `idx` indexes W2.flatten() extended by one zero."""
+    key = str(device)
+    if key in _FUSED_MAPS:
+        return _FUSED_MAPS[key]
+    import numpy as np
+    # tap[i, i', t, a] = dy with (i + dy - 1) mod 2 == i' and floor((i + dy - 1) / 2) + 1 + a == t, else -1 (same table for j / dx / u / b)
+    tap = -np.ones((2, 2, 5, 3), dtype=np.int64)
+    sub = np.zeros((2, 3), dtype=np.int64)
+    for i in range(2):
+        for dy in range(3):
+            oy, ip = divmod(i + dy - 1, 2)
+            sub[i, dy] = ip
+            for a in range(3):
+                tap[i, ip, oy + 1 + a, a] = dy
+    keep = np.ones((3, 2, 3), dtype=bool)          # [v, i, dy]: the first row's upper sub-pixel cannot look up, the last row's lower one not down
+    keep[0, 0, 0] = False
+    keep[2, 1, 2] = False
+    # broadcast to [vy, vx, c, i, j, t, u, k, i', j', a, b]
+    sh = (3, 3, 3, 2, 2, 5, 5, 64, 2, 2, 3, 3)
+    ax = {n: k for k, n in enumerate(("vy", "vx", "c", "i", "j", "t", "u", "k", "ip", "jp", "a", "b"))}
+
+    def bc(arr, names):
+        shape = [1] * len(sh)
+        for d, nme in zip(arr.shape, names):
+            shape[ax[nme]] = d
+        order = sorted(range(len(names)), key=lambda q: ax[names[q]])
+        return np.transpose(arr, order).reshape(shape)
+    dy = bc(tap, ("i", "ip", "t", "a"))
+    dx = bc(tap, ("j", "jp", "u", "b"))
+    ok = (dy >= 0) & (dx >= 0)
+    vy = np.arange(3).reshape(bc(np.arange(3), ("vy",)).shape)
+    vx = np.arange(3).reshape(bc(np.arange(3), ("vx",)).shape)
+    ii = np.arange(2).reshape(bc(np.arange(2), ("i",)).shape)
+    jj = np.arange(2).reshape(bc(np.arange(2), ("j",)).shape)
+    valid = ok & keep[vy, ii, np.where(dy >= 0, dy, 0)] & keep[vx, jj, np.where(dx >= 0, dx, 0)]
+    cc = np.arange(3).reshape(bc(np.arange(3), ("c",)).shape)
+    kk = np.arange(64).reshape(bc(np.arange(64), ("k",)).shape)
+    flat = ((cc * 64 + kk) * 3 + np.where(dy >= 0, dy, 0)) * 3 + np.where(dx >= 0, dx, 0)
+    idx = np.where(np.broadcast_to(valid, sh), np.broadcast_to(flat, sh), 3 * 64 * 9).reshape(-1)
+    # the inverse map for the backward: every W2 entry sits at <= 324 places of A; gathering those (padded with an index one past the
+    # end = a zero) and summing is deterministic, where index_select's own backward is 6.2 M atomic adds onto 1728 addresses
+    nA, nW = idx.size, 3 * 64 * 9
+    order = np.argsort(idx, kind="stable")
+    srt = idx[order]
+    counts = np.bincount(srt, minlength=nW + 1)
+    starts = np.concatenate(([0], np.cumsum(counts)[:-1]))
+    rank = np.arange(nA) - starts[srt]
+    lmax = int(counts[:nW].max())
+    inv = np.full((nW, lmax), nA, dtype=np.int64)
+    real = srt < nW
+    inv[srt[real], rank[real]] = order[real]
+    maps = {"idx": torch.from_numpy(idx.astype(np.int32)).to(device), "inv": torch.from_numpy(inv.astype(np.int32)).to(device),
+            "sub": torch.from_numpy(sub).to(device), "keep": torch.from_numpy(keep.astype(np.float32)).to(device)}
+    _FUSED_MAPS[key] = maps
+    return maps
+
+
+class _GatherW2(torch.autograd.Function):
+    """A = [W2.flatten(), 0][idx] with a deterministic, atomics-free backward (gather through the inverse map + sum)."""
+
+    @staticmethod
+    def forward(ctx, w2, idx, inv):
+        ctx.save_for_backward(inv)
+        ctx.shape = w2.shape
+        return torch.cat((w2.reshape(-1), w2.new_zeros(1))).index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, gA):
+        inv, = ctx.saved_tensors
+        ge = torch.cat((gA.reshape(-1), gA.new_zeros(1)))
+        return ge.index_select(0, inv.reshape(-1)).view(inv.shape).sum(1).view(ctx.shape), None, None
+
+
+def fused_upnet_operator(w0, b0, w2, b2):
+    """The same operators as `fused_upnet_weights`, as ONE gather + ONE matrix product in the parameters' dtype (differentiable: a handful of
+    launches forward and backward) — what a training step builds per weight set.  Returns (ring layout [9, 12, 25, G0], [9, 12]);
+    operator v as a convolution weight is `out[v].permute(0, 2, 1).reshape(12, G0, 5, 5)`."""
+    m = _fused_upnet_maps(w0.device)
+    g0 = w0.shape[1]
+    A = _GatherW2.apply(w2, m["idx"], m["inv"]).view(9 * 12 * 25, 64 * 2 * 2 * 9)
+    w0p = w0.view(64, 2, 2, g0, 3, 3).permute(0, 1, 2, 4, 5, 3).reshape(64 * 2 * 2 * 9, g0)
+    W = (A @ w0p).view(9, 12, 25, g0)
+    sub, keep = m["sub"], m["keep"].to(w0.dtype)
+    tb = torch.einsum("ckyx,kpq->cyxpq", w2, b0.view(64, 2, 2))                      # [c, dy, dx, i', j']
+    tg = tb[:, :, :, sub.reshape(-1)].view(3, 3, 3, 2, 3, 2)                          # [c, dy, dx, i, dy', j'] -> take dy' == dy below
+    tg = torch.diagonal(tg, dim1=1, dim2=4)                                           # [c, dx, i, j', dy]
+    tg = tg[:, :, :, sub.reshape(-1)].reshape(3, 3, 2, 2, 3, 3)                       # [c, dx, i, j, dx', dy]
+    tg = torch.diagonal(tg, dim1=1, dim2=4)                                           # [c, i, j, dy, dx]
+    B = b2.view(1, 1, 3, 1, 1) + torch.einsum("cijyx,viy,wjx->vwcij", tg, keep, keep)
+    return W, B.reshape(9, 12)
+
+
 def fused_upnet_reference(x, W, B):
     """Plain-torch statement of what the fused UPNet computes from `fused_upnet_weights` (tests; the device path is
     BINHIP_PLAN_FUSED_UPNET): the interior operator everywhere, then the full-resolution border ring from its own variants."""
@@ -115,10 +214,25 @@ class RdnWeights:
         self._up_src = tuple(params[f"{prefix}UPNet.{k}.{t}"] for k in (0, 2) for t in ("weight", "bias"))
         self.fused_up = None
         self.fused_w4 = None
+        self.fused_graph = None
 
-    def ensure_fused_upnet(self):
+    def ensure_fused_upnet(self, train=False):
         """(ConvWeights of the [12][G0][5][5] interior operator, fp32 [9][12][25][G0] ring operators, fp32 [9][12] ring biases) or None when
-        this weight set's UPNet is not the 256 -> shuffle -> 3 one."""
+        this weight set's UPNet is not the 256 -> shuffle -> 3 one.  `train`: build them with `fused_upnet_operator` under autograd and
+        keep the graph (`fused_graph` = leaves, operators, biases): the backward maps the operators' gradients to UPNet.0 / UPNet.2."""
+        if self.fused_up is None and self._up_src is not None and train:
+            w0, b0, w2, b2 = self._up_src
+            if tuple(w0.shape[2:]) == (3, 3) and w0.shape[0] == 256 and tuple(w2.shape) == (3, 64, 3, 3):
+                with torch.enable_grad():
+                    leaves = [t.detach().float().requires_grad_() for t in (w0, b0, w2, b2)]
+                    Wr, Br = fused_upnet_operator(*leaves)
+                self.fused_graph = (leaves, Wr, Br)
+                with torch.no_grad():
+                    g0 = Wr.shape[3]
+                    self.fused_w4 = Wr[4].permute(0, 2, 1).reshape(12, g0, 5, 5).contiguous()
+                    main = ConvWeights(self.fused_w4, Br[4].detach().contiguous(), nterms=self.nterms)
+                    self.fused_up = (main, Wr.detach().contiguous(), Br.detach().contiguous())
+            self._up_src = None
         if self.fused_up is None and self._up_src is not None:
             with torch.no_grad():
                 w0, b0, w2, b2 = self._up_src
