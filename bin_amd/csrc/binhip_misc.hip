@@ -879,7 +879,8 @@ __global__ void __launch_bounds__(256) upnet_ring_wgrad_kernel(const RingBwdArgs
     const int sub = id & 3, var = id >> 2;
     const int vy = var / 3, vx = var - 3 * vy, i = sub >> 1, j = sub & 1;
     const int ty = tap / 5 - 2, tx = tap % 5 - 2;
-    const int ci = threadIdx.x, sl = threadIdx.y, S = blockDim.y;      // S slices of the pixel walk per channel (256 / cin of them)
+    const int ci = threadIdx.x, sl = threadIdx.y, S = blockDim.y;      // S slices of the pixel walk per channel (256 / cin of them; 1024-thread
+    // workgroups measured slower in the step: the kernel shares the chip with the backward-data chain)
     // the pixels (Y, X) of this variant with parity (i, j): a border row / column has ONE parity (row 0: i = 0, row 2H - 1: i = 1), the
     // free coordinate of an edge runs over [1, L - 2] in steps of two
     int Y0, Y1, X0, X1;      // inclusive ranges, step 2; an empty range has Y0 > Y1 (X0 > X1)

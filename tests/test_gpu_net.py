@@ -707,25 +707,48 @@ def test_fused_upnet_equals_the_two_layer_form(k, nhw, canon_cpu):
     assert float(d.max()) <= 2e-6 * max(1.0, float(two.abs().max()))
 
 
-def test_fused_upnet_is_inference_only(canon_cpu):
-    """A differentiable call keeps the two layers (their activations and separate weight gradients are what the backward needs): the training
-    forward gives what it gave before.  The single-product mode fuses too; there the two forms differ by the mode's own fp16 rounding."""
+def test_fused_upnet_in_training_and_in_the_single_product_mode(canon_cpu, monkeypatch):
+    """Training runs the fused UPNet too (BINHIP_PLAN_FUSED_UPNET_TRAIN / BINHIP_BWD_FUSED_UPNET): its forward is the inference forward up to
+    how the operators were built (fp32 matrix product per step against the float64 einsum of inference), UPNet.0 and UPNet.2 receive their
+    gradients through the operator's chain rule, and BIN_AMD_FUSED_UPNET_TRAIN=0 brings the two-layer training path back bit for bit.
+    The single-product mode fuses as well; there the two forms differ by the mode's own fp16 rounding."""
     from bin_amd import _lib as L
     from bin_amd.models.archs import RDN as A
     from bin_amd.weights import rdn_param_shapes
-    mod = A.RDN_residual_interp_2_input(G0=96, D=12)
-    mod.load_state_dict({n: canon_cpu[f"model1.{n}"] for n in rdn_param_shapes(2)})
-    mod = mod.cuda()
+
+    def make():
+        m = A.RDN_residual_interp_2_input(G0=96, D=12)
+        m.load_state_dict({n: canon_cpu[f"model1.{n}"] for n in rdn_param_shapes(2)})
+        m = m.cuda()
+        m.precision = "f16x3"
+        return m
     gen = torch.Generator().manual_seed(6)
     ins = [torch.rand(1, 3, 32, 48, generator=gen).cuda() for _ in range(2)]
-    mod.precision = "f16x3"
-    out = mod(*ins)                                                  # grad mode: KEEP_ACTS
+    mod = make()
+    out = mod(*ins)                                                  # grad mode: KEEP_ACTS + the fused UPNet
     out.sum().backward()
-    assert mod.UPNet[0].weight.grad is not None and mod.UPNet[2].weight.grad is not None
+    g_fused = [mod.UPNet[0].weight.grad.clone(), mod.UPNet[0].bias.grad.clone(), mod.UPNet[2].weight.grad.clone(), mod.UPNet[2].bias.grad.clone()]
     with torch.no_grad():
+        inf = mod(*ins)
         mod.plan_flags &= ~L.PLAN_FUSED_UPNET
         two = mod(*ins)
-    assert torch.equal(out.detach(), two)                            # the training forward IS the two-layer forward
+    assert float((out.detach() - inf).abs().max()) <= 5e-7 and float((out.detach() - two).abs().max()) <= 2e-6
+    monkeypatch.setenv("BIN_AMD_FUSED_UPNET_TRAIN", "0")
+    ref = make()
+    out2 = ref(*ins)
+    out2.sum().backward()
+    assert torch.equal(out2.detach(), two)                           # the two-layer training forward IS the two-layer inference forward
+    g_two = [ref.UPNet[0].weight.grad, ref.UPNet[0].bias.grad, ref.UPNet[2].weight.grad, ref.UPNet[2].bias.grad]
+    for nm, a, b in zip(("UPNet.0.weight", "UPNet.0.bias", "UPNet.2.weight", "UPNet.2.bias"), g_fused, g_two):
+        rel = float((a - b).abs().max() / b.abs().max())
+        print(f"{nm}: fused vs two-layer gradient, relative {rel:.2e}")
+        assert rel <= 2e-5, (nm, rel)
+    other = float(max((p.grad - q.grad).abs().max() / q.grad.abs().max().clamp_min(1e-20)
+                      for (n, p), (_, q) in zip(mod.named_parameters(), ref.named_parameters()) if not n.startswith("UPNet")))
+    print(f"every other parameter: {other:.2e}")
+    assert other <= 2e-5
+    monkeypatch.delenv("BIN_AMD_FUSED_UPNET_TRAIN")
+    mod.plan_flags &= ~L.PLAN_FUSED_UPNET                            # (still off from above: `a` below is the two-layer form)
     mod.precision = "f16"
     with torch.no_grad():
         a = mod(*ins)
