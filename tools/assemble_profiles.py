@@ -78,7 +78,7 @@ Command on the GPU box (`tools/gpu.sh "kt x3 ..."`, see the header of `tools/ass
 `export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/x3 -o kt -- python bench.py --steps 3
 --warmup 1 --no-cpu-baseline --no-extras --no-power` (default precision f16x3, default schedule = 1 stream, 17 RDN calls per window).  The run
 holds 8 forwards (1 warm-up + 3 timed + 1 + 3 of the serial roofline leg); per forward 612 dense-block conv launches (`{DOM_X3}`), 204
-fused tails, 34 wide 3x3 layers, 17 each of UPNet.0, UPNet.2, GFF.0, SFENet1.  bench.py's line in the same (profiled) run: {bp['value']} frames/s,
+fused tails, 34 wide 3x3 layers, 17 each of GFF.0, SFENet1 and the fused UPNet (`conv_x3_kernel<5, 2, 8, 4, 0, false>` + `upnet_ring_kernel`: round 6, one 5x5 convolution on 12 sub-pixel channels instead of UPNet.0 + UPNet.2).  bench.py's line in the same (profiled) run: {bp['value']} frames/s,
 {bp['ms_per_step']} ms / window, live HIP-event average of the dominant kernel {bp['roofline']['avg_kernel_us']} us.  Un-profiled on the same box
 (`{R}_bench_f16x3.json`): **{b['value']} frames/s, {b['ms_per_step']} ms / window**, dominant kernel {roof['avg_kernel_us']} us by events,
 {xcd(b.get('power'))} MHz (per-XCD mean; amdsmi's GFX clk = XCD 0 alone: {mean(b.get('power'), 'clock_mhz')}) at {(b.get('power') or {}).get('power_from_energy_w')} W by the energy
@@ -97,7 +97,7 @@ chunk of the 24- / 36-channel calls on tap pairs): {row(sx, 'conv_x3_kernel<5, 2
 
 ## f16 (tolerance mode: `--precision f16`, 3 streams in the timed region, serial in the roofline leg)
 
-UPNet.2 runs as `final_dot2_kernel<1>` here.
+UPNet runs fused here too (`conv_mfma_kernel<5, 1, 1, 2, 8, 1, 1, 2, 4, false>` + `upnet_ring_kernel`).
 
 {sf.strip()}
 """)
