@@ -873,14 +873,17 @@ __global__ void __launch_bounds__(256) upnet_ring_dgrad_kernel(const RingBwdArgs
 __global__ void __launch_bounds__(256) upnet_ring_wgrad_kernel(const RingBwdArgs a) {
     const int H = a.H, W = a.W, H2 = 2 * H, W2 = 2 * W, cin = a.cin;
     int id = blockIdx.x;
+    const int ncg = (cin + 31) >> 5;                   // 32 input channels per workgroup
+    const int cg = id % ncg; id /= ncg;
     const int n = id / (9 * 4 * 25);                   // one image per workgroup: per-image partials, summed by the caller (deterministic)
     id -= n * (9 * 4 * 25);
     const int tap = id % 25; id /= 25;
     const int sub = id & 3, var = id >> 2;
     const int vy = var / 3, vx = var - 3 * vy, i = sub >> 1, j = sub & 1;
     const int ty = tap / 5 - 2, tx = tap % 5 - 2;
-    const int ci = threadIdx.x, sl = threadIdx.y, S = blockDim.y;      // S slices of the pixel walk per channel (256 / cin of them; 1024-thread
-    // workgroups measured slower in the step: the kernel shares the chip with the backward-data chain)
+    const int ci = cg * 32 + threadIdx.x, sl = threadIdx.y, S = blockDim.y;      // 8 slices of the pixel walk per channel (an edge of 127 pixels = 16 per
+    // thread; with cin x 2 threads and 64 pixels per thread the launch took 359 us; 1024-thread workgroups measured slower in the step:
+    // the kernel shares the chip with the backward-data chain)
     // the pixels (Y, X) of this variant with parity (i, j): a border row / column has ONE parity (row 0: i = 0, row 2H - 1: i = 1), the
     // free coordinate of an edge runs over [1, L - 2] in steps of two
     int Y0, Y1, X0, X1;      // inclusive ranges, step 2; an empty range has Y0 > Y1 (X0 > X1)
@@ -893,10 +896,9 @@ __global__ void __launch_bounds__(256) upnet_ring_wgrad_kernel(const RingBwdArgs
     const bool none = (var == 4);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
     if (!none && ci < cin) {
-            int pix = 0;
-            for (int Y = Y0; Y <= Y1; Y += 2)
-                for (int X = X0; X <= X1; X += 2, ++pix) {
-                    if (pix % S != sl) continue;
+            const int ny = Y1 >= Y0 ? (Y1 - Y0) / 2 + 1 : 0, nx = X1 >= X0 ? (X1 - X0) / 2 + 1 : 0;
+            for (int pix = sl; pix < ny * nx; pix += S) {
+                    const int Y = Y0 + 2 * (pix / nx), X = X0 + 2 * (pix % nx);
                     const float g0 = a.g[(((long long)n * 3 + 0) * H2 + Y) * W2 + X];
                     const float g1 = a.g[(((long long)n * 3 + 1) * H2 + Y) * W2 + X];
                     const float g2 = a.g[(((long long)n * 3 + 2) * H2 + Y) * W2 + X];
@@ -911,13 +913,13 @@ __global__ void __launch_bounds__(256) upnet_ring_wgrad_kernel(const RingBwdArgs
     }
     __shared__ float red[6][256];
     {
-        const int t = sl * blockDim.x + ci;
+        const int t = sl * blockDim.x + threadIdx.x;
         red[0][t] = s0; red[1][t] = s1; red[2][t] = s2; red[3][t] = b0; red[4][t] = b1; red[5][t] = b2;
     }
     __syncthreads();
     if (sl != 0) return;
     for (int q = 1; q < S; ++q) {                       // fixed order: deterministic
-        const int t = q * blockDim.x + ci;
+        const int t = q * blockDim.x + threadIdx.x;
         s0 += red[0][t]; s1 += red[1][t]; s2 += red[2][t]; b0 += red[3][t]; b1 += red[4][t]; b2 += red[5][t];
     }
     if (ci < cin) {
@@ -927,7 +929,7 @@ __global__ void __launch_bounds__(256) upnet_ring_wgrad_kernel(const RingBwdArgs
             a.dwvar[(((((long long)n * 9 + var) * 12 + 4 * c + sub) * 25 + tap) * cin) + ci] = sv[c];
         }
     }
-    if (tap == 0 && ci == 0) {
+    if (tap == 0 && ci == 0) {                            // (channel group 0, thread 0)
         const float bv[3] = {b0, b1, b2};
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -968,8 +970,8 @@ int bh_upnet_ring_wgrad(const float* g, const void* x_hi, const void* x_lo, floa
     RingBwdArgs a;
     if (!x_hi || !dwvar || !dbvar) return BINHIP_E_ARG;
     if (int rc = ring_bwd_args(a, g, nullptr, nullptr, x_hi, x_lo, nullptr, nullptr, dwvar, dbvar, nullptr, N, H, W, cin, accumulate)) return rc;
-    const int S = 256 / cin > 0 ? 256 / cin : 1;
-    upnet_ring_wgrad_kernel<<<dim3((unsigned)(9 * 4 * 25 * N)), dim3((unsigned)cin, (unsigned)S), 0, s>>>(a);
+    const int ncg = (cin + 31) / 32;
+    upnet_ring_wgrad_kernel<<<dim3((unsigned)(9 * 4 * 25 * N * ncg)), dim3(32, 8), 0, s>>>(a);
     BH_CHECK_LAUNCH();
     return 0;
 }
