@@ -825,7 +825,10 @@ def train_roofline(batch, size, step_s, prec, bwd_prec, kern, kern_overlapped=No
     prod_f, prod_b = PRODUCTS[prec], (1 if bwd_prec else PRODUCTS[prec])
     executed = (prod_f + 2.0 * prod_b) / 3.0 * flops
     out = {"algorithmic_TFLOP_per_step": round(flops / 1e12, 2), "algorithmic_GB_per_step": round(byts / 1e9, 1),
-           "note": "3 x the 17-call forward of one 6-frame sample (SURVEY 8d layer model) x batch; bytes at the storage width",
+           "note": "3 x the 17-call forward of one 6-frame sample (SURVEY 8d layer model: the reference's layer list) x batch; bytes at the storage "
+                   "width.  The step executes somewhat less: UPNet runs fused, forward and backward (one 5x5 convolution on 12 sub-pixel channels "
+                   "instead of conv3x3 96->256 + conv3x3 64->3: 8 % of a call's multiply-adds become 1 %), so the whole-step rates are "
+                   "reference-equivalent work per second, an upper reading of the executed rate",
            "mfma": {"achieved": round(executed / step_s / 1e12, 1), "peak": MFMA_PEAK_TF, "unit": "TFLOP/s",
                     "frac": round(executed / step_s / 1e12 / MFMA_PEAK_TF, 4),
                     "algorithmic_TFLOPs": round(flops / step_s / 1e12, 1)},
