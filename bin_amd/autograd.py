@@ -169,8 +169,8 @@ class _RdnFn(torch.autograd.Function):
             plan.reserved |= L.BWD_FUSED_UPNET
             up_dw4 = torch.empty((12, g0, 5, 5), dtype=torch.float32, device=dev)
             up_db4 = torch.empty((12,), dtype=torch.float32, device=dev)
-            up_dwr = torch.empty((n, 9, 12, 25, g0), dtype=torch.float32, device=dev)
-            up_dbr = torch.empty((n, 9, 12), dtype=torch.float32, device=dev)
+            up_dwr = torch.zeros((n, 9, 12, 25, g0), dtype=torch.float32, device=dev)      # (the kernel writes the 12 pairs with ring pixels)
+            up_dbr = torch.zeros((n, 9, 12), dtype=torch.float32, device=dev)
             plan.dw[nl], plan.db[nl], plan.dw[nl + 1], plan.db[nl + 1] = (up_dw4.data_ptr(), up_db4.data_ptr(), up_dwr.data_ptr(),
                                                                         up_dbr.data_ptr())
         gins = []

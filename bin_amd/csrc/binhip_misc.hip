@@ -875,10 +875,12 @@ __global__ void __launch_bounds__(256) upnet_ring_wgrad_kernel(const RingBwdArgs
     int id = blockIdx.x;
     const int ncg = (cin + 31) >> 5;                   // 32 input channels per workgroup
     const int cg = id % ncg; id /= ncg;
-    const int n = id / (9 * 4 * 25);                   // one image per workgroup: per-image partials, summed by the caller (deterministic)
-    id -= n * (9 * 4 * 25);
+    const int n = id / (12 * 25);                      // one image per workgroup: per-image partials, summed by the caller (deterministic)
+    id -= n * (12 * 25);
     const int tap = id % 25; id /= 25;
-    const int sub = id & 3, var = id >> 2;
+    // the twelve (variant, sub-pixel) pairs that have ring pixels: an edge row / column carries one parity of its fixed coordinate and both
+    // of the running one, a corner one pair.  The caller zero-fills the buffers: the other 24 pairs (and variant 4) stay zero.
+    const int var = (int)((0x862055337711ull >> (4 * id)) & 15), sub = (int)((0x321031203210ull >> (4 * id)) & 3);   // (1,0) (1,1) (7,2) (7,3) (3,0) (3,2) (5,1) (5,3) + corners
     const int vy = var / 3, vx = var - 3 * vy, i = sub >> 1, j = sub & 1;
     const int ty = tap / 5 - 2, tx = tap % 5 - 2;
     const int ci = cg * 32 + threadIdx.x, sl = threadIdx.y, S = blockDim.y;      // 8 slices of the pixel walk per channel (an edge of 127 pixels = 16 per
@@ -971,7 +973,7 @@ int bh_upnet_ring_wgrad(const float* g, const void* x_hi, const void* x_lo, floa
     if (!x_hi || !dwvar || !dbvar) return BINHIP_E_ARG;
     if (int rc = ring_bwd_args(a, g, nullptr, nullptr, x_hi, x_lo, nullptr, nullptr, dwvar, dbvar, nullptr, N, H, W, cin, accumulate)) return rc;
     const int ncg = (cin + 31) / 32;
-    upnet_ring_wgrad_kernel<<<dim3((unsigned)(9 * 4 * 25 * N * ncg)), dim3(32, 8), 0, s>>>(a);
+    upnet_ring_wgrad_kernel<<<dim3((unsigned)(12 * 25 * N * ncg)), dim3(32, 8), 0, s>>>(a);
     BH_CHECK_LAUNCH();
     return 0;
 }

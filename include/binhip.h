@@ -374,7 +374,7 @@ BINHIP_API int binhip_convlstm_bwd(const float* x, const float* c_prev, const fl
                                    * wt_hi / wt_lo[L] = binhip_weights_relayout_dgrad of the [12][G0][5][5] interior operator, wt_hi[L + 1] = the fp32
                                    * [9][12][25][G0] ring operators; results: dw[L] / db[L] = fp32 [12][G0][5][5] / [12] gradient of the interior
                                    * operator (always WRITTEN, never accumulated), dw[L + 1] / db[L + 1] = fp32 [N][9][12][25][G0] / [N][9][12]
-                                   * per-image gradients of the ring operators (variant 4 zero).  dw / db of UPNet.0 and UPNet.2 are NOT written:
+                                   * per-image gradients of the ring operators: the caller ZERO-FILLS both, the kernel writes the entries that have ring pixels.  dw / db of UPNet.0 and UPNet.2 are NOT written:
                                    * the caller maps the operator gradients to them (autograd of rdn_plan.fused_upnet_weights).               */
 #define BINHIP_BWD_SAVED_X3   2   /* `saved` has the nterms = 3 layout while this plan's nterms is 1: a single-product
                                    * backward behind the fp32-class forward (exact loss and ReLU masks, ~1e-3 relative
